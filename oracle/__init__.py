@@ -1,0 +1,6 @@
+"""CPU restatement of the lyd405121/wcsph hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package, and only as the checker / reported baseline.  PARITY UNPINNED (see wcsph_ref.c).
+"""
+from .oracle import Oracle, build_oracle  # noqa: F401

@@ -1,0 +1,191 @@
+"""ctypes front-end of oracle/wcsph_ref.c (TEST INFRASTRUCTURE ONLY, parity unpinned).
+
+The class mirrors the reference objects a driver script touches: the ParticleData /
+HashGrid fields (numpy views on the C arrays, original particle order, liquid first) and
+the zero-argument step functions of dfsph.py / sesph.py under their reference names.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libwcsph_oracle.so")
+
+_SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
+            "tension_coff", "tension_coff_b", "VL0", "VS0", "liqiudMass", "searchR", "gridR", "invGridR", "rho_L0",
+            "viscosity_err", "vorticity_coff", "viscosity_omega", "vorticity_init"]
+_INTS = ["vs_iter", "dv_iter", "pr_iter", "overflow_grid", "overflow_neighbor", "table_size", "bs0", "bs1", "bs2",
+         "tension_fixed", "mode"]
+_VEC3 = ["vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s"]
+_SCAL = ["rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v"]
+_STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff", "update_drho_divergence",
+          "update_drho_pressure", "warmstart_divergence_vel", "begin_divergence_iter", "divergence_iter",
+          "end_divergence_iter", "warmstart_pressure", "begin_pressure_iter", "pressure_iter", "end_pressure_iter",
+          "clear_nonpressure", "compute_tension", "init_viscosity_para", "compute_viscosity_force", "end_viscosity",
+          "compute_vorticity", "cfl_reduce", "optimize_time_step", "update_vel", "update_pos",
+          "compute_nonpressure_force", "solve_vel_divergence", "solve_pressure", "dfsph_step",
+          "sesph_reset_param", "sesph_update_advection_density", "sesph_update_pressure", "sesph_compute_force",
+          "sesph_integrate", "sesph_step"]
+
+
+def build_oracle(force=False):
+    """Compile oracle/wcsph_ref.c with gcc (oracle/Makefile). Returns the .so path."""
+    src = os.path.join(_HERE, "wcsph_ref.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        lib = C.CDLL(build_oracle())
+        lib.orc_create.restype = C.c_void_p
+        lib.orc_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
+        lib.orc_destroy.argtypes = [C.c_void_p]
+        lib.orc_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_setup.restype = C.c_int
+        lib.orc_cell_hash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.orc_cell_hash.restype = C.c_int
+        lib.orc_cell_of.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.orc_W_norm.argtypes = [C.c_void_p, C.c_float]
+        lib.orc_W_norm.restype = C.c_float
+        lib.orc_coh_W.argtypes = [C.c_void_p, C.c_float]
+        lib.orc_coh_W.restype = C.c_float
+        lib.orc_adh_W.argtypes = [C.c_void_p, C.c_float]
+        lib.orc_adh_W.restype = C.c_float
+        lib.orc_gradW.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_sesph_init.argtypes = [C.c_void_p, C.c_double]
+        lib.orc_get_scalar.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_get_scalar.restype = C.c_float
+        lib.orc_set_scalar.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        lib.orc_get_int.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_get_int.restype = C.c_int
+        lib.orc_set_int.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for s in _STEPS:
+            getattr(lib, "orc_" + s).argtypes = [C.c_void_p]
+            getattr(lib, "orc_" + s).restype = None
+        for f in _VEC3 + _SCAL + ["pos", "cg_Minv"]:
+            getattr(lib, "orc_ptr_" + f).argtypes = [C.c_void_p]
+            getattr(lib, "orc_ptr_" + f).restype = C.POINTER(C.c_float)
+        for f in ["gridCount", "grid", "neighborCount", "neighbor"]:
+            getattr(lib, "orc_ptr_" + f).argtypes = [C.c_void_p]
+            getattr(lib, "orc_ptr_" + f).restype = C.POINTER(C.c_int)
+        _lib = lib
+    return _lib
+
+
+class Oracle:
+    """One reference simulation state.
+
+    Oracle(pos, n_liquid, particleR, mode) follows ParticleData(particleR) + add_*_point
+    for every row of `pos` (liquid rows first) + setup_data_gpu/cpu
+    (ref: ParticleData.py:12-185, HashGrid.py:10-54).
+    mode: "faithful" (reference hash table, bucket multiset) or "clean" (collision-free).
+    """
+
+    def __init__(self, pos, n_liquid, particleR=0.025, mode="faithful", maxInGrid=64, maxNeighbour=2048,
+                 bounds=None):
+        lib = _load()
+        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        n = pos.shape[0]
+        d = self.__dict__
+        d["lib"] = lib
+        d["count"], d["liquid_count"], d["solid_count"] = n, int(n_liquid), n - int(n_liquid)
+        d["maxInGrid"], d["maxNeighbour"] = maxInGrid, maxNeighbour
+        d["h"] = lib.orc_create(self.liquid_count, self.solid_count, float(particleR), maxInGrid, maxNeighbour,
+                                0 if mode == "faithful" else 1)
+        if bounds is None:  # running bbox of every added point, f32 (ParticleData.py:100-126)
+            maxb, minb = pos.max(axis=0), pos.min(axis=0)
+        else:
+            maxb, minb = bounds
+        d["maxboundarynp"] = np.ascontiguousarray(maxb, dtype=np.float32).reshape(1, 3)
+        d["minboundarynp"] = np.ascontiguousarray(minb, dtype=np.float32).reshape(1, 3)
+        rc = lib.orc_setup(self.h, pos.ctypes.data, self.maxboundarynp.ctypes.data, self.minboundarynp.ctypes.data)
+        if rc != 0:
+            raise MemoryError("oracle table allocation failed")
+        nl = self.liquid_count
+        d["pos"] = self._view("pos", (n, 3))
+        for f in _VEC3:
+            d[f] = self._view(f, (nl, 3))
+        for f in _SCAL:
+            d[f] = self._view(f, (nl,))
+        d["cg_Minv"] = self._view("cg_Minv", (nl, 3, 3))
+        d["neighborCount"] = self._view("neighborCount", (nl,), np.int32)
+        d["neighbor"] = self._view("neighbor", (nl, maxNeighbour), np.int32)
+        ts = self.table_size
+        d["gridCount"] = self._view("gridCount", (ts,), np.int32)
+        d["grid"] = self._view("grid", (ts, maxInGrid), np.int32)
+        for s in _STEPS:
+            d[s] = (lambda fn: (lambda: fn(self.h)))(getattr(lib, "orc_" + s))
+
+    def _view(self, name, shape, dtype=np.float32):
+        p = getattr(self.lib, "orc_ptr_" + name)(self.h)
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype)
+        ct = C.c_float if dtype == np.float32 else C.c_int
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).reshape(shape)
+
+    def __getattr__(self, name):
+        if name in _SCALARS:
+            return float(self.lib.orc_get_scalar(self.h, _SCALARS.index(name)))
+        if name in _INTS:
+            return int(self.lib.orc_get_int(self.h, _INTS.index(name)))
+        raise AttributeError(name)
+
+    def __setattr__(self, name, v):
+        if name in _SCALARS:
+            self.lib.orc_set_scalar(self.h, _SCALARS.index(name), float(v))
+        elif name in ("vs_iter", "dv_iter", "pr_iter", "tension_fixed"):
+            self.lib.orc_set_int(self.h, _INTS.index(name), int(v))
+        elif name in self.__dict__ and isinstance(self.__dict__[name], np.ndarray):
+            self.__dict__[name][...] = v  # field assignment copies into the C array
+        else:
+            object.__setattr__(self, name, v)
+
+    @property
+    def blockSize(self):
+        return (self.bs0, self.bs1, self.bs2)
+
+    def cell_hash(self, x, y, z):
+        return int(self.lib.orc_cell_hash(self.h, int(x), int(y), int(z)))
+
+    def cell_of(self, i):
+        out = np.zeros(3, np.int32)
+        self.lib.orc_cell_of(self.h, int(i), out.ctypes.data)
+        return out
+
+    def W_norm(self, r):
+        return float(self.lib.orc_W_norm(self.h, float(r)))
+
+    def gradW(self, r):
+        r = np.ascontiguousarray(r, np.float32)
+        out = np.zeros(3, np.float32)
+        self.lib.orc_gradW(self.h, r.ctypes.data, out.ctypes.data)
+        return out
+
+    def coh_W(self, r):
+        return float(self.lib.orc_coh_W(self.h, float(r)))
+
+    def adh_W(self, r):
+        return float(self.lib.orc_adh_W(self.h, float(r)))
+
+    def sesph_init(self, particleRadius=0.025):
+        self.lib.orc_sesph_init(self.h, float(particleRadius))
+
+    def close(self):
+        if self.__dict__.get("h"):
+            self.lib.orc_destroy(self.h)
+            self.__dict__["h"] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

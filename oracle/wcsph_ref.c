@@ -1,0 +1,851 @@
+/*
+ * oracle/wcsph_ref.c -- CPU restatement of the lyd405121/wcsph per-particle hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under wcsph_amd/ may import, link or call this
+ * file; it is used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * as the CHECKER (and as the reported CPU baseline), never as the product path.
+ *
+ * PARITY UNPINNED: the reference is Python+Taichi, ships no tests / golden vectors and
+ * cannot be imported in the build container (no taichi wheel).  This file follows the
+ * reference sources line by line (citations "ref: file:line" are into /root/reference)
+ * and is pinned only by the analytic known-answers in tests/test_oracle_known_answers.py
+ * (kernel normalisation, lattice density 799.978, alpha, gradW samples, int32-wrap hash
+ * values, default-scene blockSize).
+ *
+ * Semantics encoded: f32 / i32 arithmetic, float->int truncation
+ * toward zero, int32 wrap-around multiply in the hash, every top-level Taichi `for` is
+ * one parallel loop (here: an OpenMP loop or a serial loop), scalar `+=` inside a
+ * parallel loop is a reduction (here: accumulated in double, stored as f32).
+ *
+ * neighbour modes:
+ *   mode 0  "faithful": hash table with `count` buckets, ref hash, bucket multiset
+ *           (aliasing cells => duplicated / far list entries), HashGrid.py:56-114.
+ *   mode 1  "clean":    the same walk with a collision-free hash (bucket == cell), i.e.
+ *           every particle of the 5x5x5 in-box cells exactly once.
+ *
+ * Build: gcc -O2 -fopenmp -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float x, y, z; } v3;
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float nsq(v3 a) { return dot(a, a); }
+static inline v3 cross(v3 a, v3 b) {
+  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+typedef struct orc_ctx {
+  /* ---- ParticleData (ref: ParticleData.py:12-96) ---- */
+  int count, liquid_count, solid_count;
+  float rho_L0, rho_S0, VL0, VS0, liqiudMass;
+  v3 gravity;
+  float dim_coff, viscosity, viscosity_b, viscosity_err;
+  float tension_coff, tension_coff_b;
+  float viscosity_omega, vorticity_coff, vorticity_init;
+  float eps;
+  int tension_fixed; /* 0: Q8/Q9-faithful normals (garbage), 1: fixed normals n = h*sum */
+  v3 *pos;                                              /* [count] */
+  v3 *vel, *vel_guess, *d_vel, *omega, *d_omega, *normal; /* [liquid] */
+  float *rho, *adv_rho, *pressure, *vel_max;            /* [liquid] */
+  float *cg_Minv;                                       /* [liquid*9] row-major */
+  v3 *cg_r, *cg_dir, *cg_Ad, *cg_s;
+  float avg_density_err, cg_delta, cg_delta_old, cg_delta_zero;
+  /* ---- dfsph.py module globals (ref: dfsph.py:42-48) ---- */
+  float *alpha_coff, *kappa, *kappa_v;
+  float deltaT;
+  int vs_iter, dv_iter, pr_iter;
+  double particleRadius, user_max_t, user_min_t; /* python-scope doubles, dfsph.py:27,39-40 */
+  /* ---- HashGrid (ref: HashGrid.py:10-54) ---- */
+  int maxInGrid, maxNeighbour;
+  float gridR, invGridR, searchR;
+  double gridR_d; /* python-scope double used by setup_grid_cpu */
+  int blockSize[3];
+  v3 min_boundary, max_boundary;
+  int *gridCount, *grid, *neighborCount, *neighbor;
+  int table_size; /* faithful: count ; clean: number of cells */
+  int mode;
+  int overflow_grid, overflow_neighbor;
+  /* ---- CubicKernel constants (ref: kernels/CubicKernel.py:12-17) ---- */
+  float ck_h, ck_h3, ck_mk, ck_ml;
+  /* cohesion / adhesion (ref: kernels/CohesionKernel.py:12-15, AdhesionKernel.py:12-14) */
+  float coh_mk, coh_mc, adh_mk;
+  /* ---- sesph.py private state (ref: sesph.py:23-62) ---- */
+  float ss_searchR, ss_mk, ss_ml, ss_VL0, ss_VS0, ss_mass, ss_rho0, ss_stiff, ss_dim, ss_visc, ss_visc_b;
+} orc_ctx;
+
+/* ------------------------------------------------------------------------------------ */
+/* creation                                                                               */
+
+/* ref: ParticleData.py:12-31 (constants), HashGrid.py:10-19, kernels/ ctors.
+ * particleR is what the driver script passes to ParticleData(); dfsph passes the radius
+ * (dfsph.py:66), sesph passes the DIAMETER (sesph.py:71, quirk Q11). */
+orc_ctx *orc_create(int n_liquid, int n_solid, double particleR, int maxInGrid, int maxNeighbour, int mode) {
+  orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
+  c->liquid_count = n_liquid; c->solid_count = n_solid; c->count = n_liquid + n_solid;
+  c->rho_L0 = 1000.0f; c->rho_S0 = c->rho_L0;
+  c->VL0 = (float)((double)particleR * particleR * particleR * 0.8 * 8.0);
+  c->VS0 = c->VL0;
+  c->liqiudMass = (float)((double)c->VL0 * (double)c->rho_L0);
+  c->gravity = V(0.0f, -9.81f, 0.0f);
+  c->dim_coff = 10.0f; c->viscosity = 10.0f; c->viscosity_b = 10.0f; c->viscosity_err = 0.05f;
+  c->tension_coff = 0.0f; c->tension_coff_b = 0.0f;
+  c->viscosity_omega = 0.1f; c->vorticity_coff = 0.01f; c->vorticity_init = 0.5f;
+  c->eps = 1e-5f;
+  c->particleRadius = particleR; c->user_max_t = 0.005; c->user_min_t = 0.0001;
+  c->maxInGrid = maxInGrid; c->maxNeighbour = maxNeighbour; c->mode = mode;
+  double gridR = (double)particleR * 2.0;           /* HashGrid(particleR*2.0, ...) ParticleData.py:27 */
+  c->gridR_d = gridR; c->gridR = (float)gridR; c->invGridR = (float)(1.0 / gridR); c->searchR = (float)(gridR * 2.0);
+  double h = gridR * 2.0;
+  c->ck_h = (float)h; c->ck_h3 = (float)(1.0 / (h * h * h));
+  c->ck_mk = (float)(8.0 / M_PI); c->ck_ml = (float)(48.0 / M_PI);
+  c->coh_mk = (float)(32.0 / (M_PI * pow(h, 9.0))); c->coh_mc = (float)(pow(h, 6.0) / 64.0);
+  c->adh_mk = (float)(0.007 / pow(h, 3.25));
+  size_t nl = (size_t)n_liquid, n = (size_t)c->count;
+  c->pos = (v3 *)calloc(n, sizeof(v3));
+#define AL3(f) c->f = (v3 *)calloc(nl, sizeof(v3))
+#define AL1(f) c->f = (float *)calloc(nl, sizeof(float))
+  AL3(vel); AL3(vel_guess); AL3(d_vel); AL3(omega); AL3(d_omega); AL3(normal);
+  AL1(rho); AL1(adv_rho); AL1(pressure); AL1(vel_max);
+  c->cg_Minv = (float *)calloc(nl * 9, sizeof(float));
+  AL3(cg_r); AL3(cg_dir); AL3(cg_Ad); AL3(cg_s);
+  AL1(alpha_coff); AL1(kappa); AL1(kappa_v);
+  c->neighborCount = (int *)calloc(nl, sizeof(int));
+  c->neighbor = (int *)malloc(nl * (size_t)maxNeighbour * sizeof(int));
+  c->deltaT = 0.0f;
+  return c;
+}
+
+void orc_destroy(orc_ctx *c) {
+  if (!c) return;
+  free(c->pos); free(c->vel); free(c->vel_guess); free(c->d_vel); free(c->omega); free(c->d_omega);
+  free(c->normal); free(c->rho); free(c->adv_rho); free(c->pressure); free(c->vel_max); free(c->cg_Minv);
+  free(c->cg_r); free(c->cg_dir); free(c->cg_Ad); free(c->cg_s); free(c->alpha_coff); free(c->kappa);
+  free(c->kappa_v); free(c->neighborCount); free(c->neighbor); free(c->gridCount); free(c->grid);
+  free(c);
+}
+
+/* ref: ParticleData.py:180-185 + HashGrid.py:44-54.  pos is [count][3], liquid first.
+ * maxb/minb are the running bbox of every added point (ParticleData.py:100-126). */
+int orc_setup(orc_ctx *c, const float *pos, const float *maxb, const float *minb) {
+  memcpy(c->pos, pos, (size_t)c->count * sizeof(v3));
+  c->max_boundary = V(maxb[0], maxb[1], maxb[2]);
+  c->min_boundary = V(minb[0], minb[1], minb[2]);
+  for (int i = 0; i < 3; i++) /* int( (max-min)/gridR + 1 ): numpy f32 - f32, / python float => double */
+    c->blockSize[i] = (int)((double)(float)(maxb[i] - minb[i]) / c->gridR_d + 1.0);
+  long ncell = (long)c->blockSize[0] * c->blockSize[1] * c->blockSize[2];
+  c->table_size = (c->mode == 0) ? c->count : (int)ncell;
+  free(c->gridCount); free(c->grid);
+  c->gridCount = (int *)calloc((size_t)c->table_size, sizeof(int));
+  c->grid = (int *)malloc((size_t)c->table_size * (size_t)c->maxInGrid * sizeof(int));
+  return (c->gridCount && c->grid) ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* HashGrid                                                                               */
+
+/* ref: HashGrid.py:108-114 -- int32 wrap-around products, xor, normalised modulo. */
+static inline int cell_hash(const orc_ctx *c, int x, int y, int z) {
+  if (c->mode == 1) return (x * c->blockSize[1] + y) * c->blockSize[2] + z; /* clean: bucket == cell */
+  int32_t p1 = (int32_t)(73856093u * (uint32_t)x);
+  int32_t p2 = (int32_t)(19349663u * (uint32_t)y);
+  int32_t p3 = (int32_t)(83492791u * (uint32_t)z);
+  int32_t n = c->count;
+  return (int)((((p1 ^ p2 ^ p3) % n) + n) % n);
+}
+int orc_cell_hash(const orc_ctx *c, int x, int y, int z) { return cell_hash(c, x, y, z); }
+
+/* ref: HashGrid.py:117-124 */
+static inline int in_box(const orc_ctx *c, int x, int y, int z) {
+  return !(x < 0 || x >= c->blockSize[0] || y < 0 || y >= c->blockSize[1] || z < 0 || z >= c->blockSize[2]);
+}
+/* ref: HashGrid.py:68 -- ti.cast((pos - min) * invGridR, i32): f32 ops, truncation toward zero */
+static inline void cell_of(const orc_ctx *c, v3 p, int *x, int *y, int *z) {
+  *x = (int)((p.x - c->min_boundary.x) * c->invGridR);
+  *y = (int)((p.y - c->min_boundary.y) * c->invGridR);
+  *z = (int)((p.z - c->min_boundary.z) * c->invGridR);
+}
+void orc_cell_of(const orc_ctx *c, int i, int *xyz) { cell_of(c, c->pos[i], xyz, xyz + 1, xyz + 2); }
+
+/* ref: HashGrid.py:56-106.  The bucket insert is done serially in index order (the
+ * reference's slot order is atomic-schedule dependent, Q16; any order is "a" reference run). */
+void orc_update_grid(orc_ctx *c) {
+  const int MIG = c->maxInGrid, MN = c->maxNeighbour;
+  /* :58-64 full-table clears */
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)c->table_size; i++) {
+    c->gridCount[i] = 0;
+    for (int j = 0; j < MIG; j++) c->grid[i * MIG + j] = -1;
+  }
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)c->liquid_count; i++) {
+    c->neighborCount[i] = 0;
+    for (int j = 0; j < MN; j++) c->neighbor[i * MN + j] = -1;
+  }
+  /* :67-76 insert */
+  for (int i = 0; i < c->count; i++) {
+    int x, y, z; cell_of(c, c->pos[i], &x, &y, &z);
+    if (in_box(c, x, y, z)) {
+      int h = cell_hash(c, x, y, z);
+      int old = c->gridCount[h]++;
+      if (old > MIG - 1) { c->gridCount[h] = MIG; c->overflow_grid++; }
+      else c->grid[(long)h * MIG + old] = i;
+    }
+  }
+  /* :79-106 neighbour lists, liquid particles only */
+  int ovf = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : ovf)
+  for (int i = 0; i < c->liquid_count; i++) {
+    int x, y, z; cell_of(c, c->pos[i], &x, &y, &z);
+    if (!in_box(c, x, y, z)) continue;
+    int cnt = 0;
+    for (int m = -2; m < 3; m++) for (int n = -2; n < 3; n++) for (int q = -2; q < 3; q++) {
+      int cx = x + m, cy = y + n, cz = z + q;
+      if (!in_box(c, cx, cy, cz)) continue; /* :90-92 */
+      int h = cell_hash(c, cx, cy, cz);
+      int gc = c->gridCount[h];
+      for (int k = 0; k < gc; k++) {
+        int j = c->grid[(long)h * MIG + k];
+        if (j >= 0 && i != j) {
+          int old = cnt++;
+          if (old > MN - 1) ovf++;          /* :100-103 count keeps growing, entry dropped (Q3) */
+          else c->neighbor[(long)i * MN + old] = j;
+        }
+      }
+    }
+    c->neighborCount[i] = cnt;
+  }
+  c->overflow_neighbor += ovf;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* kernels (ref: kernels/CubicKernel.py:20-54, CohesionKernel.py:17-29, AdhesionKernel.py:20-29) */
+
+static inline v3 CubicGradW(const orc_ctx *c, v3 r) {
+  v3 res = V(0, 0, 0);
+  float rl = sqrtf(nsq(r));
+  float q = rl / c->ck_h;
+  if (rl > 1.0e-5f && q <= 1.0f) {
+    v3 gradq = mul(r, 1.0f / (rl * c->ck_h));
+    if (q <= 0.5f) res = mul(gradq, c->ck_ml * c->ck_h3 * q * (3.0f * q - 2.0f));
+    else { float f = 1.0f - q; res = mul(gradq, -c->ck_ml * c->ck_h3 * (f * f)); }
+  }
+  return res;
+}
+static inline float Cubic_W_P(float q) {
+  float res = 0.0f;
+  if (q <= 1.0f) {
+    if (q <= 0.5f) { float qq = q * q, qqq = qq * q; res = 6.0f * qqq - 6.0f * qq + 1.0f; }
+    else { float f = 1.0f - q; res = 2.0f * f * f * f; }
+  }
+  return res;
+}
+static inline float Cubic_W_norm(const orc_ctx *c, float r) { return Cubic_W_P(r / c->ck_h) * c->ck_mk * c->ck_h3; }
+static inline float Cubic_W(const orc_ctx *c, v3 r) { return Cubic_W_norm(c, sqrtf(nsq(r))); }
+
+static inline float Coh_W_norm(const orc_ctx *c, float r) {
+  float res = 0.0f, h = c->ck_h, radius2 = h * h, r2 = r * r;
+  if (r2 <= radius2) {
+    float r3 = r2 * r;
+    if (r > 0.5f * h) res = c->coh_mk * powf(h - r, 3.0f) * r3;
+    else res = c->coh_mk * 2.0f * powf(h - r, 3.0f) * r3 - c->coh_mc;
+  }
+  return res;
+}
+static inline float Adh_W_norm(const orc_ctx *c, float r) {
+  float res = 0.0f, h = c->ck_h, radius2 = h * h, r2 = r * r;
+  if (r2 <= radius2)
+    if (r > 0.5f * h) res = c->adh_mk * powf(-4.0f * r2 / h + 6.0f * r - 2.0f * h, 0.25f);
+  return res;
+}
+/* exported scalar probes for the known-answer tests */
+float orc_W_norm(const orc_ctx *c, float r) { return Cubic_W_norm(c, r); }
+void orc_gradW(const orc_ctx *c, const float *r, float *out) {
+  v3 g = CubicGradW(c, V(r[0], r[1], r[2])); out[0] = g.x; out[1] = g.y; out[2] = g.z;
+}
+float orc_coh_W(const orc_ctx *c, float r) { return Coh_W_norm(c, r); }
+float orc_adh_W(const orc_ctx *c, float r) { return Adh_W_norm(c, r); }
+
+#define NB_BEGIN(i)                                                        \
+  int cur_neighbor = c->neighborCount[i];                                  \
+  const int *nb_ = c->neighbor + (long)(i) * c->maxNeighbour;              \
+  for (int k = 0; k < cur_neighbor; k++) {                                 \
+    int j = nb_[k];                                                        \
+    v3 r = sub(c->pos[i], c->pos[j]);
+#define NB_END }
+#define PFOR _Pragma("omp parallel for schedule(static)")
+#define NL (c->liquid_count)
+
+/* ------------------------------------------------------------------------------------ */
+/* dfsph.py kernels                                                                       */
+
+/* ref: dfsph.py:167-178 */
+void orc_reset_param(orc_ctx *c) {
+  for (int i = 0; i < NL; i++) {
+    c->vel[i] = V(0, 0, 0); c->omega[i] = V(0, 0, 0);
+    c->pressure[i] = 0.0f; c->kappa_v[i] = 0.0f; c->kappa[i] = 0.0f;
+  }
+  c->deltaT = 0.001f;
+}
+
+/* ref: dfsph.py:248-262 */
+void orc_compute_density(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float rho = c->VL0 * Cubic_W_norm(c, 0.0f) * c->rho_L0;
+    NB_BEGIN(i)
+      if (j < NL) rho += c->VL0 * Cubic_W(c, r) * c->rho_L0;
+      else        rho += c->VS0 * Cubic_W(c, r) * c->rho_S0;
+    NB_END
+    c->rho[i] = rho;
+  }
+}
+
+/* ref: dfsph.py:345-372 */
+void orc_compute_dfsph_coff(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 sum_grad = V(0, 0, 0); float sum_grad_square = 0.0f;
+    NB_BEGIN(i)
+      v3 gradV = CubicGradW(c, r);
+      if (j < NL) { v3 t = mul(gradV, c->VL0); sum_grad_square += nsq(t); sum_grad = add(sum_grad, t); }
+      else sum_grad = add(sum_grad, mul(gradV, c->VS0));
+    NB_END
+    sum_grad_square += nsq(sum_grad);
+    c->alpha_coff[i] = (sum_grad_square > c->eps) ? -1.0f / sum_grad_square : 0.0f;
+  }
+}
+
+/* ref: dfsph.py:374-392 */
+static inline void update_drho_divergence(orc_ctx *c, int i) {
+  float a = 0.0f;
+  NB_BEGIN(i)
+    v3 gradV = CubicGradW(c, r);
+    if (j < NL) a += c->VL0 * dot(sub(c->vel[i], c->vel[j]), gradV);
+    else        a += c->VS0 * dot(c->vel[i], gradV);
+  NB_END
+  a = fmaxf(a, 0.0f);
+  if (cur_neighbor < 20) a = 0.0f;
+  c->adv_rho[i] = a;
+}
+/* ref: dfsph.py:394-412 (solid branch uses VL0, as in the reference) */
+static inline void update_drho_pressure(orc_ctx *c, int i) {
+  float temp = 0.0f;
+  NB_BEGIN(i)
+    v3 gradV = CubicGradW(c, r);
+    if (j < NL) temp += c->VL0 * dot(sub(c->vel[i], c->vel[j]), gradV);
+    else        temp += c->VL0 * dot(c->vel[i], gradV);
+  NB_END
+  float a = c->rho[i] / c->rho_L0 + c->deltaT * temp;
+  c->adv_rho[i] = fmaxf(1.0f, a);
+}
+void orc_update_drho_divergence(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) update_drho_divergence(c, i); }
+void orc_update_drho_pressure(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) update_drho_pressure(c, i); }
+
+/* ref: dfsph.py:415-439 */
+void orc_warmstart_divergence_vel(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->kappa_v[i] = 0.5f * fmaxf(c->kappa_v[i] / c->deltaT, -0.5f * c->rho_L0 * c->rho_L0);
+    update_drho_divergence(c, i);
+  }
+  /* second parallel loop: vel[i] written, kappa_v[j] read (never vel[j]) => order free */
+  PFOR for (int i = 0; i < NL; i++) {
+    if (c->adv_rho[i] > 0.0f) {
+      v3 v = c->vel[i];
+      float ki = c->kappa_v[i];
+      NB_BEGIN(i)
+        v3 gradV = CubicGradW(c, r);
+        if (j < NL) {
+          float sum = ki + c->kappa_v[j];
+          if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
+        } else if (fabsf(ki) > c->eps) v = add(v, mul(gradV, c->deltaT * ki * c->VS0));
+      NB_END
+      c->vel[i] = v;
+    }
+  }
+}
+
+/* ref: dfsph.py:441-446 */
+void orc_begin_divergence_iter(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    update_drho_divergence(c, i);
+    c->alpha_coff[i] = c->alpha_coff[i] / c->deltaT;
+    c->kappa_v[i] = 0.0f;
+  }
+}
+
+/* ref: dfsph.py:449-477 */
+void orc_divergence_iter(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float ki = c->adv_rho[i] * c->alpha_coff[i];
+    c->kappa_v[i] += ki;
+    v3 v = c->vel[i];
+    NB_BEGIN(i)
+      v3 gradV = CubicGradW(c, r);
+      if (j < NL) {
+        float sum = ki + c->alpha_coff[j] * c->adv_rho[j];
+        if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
+      } else if (fabsf(ki) > c->eps) v = add(v, mul(gradV, c->deltaT * ki * c->VS0));
+    NB_END
+    c->vel[i] = v;
+  }
+  double err = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : err)
+  for (int i = 0; i < NL; i++) { update_drho_divergence(c, i); err += (double)c->adv_rho[i]; }
+  c->avg_density_err = (float)err;
+}
+
+/* ref: dfsph.py:480-484 */
+void orc_end_divergence_iter(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) { c->kappa_v[i] *= c->deltaT; c->alpha_coff[i] *= c->deltaT; }
+}
+
+/* ref: dfsph.py:487-508 (kept literally, including the kappa_v typo in the solid branch, Q7) */
+void orc_warmstart_pressure(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++)
+    c->kappa[i] = fmaxf(c->kappa[i] / c->deltaT / c->deltaT, -0.5f * c->rho_L0 * c->rho_L0);
+  PFOR for (int i = 0; i < NL; i++) {
+    if (c->adv_rho[i] > c->rho_L0) {
+      v3 v = c->vel[i];
+      NB_BEGIN(i)
+        v3 gradV = CubicGradW(c, r);
+        if (j < NL) {
+          float sum = c->kappa[i] + c->kappa[j];
+          if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
+        } else if (fabsf(c->kappa[i]) > c->eps) v = add(v, mul(gradV, c->deltaT * c->kappa_v[i] * c->VS0));
+      NB_END
+      c->vel[i] = v;
+    }
+  }
+}
+
+/* ref: dfsph.py:511-516 */
+void orc_begin_pressure_iter(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    update_drho_pressure(c, i);
+    c->alpha_coff[i] = c->alpha_coff[i] / c->deltaT / c->deltaT;
+    c->kappa[i] = 0.0f;
+  }
+}
+
+/* ref: dfsph.py:518-547 */
+void orc_pressure_iter(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float bi = c->adv_rho[i] - 1.0f;
+    float ki = bi * c->alpha_coff[i];
+    c->kappa[i] += ki;
+    v3 v = c->vel[i];
+    NB_BEGIN(i)
+      v3 gradV = CubicGradW(c, r);
+      if (j < NL) {
+        float bj = c->adv_rho[j] - 1.0f;
+        float kj = bj * c->alpha_coff[j];
+        float sum = ki + kj;
+        if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
+      } else if (fabsf(ki) > c->eps) v = add(v, mul(gradV, c->deltaT * ki * c->VS0));
+    NB_END
+    c->vel[i] = v;
+  }
+  double err = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : err)
+  for (int i = 0; i < NL; i++) { update_drho_pressure(c, i); err += (double)(c->adv_rho[i] - 1.0f); }
+  c->avg_density_err = (float)err;
+}
+
+/* ref: dfsph.py:549-552 */
+void orc_end_pressure_iter(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) c->kappa[i] *= c->deltaT * c->deltaT;
+}
+
+/* ref: dfsph.py:333-336 */
+void orc_clear_nonpressure(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) c->d_vel[i] = c->gravity; }
+
+/* ref: dfsph.py:264-305.
+ * tension_fixed == 0 reproduces the loop literally (normal *= h once per entry, Q8; the
+ * curvature term over EVERY liquid list entry, cohesion overwritten, Q9).
+ * tension_fixed == 1 is the documented repair: n_i = h * sum (m/rho_j) gradW, curvature
+ * term only for entries inside the support. */
+void orc_compute_tension(orc_ctx *c) {
+  const float h = c->ck_h;
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 n = V(0, 0, 0);
+    NB_BEGIN(i)
+      v3 g = CubicGradW(c, r);
+      if (j < NL) n = add(n, mul(g, c->liqiudMass / c->rho[j]));
+      if (!c->tension_fixed) n = mul(n, h);
+    NB_END
+    if (c->tension_fixed) n = mul(n, h);
+    c->normal[i] = n;
+  }
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 dv = c->d_vel[i];
+    NB_BEGIN(i)
+      float len2 = nsq(r);
+      if (j < NL) {
+        float k_ij = 2.0f * c->rho_L0 / (c->rho[i] + c->rho[j]);
+        /* cohesion value is computed and discarded in the reference (Q9) */
+        v3 accel = mul(sub(c->normal[i], c->normal[j]), -c->tension_coff);
+        if (!c->tension_fixed || len2 <= h * h) dv = add(dv, mul(accel, k_ij));
+      } else {
+        v3 d = sub(c->pos[j], V(0.0f, 0.5f, 0.0f));
+        float dis = sqrtf(nsq(d));
+        if (len2 > c->eps && dis < 0.26f) {
+          v3 xixj = mul(r, 1.0f / sqrtf(len2));
+          dv = add(dv, mul(xixj, -c->tension_coff_b * c->rho_S0 * c->VS0 * Adh_W_norm(c, sqrtf(len2))));
+        }
+      }
+    NB_END
+    c->d_vel[i] = dv;
+  }
+}
+
+/* ref: dfsph.py:181-195.  x is vel_guess or cg_dir. */
+static inline v3 viscosity_Ax(const orc_ctx *c, const v3 *x, int i) {
+  v3 ret = V(0, 0, 0);
+  const float e = 0.01f * c->searchR * c->searchR;
+  NB_BEGIN(i)
+    if (j < NL) {
+      float s = c->dim_coff * c->viscosity * c->liqiudMass / c->rho[j] * dot(sub(x[i], x[j]), r) / (nsq(r) + e);
+      ret = add(ret, mul(CubicGradW(c, r), s / c->rho[i] * c->deltaT));
+    } else {
+      float s = c->dim_coff * c->viscosity_b * c->rho_S0 / c->rho[i] * c->VS0 * dot(x[i], r) / (nsq(r) + e);
+      ret = add(ret, mul(CubicGradW(c, r), s / c->rho[i] * c->deltaT));
+    }
+  NB_END
+  return sub(x[i], ret);
+}
+
+static void inv3(const float *m, float *o) { /* adjugate / determinant (Taichi Matrix.inverse 3x3) */
+  float a = m[0], b = m[1], cc = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  float det = a * A + b * B + cc * C, id = 1.0f / det;
+  o[0] = A * id; o[1] = -(b * i - cc * h) * id; o[2] = (b * f - cc * e) * id;
+  o[3] = B * id; o[4] = (a * i - cc * g) * id;  o[5] = -(a * f - cc * d) * id;
+  o[6] = C * id; o[7] = -(a * h - b * g) * id;  o[8] = (a * e - b * d) * id;
+}
+static inline v3 matvec(const float *m, v3 v) {
+  return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+
+/* ref: dfsph.py:197-223 */
+void orc_init_viscosity_para(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) c->vel_guess[i] = add(c->vel_guess[i], c->vel[i]);
+  const float e = 0.01f * c->searchR * c->searchR;
+  PFOR for (int i = 0; i < NL; i++) {
+    float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    NB_BEGIN(i)
+      v3 g = CubicGradW(c, r);
+      float s;
+      if (j < NL) s = c->dim_coff * c->viscosity * c->liqiudMass / c->rho[j] / (nsq(r) + e);
+      else        s = c->dim_coff * c->viscosity_b * c->rho_S0 / c->rho[i] * c->VS0 / (nsq(r) + e);
+      /* outer_product(gradW, r)[a][b] = g_a * r_b */
+      m[0] += s * g.x * r.x; m[1] += s * g.x * r.y; m[2] += s * g.x * r.z;
+      m[3] += s * g.y * r.x; m[4] += s * g.y * r.y; m[5] += s * g.y * r.z;
+      m[6] += s * g.z * r.x; m[7] += s * g.z * r.y; m[8] += s * g.z * r.z;
+    NB_END
+    float f = c->deltaT / c->rho[i], t[9];
+    for (int a = 0; a < 9; a++) t[a] = ((a % 4 == 0) ? 1.0f : 0.0f) - m[a] * f;
+    inv3(t, c->cg_Minv + (long)i * 9);
+  }
+  double dz = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : dz)
+  for (int i = 0; i < NL; i++) {
+    c->cg_r[i] = sub(c->vel[i], viscosity_Ax(c, c->vel_guess, i));
+    c->cg_dir[i] = matvec(c->cg_Minv + (long)i * 9, c->cg_r[i]);
+    dz += (double)dot(c->cg_r[i], c->cg_dir[i]);
+  }
+  c->cg_delta_zero = (float)dz;
+  c->cg_delta = c->cg_delta_zero;
+}
+
+/* ref: dfsph.py:225-246 */
+void orc_compute_viscosity_force(orc_ctx *c) {
+  double dAd = (double)c->eps;
+#pragma omp parallel for schedule(static) reduction(+ : dAd)
+  for (int i = 0; i < NL; i++) {
+    c->cg_Ad[i] = viscosity_Ax(c, c->cg_dir, i);
+    dAd += (double)dot(c->cg_dir[i], c->cg_Ad[i]);
+  }
+  float alpha = c->cg_delta / (float)dAd;
+  c->cg_delta_old = c->cg_delta;
+  double dl = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : dl)
+  for (int i = 0; i < NL; i++) {
+    c->vel_guess[i] = add(c->vel_guess[i], mul(c->cg_dir[i], alpha));
+    c->cg_r[i] = sub(c->cg_r[i], mul(c->cg_Ad[i], alpha));
+    c->cg_s[i] = matvec(c->cg_Minv + (long)i * 9, c->cg_r[i]);
+    dl += (double)dot(c->cg_r[i], c->cg_s[i]);
+  }
+  c->cg_delta = (float)dl;
+  float beta = c->cg_delta / c->cg_delta_old;
+  PFOR for (int i = 0; i < NL; i++) c->cg_dir[i] = add(c->cg_s[i], mul(c->cg_dir[i], beta));
+}
+
+/* ref: dfsph.py:339-343 */
+void orc_end_viscosity(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->d_vel[i] = add(c->d_vel[i], mul(sub(c->vel_guess[i], c->vel[i]), 1.0f / c->deltaT));
+    c->vel_guess[i] = sub(c->vel_guess[i], c->vel[i]);
+  }
+}
+
+/* ref: dfsph.py:307-330.  Q18: for a solid j the reference indexes omega[j] / vel[j] out of
+ * bounds; restated with omega_j = vel_j = 0 (static wall) -- unreproducible otherwise.
+ * Q10: the damping term is added once per list entry. */
+void orc_compute_vorticity(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 dom = V(0, 0, 0), dv = c->d_vel[i];
+    NB_BEGIN(i)
+      v3 gradV = CubicGradW(c, r);
+      if (j < NL) {
+        v3 dw = sub(c->omega[i], c->omega[j]);
+        dom = add(dom, mul(dw, -1.0f / c->deltaT * c->vorticity_init * c->viscosity_omega * (c->liqiudMass / c->rho[j]) * Cubic_W(c, r)));
+        dv = add(dv, mul(cross(dw, gradV), c->vorticity_coff / c->rho[i] * c->liqiudMass));
+        dom = add(dom, mul(cross(sub(c->vel[i], c->vel[j]), gradV), c->vorticity_coff / c->rho[i] * c->vorticity_init * c->liqiudMass));
+      } else {
+        dv = add(dv, mul(cross(c->omega[i], gradV), c->vorticity_coff / c->rho[i] * c->rho_L0 * c->VS0));
+        dom = add(dom, mul(cross(c->vel[i], gradV), c->vorticity_coff / c->rho[i] * c->vorticity_init * c->rho_L0 * c->VL0));
+      }
+      dom = add(dom, mul(c->omega[i], -2.0f * c->vorticity_init * c->vorticity_coff));
+    NB_END
+    c->d_omega[i] = dom; c->d_vel[i] = dv;
+  }
+  PFOR for (int i = 0; i < NL; i++) c->omega[i] = add(c->omega[i], mul(c->d_omega[i], c->deltaT));
+}
+
+/* ref: dfsph.py:555-568 + host loop :107-111.  Literal strided tree (covers the first
+ * 2^floor(log2(N-1)) particles, Q5); out-of-range reads return the element itself. */
+void orc_cfl_reduce(orc_ctx *c) {
+  int N = NL;
+  for (int size = 1; size < N; size *= 2) {
+    if (size == 1) {
+      PFOR for (int i = 0; i < N; i++)
+        c->vel_max[i] = fmaxf(nsq(add(c->vel[i], mul(c->d_vel[i], c->deltaT))), 0.1f);
+    } else {
+      int off = size / 2;
+      PFOR for (int i = 0; i < N; i += size) {
+        float vi = c->vel_max[i];
+        float vj = (i + off < N) ? c->vel_max[i + off] : vi;
+        c->vel_max[i] = (vi > vj) ? vi : vj;
+      }
+    }
+  }
+}
+
+/* ref: dfsph.py:107-129 (host side in Python doubles on f32 values) */
+void orc_optimize_time_step(orc_ctx *c) {
+  orc_cfl_reduce(c);
+  float vmax0 = c->vel_max[0];
+  if ((double)vmax0 > (double)c->eps) {
+    double time_step = 0.5 * 0.4 * c->particleRadius * 2.0 / sqrt((double)vmax0);
+    if (time_step > c->user_max_t) time_step = c->user_max_t;
+    if (time_step < c->user_min_t) time_step = c->user_min_t;
+    int it = c->vs_iter > c->pr_iter ? c->vs_iter : c->pr_iter; /* max(vs, max(pr, vs)) Q6 */
+    float dt = c->deltaT;
+    if (it > 10) dt = (float)((double)dt * 0.9);
+    else if (it < 5) dt = (float)((double)dt * 1.1);
+    if ((double)dt > time_step) dt = (float)time_step;
+    c->deltaT = dt;
+  }
+}
+
+/* ref: dfsph.py:572-580 */
+void orc_update_vel(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) c->vel[i] = add(c->vel[i], mul(c->d_vel[i], c->deltaT)); }
+void orc_update_pos(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) c->pos[i] = add(c->pos[i], mul(c->vel[i], c->deltaT)); }
+
+/* ref: dfsph.py:84-103 */
+void orc_compute_nonpressure_force(orc_ctx *c) {
+  orc_clear_nonpressure(c);
+  orc_compute_tension(c);
+  orc_init_viscosity_para(c);
+  c->vs_iter = 0;
+  while (c->vs_iter < 100) {
+    orc_compute_viscosity_force(c);
+    c->vs_iter++;
+    if ((double)c->cg_delta <= (double)c->viscosity_err * (double)c->cg_delta_zero || (double)c->cg_delta_zero < (double)c->eps) break;
+  }
+  orc_end_viscosity(c);
+  orc_compute_vorticity(c);
+}
+
+/* ref: dfsph.py:131-146 */
+void orc_solve_vel_divergence(orc_ctx *c) {
+  c->dv_iter = 0;
+  orc_warmstart_divergence_vel(c);
+  double err = -0.1;
+  orc_begin_divergence_iter(c);
+  float dt = c->deltaT;
+  while ((double)c->avg_density_err > err && c->dv_iter < 10) {
+    orc_divergence_iter(c);
+    err = 0.001 * (double)NL / (double)dt;
+    c->dv_iter++;
+  }
+  orc_end_divergence_iter(c);
+}
+
+/* ref: dfsph.py:150-164 */
+void orc_solve_pressure(orc_ctx *c) {
+  orc_warmstart_pressure(c);
+  c->pr_iter = 0;
+  double err = 0.0;
+  orc_begin_pressure_iter(c);
+  while ((err > 0.001 || c->pr_iter < 2) && c->pr_iter < 100) {
+    orc_pressure_iter(c);
+    err = (double)c->avg_density_err / (double)NL;
+    c->pr_iter++;
+  }
+  orc_end_pressure_iter(c);
+}
+
+/* ref: dfsph.py:606-617 main-loop body */
+void orc_dfsph_step(orc_ctx *c) {
+  orc_update_grid(c);
+  orc_compute_density(c);
+  orc_compute_dfsph_coff(c);
+  orc_solve_vel_divergence(c);
+  orc_compute_nonpressure_force(c);
+  orc_optimize_time_step(c);
+  orc_update_vel(c);
+  orc_solve_pressure(c);
+  orc_update_pos(c);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* sesph.py (private constants with pi = 3.1415926, private vel/d_vel/rho/pressure fields;
+ * here they alias the ParticleData arrays of the same names)                             */
+
+/* ref: sesph.py:23-62.  searchR = gridR*2 where gridR = 2*particleRadius (0.05). */
+void orc_sesph_init(orc_ctx *c, double particleRadius) {
+  double gridR = (double)particleRadius * 2.0, sr = gridR * 2.0, pi = 3.1415926;
+  double h3 = sr * sr * sr;
+  c->ss_searchR = (float)sr; c->ss_mk = (float)(8.0 / (pi * h3)); c->ss_ml = (float)(48.0 / (pi * h3));
+  double VL0 = (double)particleRadius * particleRadius * particleRadius * 0.8 * 8.0;
+  c->ss_VL0 = (float)VL0; c->ss_VS0 = (float)(VL0 * 2.0); c->ss_rho0 = 1000.0f; c->ss_mass = (float)(VL0 * 1000.0);
+  c->ss_stiff = 50000.0f; c->ss_dim = 10.0f; c->ss_visc = 0.1f; c->ss_visc_b = 0.0f;
+}
+static inline v3 ss_gradW(const orc_ctx *c, v3 r) { /* ref: sesph.py:96-107 */
+  v3 res = V(0, 0, 0);
+  float rl = sqrtf(nsq(r)), q = rl / c->ss_searchR;
+  if (rl > 1.0e-5f && q <= 1.0f) {
+    v3 gradq = mul(r, 1.0f / (rl * c->ss_searchR));
+    if (q <= 0.5f) res = mul(gradq, c->ss_ml * q * (3.0f * q - 2.0f));
+    else { float f = 1.0f - q; res = mul(gradq, -c->ss_ml * (f * f)); }
+  }
+  return res;
+}
+static inline float ss_W_norm(const orc_ctx *c, float v) { /* ref: sesph.py:110-124 */
+  float res = 0.0f, q = v / c->ss_searchR;
+  if (q <= 1.0f) {
+    if (q <= 0.5f) { float qq = q * q, qqq = qq * q; res = c->ss_mk * (6.0f * qqq - 6.0f * qq + 1.0f); }
+    else { float f = 1.0f - q; res = c->ss_mk * 2.0f * f * f * f; }
+  }
+  return res;
+}
+/* ref: sesph.py:130-135 */
+void orc_sesph_reset_param(orc_ctx *c) {
+  for (int i = 0; i < NL; i++) { c->vel[i] = V(0, 0, 0); c->pressure[i] = 0.0f; }
+  c->deltaT = 0.001f;
+}
+/* ref: sesph.py:138-154 */
+void orc_sesph_update_advection_density(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float rho = c->ss_VL0 * ss_W_norm(c, 0.0f);
+    NB_BEGIN(i)
+      float d_den = ss_W_norm(c, sqrtf(nsq(r)));
+      if (j < NL) rho += c->ss_VL0 * d_den; else rho += c->ss_VS0 * d_den;
+    NB_END
+    c->rho[i] = rho * c->ss_rho0;
+  }
+}
+/* ref: sesph.py:158-166 */
+void orc_sesph_update_pressure(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->rho[i] = fmaxf(c->rho[i], c->ss_rho0);
+    float q = c->rho[i] / c->ss_rho0, qq = q * q, qqqq = qq * qq;
+    c->pressure[i] = c->ss_stiff * (qqqq * qq * q - 1.0f);
+  }
+}
+/* ref: sesph.py:168-188 */
+void orc_sesph_compute_force(orc_ctx *c) {
+  const float e = 0.01f * c->ss_searchR * c->ss_searchR, rho_0 = c->ss_rho0;
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 a = c->gravity;
+    NB_BEGIN(i)
+      v3 grad = ss_gradW(c, r);
+      if (j < NL) {
+        a = add(a, mul(grad, c->ss_dim * c->ss_visc * c->ss_mass / c->rho[j] * dot(sub(c->vel[i], c->vel[j]), r) / (nsq(r) + e)));
+        a = add(a, mul(grad, -rho_0 * c->ss_VL0 * (c->pressure[i] / (c->rho[i] * c->rho[i]) + c->pressure[j] / (c->rho[j] * c->rho[j]))));
+      } else {
+        a = add(a, mul(grad, c->ss_dim * c->ss_visc_b * c->ss_VS0 * (c->rho[i] / rho_0) * dot(c->vel[i], r) / (nsq(r) + e)));
+        a = add(a, mul(grad, -rho_0 * c->ss_VS0 * (c->pressure[i] / (c->rho[i] * c->rho[i]) + c->pressure[i] / (rho_0 * rho_0))));
+      }
+    NB_END
+    c->d_vel[i] = a;
+  }
+}
+/* ref: sesph.py:191-196 */
+void orc_sesph_integrate(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->vel[i] = add(c->vel[i], mul(c->d_vel[i], c->deltaT));
+    c->pos[i] = add(c->pos[i], mul(c->vel[i], c->deltaT));
+  }
+}
+/* ref: sesph.py:217-225 */
+void orc_sesph_step(orc_ctx *c) {
+  orc_update_grid(c);
+  orc_sesph_update_advection_density(c);
+  orc_sesph_update_pressure(c);
+  orc_sesph_compute_force(c);
+  orc_sesph_integrate(c);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* accessors for the ctypes wrapper (oracle/oracle.py)                                    */
+#define PTR(name, type) type *orc_ptr_##name(orc_ctx *c) { return (type *)c->name; }
+PTR(pos, float) PTR(vel, float) PTR(vel_guess, float) PTR(d_vel, float) PTR(omega, float) PTR(d_omega, float)
+PTR(normal, float) PTR(rho, float) PTR(adv_rho, float) PTR(pressure, float) PTR(vel_max, float)
+PTR(cg_Minv, float) PTR(cg_r, float) PTR(cg_dir, float) PTR(cg_Ad, float) PTR(cg_s, float)
+PTR(alpha_coff, float) PTR(kappa, float) PTR(kappa_v, float)
+PTR(gridCount, int) PTR(grid, int) PTR(neighborCount, int) PTR(neighbor, int)
+
+enum { S_deltaT = 0, S_avg_density_err, S_cg_delta, S_cg_delta_old, S_cg_delta_zero, S_viscosity, S_viscosity_b,
+       S_tension_coff, S_tension_coff_b, S_VL0, S_VS0, S_liqiudMass, S_searchR, S_gridR, S_invGridR, S_rho_L0,
+       S_viscosity_err, S_vorticity_coff, S_viscosity_omega, S_vorticity_init };
+static float *sptr(orc_ctx *c, int id) {
+  switch (id) {
+    case S_deltaT: return &c->deltaT; case S_avg_density_err: return &c->avg_density_err;
+    case S_cg_delta: return &c->cg_delta; case S_cg_delta_old: return &c->cg_delta_old;
+    case S_cg_delta_zero: return &c->cg_delta_zero; case S_viscosity: return &c->viscosity;
+    case S_viscosity_b: return &c->viscosity_b; case S_tension_coff: return &c->tension_coff;
+    case S_tension_coff_b: return &c->tension_coff_b; case S_VL0: return &c->VL0; case S_VS0: return &c->VS0;
+    case S_liqiudMass: return &c->liqiudMass; case S_searchR: return &c->searchR; case S_gridR: return &c->gridR;
+    case S_invGridR: return &c->invGridR; case S_rho_L0: return &c->rho_L0; case S_viscosity_err: return &c->viscosity_err;
+    case S_vorticity_coff: return &c->vorticity_coff; case S_viscosity_omega: return &c->viscosity_omega;
+    case S_vorticity_init: return &c->vorticity_init;
+  }
+  return NULL;
+}
+float orc_get_scalar(orc_ctx *c, int id) { float *p = sptr(c, id); return p ? *p : NAN; }
+void orc_set_scalar(orc_ctx *c, int id, float v) { float *p = sptr(c, id); if (p) *p = v; }
+enum { I_vs_iter = 0, I_dv_iter, I_pr_iter, I_overflow_grid, I_overflow_neighbor, I_table_size, I_bs0, I_bs1, I_bs2,
+       I_tension_fixed, I_mode };
+int orc_get_int(orc_ctx *c, int id) {
+  switch (id) {
+    case I_vs_iter: return c->vs_iter; case I_dv_iter: return c->dv_iter; case I_pr_iter: return c->pr_iter;
+    case I_overflow_grid: return c->overflow_grid; case I_overflow_neighbor: return c->overflow_neighbor;
+    case I_table_size: return c->table_size; case I_bs0: return c->blockSize[0]; case I_bs1: return c->blockSize[1];
+    case I_bs2: return c->blockSize[2]; case I_tension_fixed: return c->tension_fixed; case I_mode: return c->mode;
+  }
+  return -1;
+}
+void orc_set_int(orc_ctx *c, int id, int v) {
+  switch (id) {
+    case I_vs_iter: c->vs_iter = v; break; case I_dv_iter: c->dv_iter = v; break; case I_pr_iter: c->pr_iter = v; break;
+    case I_tension_fixed: c->tension_fixed = v; break;
+  }
+}
