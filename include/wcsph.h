@@ -1,0 +1,172 @@
+/*
+ * wcsph.h -- C ABI of libwcsph_hip.so: the MI355X (gfx950) SPH hot path behind the
+ * lyd405121/wcsph Python surface (ParticleData / HashGrid / dfsph.py / sesph.py kernels).
+ *
+ * The reference has no FFI; its "operator interface" for this path is the set of
+ * zero-argument @ti.kernel functions the driver loops call.  Each entry
+ * point below replaces exactly one of them and cites it ("ref: file:line" into the
+ * reference tree).  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns int: 0 = OK, <0 = error
+ *       WCSPH_EARG (-1) bad argument        WCSPH_EHIP  (-2) HIP runtime error
+ *       WCSPH_EBUCKET (-3) > maxInGrid particles in one hash bucket  (ref: HashGrid.py:72-74)
+ *       WCSPH_ENEIGH  (-4) > maxNeighbour list entries for a particle (ref: HashGrid.py:100-103)
+ *       WCSPH_ENONFINITE (-5) non-finite reduction result
+ *   - wcsph_last_error(ctx) returns a human readable message for the last failure
+ *   - a context owns all device memory; host arrays are caller-owned and copied synchronously
+ *   - one host thread drives one context; all work is queued on one HIP stream
+ *     (wcsph_set_stream); kernel entry points are asynchronous, *_to_host / get_* synchronise
+ *   - host-visible particle order is ALWAYS the caller's original order (liquid first, then
+ *     solid, ref: ParticleData.py:100-126); the cell-sorted device order is internal
+ */
+#ifndef WCSPH_H
+#define WCSPH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WCSPH_OK 0
+#define WCSPH_EARG (-1)
+#define WCSPH_EHIP (-2)
+#define WCSPH_EBUCKET (-3)
+#define WCSPH_ENEIGH (-4)
+#define WCSPH_ENONFINITE (-5)
+
+/* neighbour semantics (DESIGN.md "Neighbour modes") */
+#define WCSPH_MODE_FAITHFUL 0 /* reference hash table with `count` buckets: bucket multiset, HashGrid.py:56-114 */
+#define WCSPH_MODE_CLEAN 1    /* collision-free hash: every particle of the 5x5x5 in-box cells once */
+
+typedef struct wcsph_ctx wcsph_ctx;
+
+/* Python-scope constants of ParticleData / HashGrid / the kernels (ref: ParticleData.py:12-31,61-87;
+ * HashGrid.py:10-19; kernels/CubicKernel.py:12-17; dfsph.py:19-41).  Doubles where the reference
+ * keeps Python floats that take part in host-side (double) arithmetic. */
+typedef struct wcsph_params {
+  int32_t n_liquid, n_solid;
+  int32_t neighbor_mode;     /* WCSPH_MODE_* */
+  int32_t max_in_grid;       /* 64   (ParticleData.py:27) */
+  int32_t max_neighbour;     /* 2048 (ParticleData.py:27) */
+  int32_t hash_table_size;   /* 0 => n_liquid + n_solid (HashGrid.py:114); slabs pass the global count */
+  int32_t tension_fixed;     /* 0 literal Q8/Q9 loop is NOT reproducible; only 1 (fixed normals) is implemented */
+  int32_t reserved0;
+  double particle_radius;    /* what the script passes to ParticleData(): radius (dfsph) or diameter (sesph, Q11) */
+  double cfl_radius;         /* dfsph.py:27 particleRadius used by optimize_time_step */
+  double user_max_t, user_min_t; /* dfsph.py:39-40 */
+  float rho_L0, rho_S0, VL0, VS0, liqiudMass;
+  float gravity[3];
+  float dim_coff, viscosity, viscosity_b, viscosity_err;
+  float tension_coff, tension_coff_b;
+  float viscosity_omega, vorticity_coff, vorticity_init;
+  float eps;
+  /* sesph.py private constants (sesph.py:23-62) */
+  float ss_searchR, ss_mk, ss_ml, ss_VL0, ss_VS0, ss_mass, ss_rho0, ss_stiff, ss_dim, ss_visc, ss_visc_b;
+  float reserved1;
+} wcsph_params;
+
+/* field ids for wcsph_field_to_host / wcsph_field_from_host (ref: ParticleData.py:33-76, dfsph.py:46-48) */
+enum wcsph_field {
+  WCSPH_F_POS = 0,     /* [count][3] f32 (liquid rows are dynamic, solid rows static) */
+  WCSPH_F_VEL,         /* [n_liquid][3] */
+  WCSPH_F_VEL_GUESS, WCSPH_F_D_VEL, WCSPH_F_OMEGA, WCSPH_F_D_OMEGA, WCSPH_F_NORMAL,
+  WCSPH_F_CG_R, WCSPH_F_CG_DIR, WCSPH_F_CG_AD, WCSPH_F_CG_S,
+  WCSPH_F_RHO,         /* [n_liquid] f32 */
+  WCSPH_F_ADV_RHO, WCSPH_F_PRESSURE, WCSPH_F_VEL_MAX, WCSPH_F_ALPHA, WCSPH_F_KAPPA, WCSPH_F_KAPPA_V,
+  WCSPH_F_CG_MINV,     /* [n_liquid][3][3] f32 */
+  WCSPH_F_NEIGHBOR_COUNT, /* [n_liquid] i32  (HashGrid.neighborCount) */
+  WCSPH_F__COUNT
+};
+
+/* scalar ids for wcsph_get_scalar / wcsph_set_scalar (shape-(1) fields, ref: ParticleData.py:66-69, dfsph.py:41) */
+enum wcsph_scalar {
+  WCSPH_S_DELTA_T = 0, WCSPH_S_AVG_DENSITY_ERR, WCSPH_S_CG_DELTA, WCSPH_S_CG_DELTA_OLD, WCSPH_S_CG_DELTA_ZERO,
+  WCSPH_S_VISCOSITY, WCSPH_S_VISCOSITY_B, WCSPH_S_TENSION, WCSPH_S_TENSION_B, WCSPH_S_VEL_MAX0,
+  WCSPH_S__COUNT
+};
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+int wcsph_create(const wcsph_params *p, wcsph_ctx **out);
+int wcsph_destroy(wcsph_ctx *ctx);
+const char *wcsph_last_error(wcsph_ctx *ctx);
+int wcsph_set_stream(wcsph_ctx *ctx, void *hip_stream); /* NULL => the context's own stream */
+int wcsph_sync(wcsph_ctx *ctx);                          /* drain the stream, surface -3/-4/-5 */
+int wcsph_device_count(void);
+
+/* ref: ParticleData.setup_data_cpu (ParticleData.py:180-185) + HashGrid.setup_grid_cpu (HashGrid.py:44-54):
+ * uploads [count][3] positions (liquid first), fixes the grid box from maxb/minb, sorts the static solids. */
+int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const float *minb);
+int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]);
+
+int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes);
+int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes);
+int wcsph_get_scalar(wcsph_ctx *ctx, int id, float *v);
+int wcsph_set_scalar(wcsph_ctx *ctx, int id, float v);
+int wcsph_get_iters(wcsph_ctx *ctx, int32_t *vs_iter, int32_t *dv_iter, int32_t *pr_iter);
+int wcsph_set_iters(wcsph_ctx *ctx, int32_t vs_iter, int32_t dv_iter, int32_t pr_iter);
+
+/* ---- HashGrid ------------------------------------------------------------------------ */
+/* ref: HashGrid.update_grid (HashGrid.py:56-85): rebuild cells + per-particle neighbour multiset */
+int wcsph_grid_update(wcsph_ctx *ctx);
+/* ref: HashGrid.neighbor / neighborCount (HashGrid.py:24-25,88-106): materialise the explicit list the
+ * reference stores, original indices, for particles [i0, i0+n): counts[n], lists[n][cap] (-1 padded) */
+int wcsph_neighbors_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, int32_t *counts, int32_t *lists);
+
+/* ---- dfsph.py kernels (one entry per @ti.kernel) ------------------------------------- */
+int wcsph_dfsph_reset_param(wcsph_ctx *ctx);            /* ref: dfsph.py:167-178 */
+int wcsph_dfsph_compute_density(wcsph_ctx *ctx);        /* ref: dfsph.py:248-262 */
+int wcsph_dfsph_compute_coff(wcsph_ctx *ctx);           /* ref: dfsph.py:345-372 */
+int wcsph_dfsph_warmstart_divergence(wcsph_ctx *ctx);   /* ref: dfsph.py:415-439 */
+int wcsph_dfsph_begin_divergence(wcsph_ctx *ctx);       /* ref: dfsph.py:441-446 */
+int wcsph_dfsph_divergence_iter(wcsph_ctx *ctx);        /* ref: dfsph.py:449-477 */
+int wcsph_dfsph_end_divergence(wcsph_ctx *ctx);         /* ref: dfsph.py:480-484 */
+int wcsph_dfsph_warmstart_pressure(wcsph_ctx *ctx);     /* ref: dfsph.py:487-508 */
+int wcsph_dfsph_begin_pressure(wcsph_ctx *ctx);         /* ref: dfsph.py:511-516 */
+int wcsph_dfsph_pressure_iter(wcsph_ctx *ctx);          /* ref: dfsph.py:518-547 */
+int wcsph_dfsph_end_pressure(wcsph_ctx *ctx);           /* ref: dfsph.py:549-552 */
+int wcsph_dfsph_clear_nonpressure(wcsph_ctx *ctx);      /* ref: dfsph.py:333-336 */
+int wcsph_dfsph_tension(wcsph_ctx *ctx);                /* ref: dfsph.py:264-305 */
+int wcsph_dfsph_visc_init(wcsph_ctx *ctx);              /* ref: dfsph.py:197-223 */
+int wcsph_dfsph_visc_iter(wcsph_ctx *ctx);              /* ref: dfsph.py:225-246 */
+int wcsph_dfsph_visc_end(wcsph_ctx *ctx);               /* ref: dfsph.py:339-343 */
+int wcsph_dfsph_vorticity(wcsph_ctx *ctx);              /* ref: dfsph.py:307-330 */
+int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx);             /* ref: dfsph.py:107-111,555-568 (all launches of the tree) */
+int wcsph_dfsph_update_vel(wcsph_ctx *ctx);             /* ref: dfsph.py:572-575 */
+int wcsph_dfsph_update_pos(wcsph_ctx *ctx);             /* ref: dfsph.py:577-580 */
+
+/* ---- dfsph.py host-side control (same stopping rules, loop kept next to the device) --- */
+int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx); /* ref: dfsph.py:84-103  */
+int wcsph_dfsph_optimize_time_step(wcsph_ctx *ctx);        /* ref: dfsph.py:107-129 */
+int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx);          /* ref: dfsph.py:131-146 */
+int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx);            /* ref: dfsph.py:150-164 */
+int wcsph_dfsph_step(wcsph_ctx *ctx);                      /* ref: dfsph.py:606-617 */
+
+/* ---- sesph.py kernels ----------------------------------------------------------------- */
+int wcsph_sesph_reset_param(wcsph_ctx *ctx);   /* ref: sesph.py:130-135 */
+int wcsph_sesph_density(wcsph_ctx *ctx);       /* ref: sesph.py:138-154 */
+int wcsph_sesph_pressure(wcsph_ctx *ctx);      /* ref: sesph.py:158-166 */
+int wcsph_sesph_force(wcsph_ctx *ctx);         /* ref: sesph.py:168-188 */
+int wcsph_sesph_integrate(wcsph_ctx *ctx);     /* ref: sesph.py:191-196 */
+int wcsph_sesph_step(wcsph_ctx *ctx);          /* ref: sesph.py:217-225 */
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* Times `reps` back-to-back launches of one named kernel group with hipEvents on the context's
+ * stream; *ms_per_launch is the average.  Names: "pressure_iter", "divergence_iter", "density",
+ * "grid_update", "visc_iter".  State is not preserved across the call. */
+int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms_per_launch);
+
+/* ---- slab decomposition helpers; device pointers are caller-owned -------- */
+/* gather / scatter `n` rows of a field by ORIGINAL liquid indices (device int32 array) into / from a
+ * packed device buffer (rows of 3 f32 for vec3 fields, 1 f32 for scalar fields) for halo exchange */
+int wcsph_field_gather_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, void *d_dst);
+int wcsph_field_scatter_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, const void *d_src);
+/* mark liquid particles [n_owned, n_liquid) as ghosts: they are read as neighbours but never updated,
+ * and are excluded from reductions */
+int wcsph_set_owned(wcsph_ctx *ctx, int32_t n_owned);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCSPH_H */

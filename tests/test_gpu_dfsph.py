@@ -1,0 +1,240 @@
+"""GPU parity: every dfsph.py kernel of libwcsph_hip.so against the CPU oracle, through the C ABI.
+
+Tolerances: fp32 arithmetic with a different summation order on each side (the reference itself
+is order-nondeterministic, Q16).  Per-kernel outputs must agree to TOL = 2e-5 of the field's
+max magnitude from identical inputs; the north-star bound is 1e-4 on density."""
+import numpy as np
+import pytest
+
+from util import make_pair, rel_err, set_state
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+MODES = ["faithful", "clean"]
+
+
+def _random_vel(n, seed=7, scale=0.3):
+    return (np.random.default_rng(seed).standard_normal((n, 3)) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_neighbor_count_exact(mode):
+    g, o = make_pair(8, mode, jitter=0.4)
+    g.pd.hash_grid.update_grid()
+    o.update_grid()
+    np.testing.assert_array_equal(g.pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)
+    assert list(g.pd.hash_grid.blockSize.to_numpy()[0]) == list(o.blockSize)
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_neighbor_multiset_in_walk(mode):
+    """The explicit list (original indices) equals the oracle's list restricted to particles whose cell is
+    one of the 5x5x5 walked cells -- with multiplicity; the rest of the oracle list is far aliased entries."""
+    g, o = make_pair(6, mode, jitter=0.4)
+    g.pd.hash_grid.update_grid()
+    o.update_grid()
+    counts, lists = g.pd.hash_grid.neighbor.rows(0, g.pd.liquid_count, cap=2048)
+    np.testing.assert_array_equal(counts, o.neighborCount)
+    cells = np.array([o.cell_of(i) for i in range(o.count)])
+    for i in range(0, g.pd.liquid_count, 7):
+        mine = np.sort(lists[i][lists[i] >= 0])
+        ref = o.neighbor[i, :o.neighborCount[i]]
+        near = np.all(np.abs(cells[ref] - cells[i]) <= 2, axis=1)
+        np.testing.assert_array_equal(mine, np.sort(ref[near]))
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_density_and_alpha(mode):
+    g, o = make_pair(8, mode, jitter=0.4)
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.call("dfsph_compute_coff"); o.compute_dfsph_coff()
+    rho = g.pd.rho.to_numpy()
+    assert np.abs(rho - o.rho).max() / o.rho.max() < 1e-5   # north star: <= 1e-4
+    assert rel_err(g.alpha_coff.to_numpy(), o.alpha_coff) < TOL
+    if mode == "faithful":   # the aliasing must actually matter on this scene, or the test proves nothing
+        oc = make_pair(8, "clean", jitter=0.4)
+        oc[1].update_grid(); oc[1].compute_density()
+        assert np.abs(oc[1].rho - o.rho).max() / o.rho.max() > 1e-3
+        oc[0].close()
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_divergence_kernels(mode):
+    g, o = make_pair(8, mode, jitter=0.4)
+    nl = g.pd.liquid_count
+    for s in (g.call, ):
+        pass
+    g.call("dfsph_reset_param"); o.reset_param()
+    set_state(g, o, vel=_random_vel(nl), kappa_v=np.random.default_rng(3).uniform(-2e-4, 0, nl))
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.call("dfsph_compute_coff"); o.compute_dfsph_coff()
+    g.call("dfsph_warmstart_divergence"); o.warmstart_divergence_vel()
+    assert rel_err(g.kappa_v.to_numpy(), o.kappa_v) < TOL
+    assert rel_err(g.pd.adv_rho.to_numpy(), o.adv_rho) < TOL
+    assert rel_err(g.pd.vel.to_numpy(), o.vel) < TOL
+    g.call("dfsph_begin_divergence"); o.begin_divergence_iter()
+    assert rel_err(g.pd.adv_rho.to_numpy(), o.adv_rho) < TOL
+    assert rel_err(g.alpha_coff.to_numpy(), o.alpha_coff) < TOL
+    for _ in range(2):
+        g.call("dfsph_divergence_iter"); o.divergence_iter()
+        assert rel_err(g.pd.vel.to_numpy(), o.vel) < TOL
+        assert rel_err(g.pd.adv_rho.to_numpy(), o.adv_rho) < 5 * TOL
+        assert abs(g.pd.avg_density_err[0] - o.avg_density_err) <= 1e-4 * abs(o.avg_density_err) + 1e-6
+    g.call("dfsph_end_divergence"); o.end_divergence_iter()
+    assert rel_err(g.kappa_v.to_numpy(), o.kappa_v) < 5 * TOL
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_pressure_kernels(mode):
+    g, o = make_pair(8, mode, jitter=0.4)
+    nl = g.pd.liquid_count
+    g.call("dfsph_reset_param"); o.reset_param()
+    set_state(g, o, vel=_random_vel(nl, scale=0.1))
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.call("dfsph_compute_coff"); o.compute_dfsph_coff()
+    g.call("dfsph_warmstart_pressure"); o.warmstart_pressure()
+    g.call("dfsph_begin_pressure"); o.begin_pressure_iter()
+    assert rel_err(g.pd.adv_rho.to_numpy(), o.adv_rho) < TOL
+    for _ in range(3):
+        g.call("dfsph_pressure_iter"); o.pressure_iter()
+        assert rel_err(g.pd.vel.to_numpy(), o.vel) < 2 * TOL
+        assert rel_err(g.pd.adv_rho.to_numpy(), o.adv_rho) < TOL
+        assert abs(g.pd.avg_density_err[0] - o.avg_density_err) <= 2e-4 * abs(o.avg_density_err) + 1e-5
+    g.call("dfsph_end_pressure"); o.end_pressure_iter()
+    assert rel_err(g.kappa.to_numpy(), o.kappa) < 5 * TOL
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_viscosity_pcg_and_vorticity(mode):
+    g, o = make_pair(8, mode, jitter=0.4)
+    nl = g.pd.liquid_count
+    g.call("dfsph_reset_param"); o.reset_param()
+    rng = np.random.default_rng(11)
+    set_state(g, o, vel=_random_vel(nl), omega=_random_vel(nl, 5, 0.5),
+              vel_guess=(rng.standard_normal((nl, 3)) * 0.01).astype(np.float32))
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.call("dfsph_clear_nonpressure"); o.clear_nonpressure()
+    g.call("dfsph_visc_init"); o.init_viscosity_para()
+    assert rel_err(g.pd.cg_Minv.to_numpy(), o.cg_Minv) < TOL
+    assert rel_err(g.pd.cg_r.to_numpy(), o.cg_r) < 5 * TOL
+    assert rel_err(g.pd.cg_dir.to_numpy(), o.cg_dir) < 5 * TOL
+    assert abs(g.pd.cg_delta_zero[0] - o.cg_delta_zero) < 1e-4 * abs(o.cg_delta_zero)
+    for _ in range(3):
+        g.call("dfsph_visc_iter"); o.compute_viscosity_force()
+        assert rel_err(g.pd.cg_Ad.to_numpy(), o.cg_Ad) < 1e-4
+        assert rel_err(g.pd.vel_guess.to_numpy(), o.vel_guess) < 1e-4
+        assert abs(g.pd.cg_delta[0] - o.cg_delta) < 2e-3 * abs(o.cg_delta_zero)
+    g.call("dfsph_visc_end"); o.end_viscosity()
+    assert rel_err(g.pd.d_vel.to_numpy(), o.d_vel) < 2e-4
+    g.call("dfsph_vorticity"); o.compute_vorticity()
+    assert rel_err(g.pd.d_omega.to_numpy(), o.d_omega) < 1e-4
+    assert rel_err(g.pd.omega.to_numpy(), o.omega) < 1e-4
+    assert rel_err(g.pd.d_vel.to_numpy(), o.d_vel) < 2e-4
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_tension_fixed_semantics(mode):
+    g, o = make_pair(8, mode, jitter=0.4, tension_coff=0.5, tension_coff_b=0.5)
+    o.tension_coff, o.tension_coff_b, o.tension_fixed = 0.5, 0.5, 1
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.call("dfsph_clear_nonpressure"); o.clear_nonpressure()
+    g.call("dfsph_tension"); o.compute_tension()
+    assert rel_err(g.pd.normal.to_numpy(), o.normal) < TOL
+    assert rel_err(g.pd.d_vel.to_numpy(), o.d_vel) < TOL
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_cfl_and_time_step(mode):
+    g, o = make_pair(8, mode, jitter=0.2)
+    nl = g.pd.liquid_count
+    g.call("dfsph_reset_param"); o.reset_param()
+    v = _random_vel(nl, scale=1.0)
+    v[nl - 3] = [30.0, 0, 0]   # beyond the reference tree's prefix (Q5): faithful must NOT see it
+    set_state(g, o, vel=v, d_vel=_random_vel(nl, 9, 5.0))
+    g.call("dfsph_optimize_time_step")
+    if mode == "faithful":
+        o.optimize_time_step()
+        assert abs(g.pd.vel_max.to_numpy()[0] - o.vel_max[0]) <= 1e-6 * o.vel_max[0]
+        assert abs(g.deltaT[0] - o.deltaT) <= 1e-7
+        assert g.pd.vel_max.to_numpy()[0] < 100.0
+    else:
+        assert g.pd.vel_max.to_numpy()[0] > 800.0   # true maximum
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("driver", ["fused", "reference_loop"])
+def test_full_steps(mode, driver):
+    """Three whole DFSPH steps from rest (jittered lattice): fields and iteration counts track the oracle."""
+    from wcsph_amd import dfsph
+    import util
+    liquid, solid = util.small_scene(8, jitter=0.2)
+    pd = dfsph.init_particle(particleDim=8, neighbor_mode=mode, boundary=solid)
+    pd.pos.from_numpy(np.concatenate([liquid, solid]).astype(np.float32))
+    from oracle import Oracle
+    o = Oracle(pd.pos.to_numpy(), pd.liquid_count, 0.025, mode=mode)
+    dfsph.reset_param(); o.reset_param()
+    for s in range(3):
+        (dfsph.step if driver == "fused" else dfsph.step_reference_loop)()
+        o.dfsph_step()
+        assert (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter) == (o.vs_iter, o.dv_iter, o.pr_iter)
+        assert abs(dfsph.deltaT[0] - o.deltaT) <= 1e-6 * o.deltaT
+        assert np.abs(pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-4
+        assert rel_err(pd.vel.to_numpy(), o.vel) < 1e-3
+        assert np.abs(pd.pos.to_numpy() - o.pos).max() < 1e-5
+        assert rel_err(dfsph.kappa.to_numpy(), o.kappa) < 1e-3
+    pd.close()
+
+
+def test_field_roundtrip_and_order():
+    g, o = make_pair(6, "clean", jitter=0.4)
+    nl = g.pd.liquid_count
+    v = _random_vel(nl)
+    g.pd.vel.from_numpy(v)
+    g.pd.hash_grid.update_grid()          # re-sorts the device arrays
+    np.testing.assert_array_equal(g.pd.vel.to_numpy(), v)   # host view keeps the caller's order, bit exact
+    p = g.pd.pos.to_numpy()
+    np.testing.assert_array_equal(p, o.pos)
+    assert g.pd.vel[5].tolist() == v[5].tolist()
+    g.pd.vel[5] = [1.0, 2.0, 3.0]
+    assert g.pd.vel.to_numpy()[5].tolist() == [1.0, 2.0, 3.0]
+    g.close()
+
+
+def test_bucket_overflow_is_an_error():
+    """ref: HashGrid.py:72-74 drops particles beyond maxInGrid; the library refuses instead (-3)."""
+    from wcsph_amd._lib import WcsphError
+    liquid = np.tile(np.array([[0.01, 0.21, 0.01]]), (10, 1)) + np.arange(10)[:, None] * 1e-4
+    solid = np.array([[-0.5, 0.0, -0.5], [0.5, 1.0, 0.5]])
+    import util
+    g = util.GpuSim(liquid, solid, mode="clean", maxInGrid=4)
+    g.pd.hash_grid.update_grid()
+    with pytest.raises(WcsphError) as e:
+        g.pd.sync()
+    assert e.value.code == -3
+    g.close()
+
+
+def test_escaped_particle_has_no_neighbours():
+    """Q4: a particle outside the initial bbox is neither inserted nor given neighbours."""
+    g, o = make_pair(6, "faithful", jitter=0.0)
+    p = g.pd.pos.to_numpy()
+    p[3] = [5.0, 5.0, 5.0]
+    g.pd.pos.from_numpy(p); o.pos[3] = p[3]
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    assert g.pd.hash_grid.neighborCount.to_numpy()[3] == 0 == o.neighborCount[3]
+    assert np.abs(g.pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-5
+    g.close()

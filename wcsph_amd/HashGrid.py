@@ -1,0 +1,135 @@
+"""HashGrid with the reference's constructor, attributes and methods (ref: HashGrid.py:8-152).
+
+The reference keeps a `count`-bucket hash table (64 slots each) and an explicit 2048-entry
+neighbour list per liquid particle, both cleared and refilled every step.  Here
+update_grid() is one call into libwcsph_hip.so which counting-sorts the particles into a
+dense z-fastest cell table; neighbours are re-walked from that table inside every pass.
+The reference table's aliasing (Q1) is reproduced in "faithful" mode through static
+per-cell multiplicity tables; `neighborCount` is the reference's raw list length.
+`neighbor`, `gridCount` and `grid` are materialised on demand for inspection only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .field import Field
+
+
+class _HostVec:
+    """shape-(1) ti.Vector.field stand-in held on the host (blockSize / min_boundary / max_boundary)."""
+
+    def __init__(self, dtype):
+        self._a = np.zeros((1, 3), dtype=dtype)
+        self.shape = (1,)
+
+    def to_numpy(self):
+        return self._a.copy()
+
+    def from_numpy(self, a):
+        self._a[...] = np.asarray(a).reshape(1, 3)
+
+    def __getitem__(self, i):
+        return self._a[i]
+
+
+class _NeighborList:
+    """HashGrid.neighbor[i, k] (ref: HashGrid.py:25,88-106): explicit list in ORIGINAL indices, -1 padded.
+    Entries of the reference's multiset that lie in the 5x5x5 walked cells are enumerated (with their
+    multiplicity); far entries that only alias into a walked bucket contribute exactly zero to every sum
+    and are counted in neighborCount but not enumerated."""
+
+    def __init__(self, grid):
+        self._g = grid
+
+    @property
+    def shape(self):
+        return (self._g.particle_data.liquid_count, self._g.maxNeighbour)
+
+    def rows(self, i0, n, cap=None):
+        pd = self._g.particle_data
+        ctx = pd._need_ctx()
+        cap = cap or self._g.maxNeighbour
+        counts = np.empty(n, np.int32)
+        lists = np.empty((n, cap), np.int32)
+        _lib.check(ctx, _lib.load().wcsph_neighbors_to_host(ctx, i0, n, cap, counts.ctypes.data, lists.ctypes.data))
+        return counts, lists
+
+    def to_numpy(self):
+        n = self._g.particle_data.liquid_count
+        if n * self._g.maxNeighbour > (1 << 28):
+            raise MemoryError("HashGrid.neighbor.to_numpy(): use .rows(i0, n, cap) on large scenes")
+        return self.rows(0, n)[1]
+
+    def __getitem__(self, ik):
+        i, k = ik
+        return self.rows(int(i), 1)[1][0, k]
+
+
+class HashGrid:
+    def __init__(self, gridR, maxInGrid, maxNeighbour, particle_data):
+        self.maxInGrid = maxInGrid
+        self.maxNeighbour = maxNeighbour
+        self.particle_data = particle_data
+        self.invGridR = 1.0 / gridR
+        self.gridR = gridR
+        self.searchR = gridR * 2.0
+        self.neighborCount = Field(particle_data, "neighborCount", 1, np.int32)
+        self.neighbor = _NeighborList(self)
+        self.blockSize = _HostVec(np.int32)
+        self.min_boundary = _HostVec(np.float32)
+        self.max_boundary = _HostVec(np.float32)
+
+    def setup_grid_gpu(self):
+        """ref: HashGrid.py:34-40 -- table allocation; device memory is owned by the library context."""
+        self.particle_data._need_ctx()
+
+    def setup_grid_cpu(self, maxboundarynp, minboundarynp):
+        """ref: HashGrid.py:44-54 -- fixes the grid box (never updated afterwards, Q4) and uploads positions."""
+        pd = self.particle_data
+        ctx = pd._need_ctx()
+        lib = _lib.load()
+        self.max_boundary.from_numpy(maxboundarynp)
+        self.min_boundary.from_numpy(minboundarynp)
+        pos = pd._initial_positions()
+        maxb = np.ascontiguousarray(maxboundarynp, np.float32).reshape(3)
+        minb = np.ascontiguousarray(minboundarynp, np.float32).reshape(3)
+        _lib.check(ctx, lib.wcsph_setup(ctx, pos.ctypes.data, maxb.ctypes.data, minb.ctypes.data))
+        bs = (C.c_int32 * 3)()
+        _lib.check(ctx, lib.wcsph_get_block_size(ctx, C.byref(bs)))
+        self.blockSize.from_numpy(np.array(list(bs), np.int32))
+        print("serach grid szie:", int(bs[0]) * int(bs[1]) * int(bs[2]))
+
+    def update_grid(self):
+        """ref: HashGrid.py:56-85"""
+        ctx = self.particle_data._need_ctx()
+        _lib.check(ctx, _lib.load().wcsph_grid_update(ctx))
+
+    # ---- host-side inspection helpers (not on the hot path) ----------------------------------
+    def _cells(self, pos):
+        mn = self.min_boundary.to_numpy()[0]
+        f = (pos.astype(np.float32) - mn) * np.float32(self.invGridR)
+        return np.trunc(f).astype(np.int64)
+
+    def get_cell_hash(self, a):
+        """ref: HashGrid.py:108-114 (int32 wrap-around), vectorised; `a` is [...,3] integer cell coordinates."""
+        a = np.asarray(a, dtype=np.int64)
+        def wrap(v):
+            return ((v + 2 ** 31) % 2 ** 32) - 2 ** 31
+        p1, p2, p3 = wrap(73856093 * a[..., 0]), wrap(19349663 * a[..., 1]), wrap(83492791 * a[..., 2])
+        x = (p1.astype(np.int32) ^ p2.astype(np.int32) ^ p3.astype(np.int32)).astype(np.int64)
+        n = self.particle_data.count
+        return np.mod(x, n)  # numpy mod is already the non-negative residue
+
+    def check_in_box(self, index):
+        bs = self.blockSize.to_numpy()[0]
+        index = np.asarray(index)
+        return np.all((index >= 0) & (index < bs), axis=-1).astype(np.int32)
+
+    @property
+    def gridCount(self):
+        """Reference bucket occupancy (ref: HashGrid.py:20,71), rebuilt on the host for inspection."""
+        pos = self.particle_data.pos.to_numpy()
+        cells = self._cells(pos)
+        inb = self.check_in_box(cells).astype(bool)
+        return np.bincount(self.get_cell_hash(cells[inb]), minlength=self.particle_data.count).astype(np.int32)

@@ -1,0 +1,116 @@
+"""ctypes binding of libwcsph_hip.so (include/wcsph.h).  Fails loudly when the HIP
+library is missing -- there is deliberately no CPU fallback in the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwcsph_hip.so")
+
+MODE_FAITHFUL, MODE_CLEAN = 0, 1
+
+ERRORS = {-1: "bad argument", -2: "HIP runtime error", -3: "hash bucket overflow (> maxInGrid)",
+          -4: "neighbour list overflow (> maxNeighbour)", -5: "non-finite reduction"}
+
+
+class Params(C.Structure):
+    """struct wcsph_params (include/wcsph.h)"""
+    _fields_ = [
+        ("n_liquid", C.c_int32), ("n_solid", C.c_int32), ("neighbor_mode", C.c_int32), ("max_in_grid", C.c_int32),
+        ("max_neighbour", C.c_int32), ("hash_table_size", C.c_int32), ("tension_fixed", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("particle_radius", C.c_double), ("cfl_radius", C.c_double), ("user_max_t", C.c_double),
+        ("user_min_t", C.c_double),
+        ("rho_L0", C.c_float), ("rho_S0", C.c_float), ("VL0", C.c_float), ("VS0", C.c_float),
+        ("liqiudMass", C.c_float), ("gravity", C.c_float * 3),
+        ("dim_coff", C.c_float), ("viscosity", C.c_float), ("viscosity_b", C.c_float), ("viscosity_err", C.c_float),
+        ("tension_coff", C.c_float), ("tension_coff_b", C.c_float),
+        ("viscosity_omega", C.c_float), ("vorticity_coff", C.c_float), ("vorticity_init", C.c_float),
+        ("eps", C.c_float),
+        ("ss_searchR", C.c_float), ("ss_mk", C.c_float), ("ss_ml", C.c_float), ("ss_VL0", C.c_float),
+        ("ss_VS0", C.c_float), ("ss_mass", C.c_float), ("ss_rho0", C.c_float), ("ss_stiff", C.c_float),
+        ("ss_dim", C.c_float), ("ss_visc", C.c_float), ("ss_visc_b", C.c_float), ("reserved1", C.c_float),
+    ]
+
+
+# enum wcsph_field
+FIELDS = ["pos", "vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s",
+          "rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "cg_Minv", "neighborCount"]
+FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
+# enum wcsph_scalar
+SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
+           "tension_coff", "tension_coff_b", "vel_max0"]
+SCALAR_ID = {n: i for i, n in enumerate(SCALARS)}
+
+# every entry point include/wcsph.h declares that takes only the context
+CTX_ONLY = [
+    "wcsph_destroy", "wcsph_sync", "wcsph_grid_update",
+    "wcsph_dfsph_reset_param", "wcsph_dfsph_compute_density", "wcsph_dfsph_compute_coff",
+    "wcsph_dfsph_warmstart_divergence", "wcsph_dfsph_begin_divergence", "wcsph_dfsph_divergence_iter",
+    "wcsph_dfsph_end_divergence", "wcsph_dfsph_warmstart_pressure", "wcsph_dfsph_begin_pressure",
+    "wcsph_dfsph_pressure_iter", "wcsph_dfsph_end_pressure", "wcsph_dfsph_clear_nonpressure",
+    "wcsph_dfsph_tension", "wcsph_dfsph_visc_init", "wcsph_dfsph_visc_iter", "wcsph_dfsph_visc_end",
+    "wcsph_dfsph_vorticity", "wcsph_dfsph_cfl_reduce", "wcsph_dfsph_update_vel", "wcsph_dfsph_update_pos",
+    "wcsph_dfsph_compute_nonpressure_force", "wcsph_dfsph_optimize_time_step", "wcsph_dfsph_solve_divergence",
+    "wcsph_dfsph_solve_pressure", "wcsph_dfsph_step",
+    "wcsph_sesph_reset_param", "wcsph_sesph_density", "wcsph_sesph_pressure", "wcsph_sesph_force",
+    "wcsph_sesph_integrate", "wcsph_sesph_step",
+]
+OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_count", "wcsph_setup",
+         "wcsph_get_block_size", "wcsph_field_to_host", "wcsph_field_from_host", "wcsph_get_scalar",
+         "wcsph_set_scalar", "wcsph_get_iters", "wcsph_set_iters", "wcsph_neighbors_to_host", "wcsph_time_kernel",
+         "wcsph_field_gather_rows", "wcsph_field_scatter_rows", "wcsph_set_owned"]
+ALL_SYMBOLS = CTX_ONLY + OTHER
+
+_lib = None
+
+
+def load():
+    """Load libwcsph_hip.so.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "wcsph_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.wcsph_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    lib.wcsph_last_error.argtypes = [vp]
+    lib.wcsph_last_error.restype = C.c_char_p
+    lib.wcsph_set_stream.argtypes = [vp, vp]
+    lib.wcsph_device_count.argtypes = []
+    lib.wcsph_setup.argtypes = [vp, vp, vp, vp]
+    lib.wcsph_get_block_size.argtypes = [vp, C.POINTER(C.c_int32 * 3)]
+    lib.wcsph_field_to_host.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.wcsph_field_from_host.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.wcsph_get_scalar.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    lib.wcsph_set_scalar.argtypes = [vp, C.c_int, C.c_float]
+    lib.wcsph_get_iters.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.wcsph_set_iters.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.wcsph_neighbors_to_host.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    lib.wcsph_time_kernel.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_float)]
+    lib.wcsph_field_gather_rows.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
+    lib.wcsph_field_scatter_rows.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
+    lib.wcsph_set_owned.argtypes = [vp, C.c_int32]
+    for name in CTX_ONLY:
+        getattr(lib, name).argtypes = [vp]
+    for name in ALL_SYMBOLS:
+        if name != "wcsph_last_error":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class WcsphError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("wcsph error %d (%s): %s" % (code, ERRORS.get(code, "?"), msg))
+        self.code = code
+
+
+def check(ctx, rc):
+    if rc != 0:
+        lib = load()
+        msg = lib.wcsph_last_error(ctx)
+        raise WcsphError(rc, msg.decode() if msg else "")
+    return rc

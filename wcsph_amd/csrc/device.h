@@ -1,0 +1,195 @@
+// device.h -- device-side data view, pair geometry and the neighbour walk shared by every pass.
+//
+// Layout (DESIGN.md "Data layout in HBM"): liquid particles live in CELL-SORTED order in
+// SoA arrays; vec3 fields are float4-padded so that one neighbour gather is a single
+// 16-byte load.  pos.w carries the particle's packed cell (cx | cy<<10 | cz<<20, -1 when the
+// particle is outside the grid box, ref: HashGrid.py:68-69,117-124).  Static solids are
+// sorted once.  Cells are linearised z-fastest so that the 5 cells of one (dx,dy) row of
+// the 5x5x5 walk (ref: HashGrid.py:82-85) are ONE contiguous particle range.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+#define BLOCK 256
+#define ALIAS_STRIDE 128 /* uint16 per aliased cell: [0]=n entries, [1]=self multiplicity, [2..] = k | extra<<8 */
+
+struct Dev {
+  // counts
+  int nl, ns, n_owned;
+  int nx, ny, nz, ncell;
+  int table_size;  // reference hash table size (HashGrid.py:114)
+  int faithful;
+  int cfl_prefix;  // Q5: CFL max covers original indices [0, cfl_prefix)
+  int max_neighbour, max_in_grid;
+  // grid box
+  float minx, miny, minz, inv_grid;
+  // CubicKernel (ref: kernels/CubicKernel.py:12-17) for the active solver
+  float h, h2, inv_h, ml_h3, mk_h3;
+  // material constants (ref: ParticleData.py:18-24,61-87)
+  float VL0, VS0, rho_L0, rho_S0, mass, eps;
+  float gx, gy, gz;
+  float dim_coff, visc, visc_b;
+  float tension, tension_b, adh_mk;
+  float visc_omega, vort_coff, vort_init;
+  // sesph private constants (ref: sesph.py:34-62)
+  float ss_VL0, ss_VS0, ss_mass, ss_rho0, ss_stiff, ss_dim, ss_visc, ss_visc_b;
+  // liquid, cell-sorted
+  float4 *pos, *vel, *vel_guess, *omega;  // persistent (re-sorted every grid update)
+  float *kappa, *kappa_v;                 // persistent
+  int *oid;                               // sorted -> original index
+  int *where;                             // original -> sorted index
+  float4 *d_vel, *d_omega, *normal, *cg_r, *cg_dir, *cg_Ad, *cg_s;
+  float4 *minv0, *minv1, *minv2;          // rows of cg_Minv
+  float *rho, *adv_rho, *pressure, *vel_max, *alpha, *kbuf;
+  int *ncount;                            // HashGrid.neighborCount (raw list length)
+  // solids, cell-sorted once
+  float4 *spos;
+  // cell tables
+  int *cs_l;          // [ncell+2] liquid cell start (ncell = out-of-box bin)
+  int *cs_s;          // [ncell+1] solid cell start
+  int *cell_info;     // [ncell] bit0: solids within the 5^3 walk; bits1..: alias slot + 1
+  uint16_t *alias;    // [n_alias][ALIAS_STRIDE]
+  // reductions
+  double *acc;        // [8]
+  int *flags;         // [4] error bits, vmax bits
+};
+
+enum { ACC_ERR = 0, ACC_DAD = 1, ACC_DNEW = 2, ACC_DZERO = 3 };
+enum { FLAG_ERR = 0, FLAG_VMAX = 1 };
+enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2 };
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+  return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 f4(float3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+// ref: kernels/CubicKernel.py:43-54 (Cubic_W_P) * m_k*h3 -- caller guarantees r2 <= h2
+__device__ __forceinline__ float cubic_W(const Dev &d, float r2) {
+  float q = sqrtf(r2) * d.inv_h;
+  float f = 1.0f - q;
+  float w = (q <= 0.5f) ? (6.0f * q * q * q - 6.0f * q * q + 1.0f) : (2.0f * f * f * f);
+  return (q <= 1.0f) ? w * d.mk_h3 : 0.0f;
+}
+// ref: kernels/CubicKernel.py:20-32 (CubicGradW) -- returns g with gradW = g * r
+__device__ __forceinline__ float cubic_gradW_scale(const Dev &d, float r2) {
+  float inv_rl = rsqrtf(fmaxf(r2, 1e-30f));
+  float rl = r2 * inv_rl;
+  float q = rl * d.inv_h;
+  float f = 1.0f - q;
+  float s = (q <= 0.5f) ? q * (3.0f * q - 2.0f) : -(f * f);
+  float g = s * d.ml_h3 * inv_rl * d.inv_h;
+  return (rl > 1.0e-5f && q <= 1.0f) ? g : 0.0f;
+}
+
+// XCD-aware block remap: the dispatcher places block b on XCD b%8 (MI355X_MICROARCH "Workgroup
+// dispatch"); give every XCD one CONTIGUOUS eighth of the cell-sorted particle range so that its
+// private L2 holds one spatial region instead of a 1/8 sample of all of them.  gridDim.x is a
+// multiple of 8 by construction (grid_for()).
+__device__ __forceinline__ int sorted_index() {
+  int per = gridDim.x >> 3;
+  int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return blk * BLOCK + threadIdx.x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+  return v;
+}
+// every thread of the block must call this
+__device__ __forceinline__ void block_accumulate(double *dst, float v) {
+  __shared__ float sh[BLOCK / WAVE];
+  v = wave_sum(v);
+  int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < BLOCK / WAVE; k++) s += sh[k];
+    atomicAdd(dst, (double)s);
+  }
+}
+
+// The neighbour walk.  fl(j, r, r2, m) is called for every liquid list entry j != i inside the
+// support (r = x_i - x_j, m = multiplicity of the entry in the reference's bucket multiset),
+// fs(j, r, r2, m) likewise for solid entries.  Entries outside the support contribute exactly zero
+// to every kernel-weighted sum of the reference (compact support) and are skipped here; the raw
+// list LENGTH the reference also uses (Q2/Q10) is d.ncount[i], built by the grid update.
+template <class FL, class FS>
+__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, FL &&fl, FS &&fs) {
+  const int cw = __float_as_int(pi.w);
+  if (cw < 0) return;  // outside the grid box: no neighbours (ref: HashGrid.py:80-81, Q4)
+  const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
+  const int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
+  const float3 xi = xyz(pi);
+  const int info = d.cell_info[(cx * d.ny + cy) * d.nz + cz];
+#pragma unroll 1
+  for (int dx = -2; dx <= 2; dx++) {
+    const int x = cx + dx;
+    if ((unsigned)x >= (unsigned)d.nx) continue;
+#pragma unroll 1
+    for (int dy = -2; dy <= 2; dy++) {
+      const int y = cy + dy;
+      if ((unsigned)y >= (unsigned)d.ny) continue;
+      const int base = (x * d.ny + y) * d.nz;
+      const int lo = d.cs_l[base + z0], hi = d.cs_l[base + z1];
+      for (int j = lo; j < hi; j++) {
+        const float4 pj = d.pos[j];
+        const float3 r = xi - xyz(pj);
+        const float r2 = dot3(r, r);
+        if (r2 <= d.h2 && j != i) fl(j, r, r2, 1.0f);
+      }
+    }
+  }
+  if (info & 1) {
+#pragma unroll 1
+    for (int dx = -2; dx <= 2; dx++) {
+      const int x = cx + dx;
+      if ((unsigned)x >= (unsigned)d.nx) continue;
+#pragma unroll 1
+      for (int dy = -2; dy <= 2; dy++) {
+        const int y = cy + dy;
+        if ((unsigned)y >= (unsigned)d.ny) continue;
+        const int base = (x * d.ny + y) * d.nz;
+        const int lo = d.cs_s[base + z0], hi = d.cs_s[base + z1];
+        for (int j = lo; j < hi; j++) {
+          const float4 pj = d.spos[j];
+          const float3 r = xi - xyz(pj);
+          const float r2 = dot3(r, r);
+          if (r2 <= d.h2) fs(j, r, r2, 1.0f);
+        }
+      }
+    }
+  }
+  if (info >> 1) {
+    // faithful mode, rare: some of this cell's 125 walked cells share a hash bucket, so the
+    // reference visits their particles again (Q1).  Entries: k = walked-cell index, extra visits.
+    const uint16_t *e = d.alias + (size_t)((info >> 1) - 1) * ALIAS_STRIDE;
+    const int n = e[0];
+#pragma unroll 1
+    for (int t = 0; t < n; t++) {
+      const int k = e[2 + t] & 0xff;
+      const float m = (float)(e[2 + t] >> 8);
+      const int x = cx + k / 25 - 2, y = cy + (k / 5) % 5 - 2, z = cz + k % 5 - 2;
+      const int c = (x * d.ny + y) * d.nz + z;
+      for (int j = d.cs_l[c]; j < d.cs_l[c + 1]; j++) {
+        const float3 r = xi - xyz(d.pos[j]);
+        const float r2 = dot3(r, r);
+        if (r2 <= d.h2 && j != i) fl(j, r, r2, m);
+      }
+      for (int j = d.cs_s[c]; j < d.cs_s[c + 1]; j++) {
+        const float3 r = xi - xyz(d.spos[j]);
+        const float r2 = dot3(r, r);
+        if (r2 <= d.h2) fs(j, r, r2, m);
+      }
+    }
+  }
+}

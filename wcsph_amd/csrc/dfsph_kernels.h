@@ -1,0 +1,482 @@
+// dfsph_kernels.h -- the @ti.kernel loops of dfsph.py as hand-written gfx950 kernels.
+// One thread per cell-sorted liquid particle; neighbours are re-walked from the cell table
+// (device.h walk()) instead of read from a materialised 8 KiB/particle list.
+#pragma once
+#include "device.h"
+
+#define LOAD_I                                        \
+  const int i = sorted_index();                       \
+  const bool live = i < d.nl;                         \
+  const float4 pi = live ? d.pos[i] : make_float4(0, 0, 0, __int_as_float(-1)); \
+  const bool own = live && d.oid[i] < d.n_owned;
+
+// ref: dfsph.py:248-262 compute_density
+__global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
+  LOAD_I
+  if (!own) return;
+  float sl = 0.f, ss = 0.f;
+  walk(d, i, pi, [&](int, float3, float r2, float m) { sl += m * cubic_W(d, r2); },
+       [&](int, float3, float r2, float m) { ss += m * cubic_W(d, r2); });
+  d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+}
+
+// ref: dfsph.py:345-372 compute_dfsph_coff
+__global__ void __launch_bounds__(BLOCK) k_coff(Dev d) {
+  LOAD_I
+  if (!own) return;
+  float3 sg = f3(0, 0, 0);
+  float sq = 0.f;
+  walk(d, i, pi,
+       [&](int, float3 r, float r2, float m) {
+         float g = cubic_gradW_scale(d, r2) * d.VL0;
+         sq += m * g * g * r2;
+         sg = sg + r * (m * g);
+       },
+       [&](int, float3 r, float r2, float m) { sg = sg + r * (m * cubic_gradW_scale(d, r2) * d.VS0); });
+  sq += dot3(sg, sg);
+  d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
+}
+
+// fused density + alpha (one walk instead of two); used by wcsph_dfsph_step
+__global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
+  LOAD_I
+  if (!own) return;
+  float sl = 0.f, ss = 0.f, sq = 0.f;
+  float3 sg = f3(0, 0, 0);
+  walk(d, i, pi,
+       [&](int, float3 r, float r2, float m) {
+         sl += m * cubic_W(d, r2);
+         float g = cubic_gradW_scale(d, r2) * d.VL0;
+         sq += m * g * g * r2;
+         sg = sg + r * (m * g);
+       },
+       [&](int, float3 r, float r2, float m) {
+         ss += m * cubic_W(d, r2);
+         sg = sg + r * (m * cubic_gradW_scale(d, r2) * d.VS0);
+       });
+  d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  sq += dot3(sg, sg);
+  d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
+}
+
+// ---- density-change passes ------------------------------------------------------------------
+enum { DRHO_PLAIN = 0, DRHO_WARM = 1, DRHO_BEGIN = 2, DRHO_ITER = 3 };
+
+// ref: dfsph.py:374-392 update_drho_divergence, inlined at :418 (WARM), :443 (BEGIN), :475 (ITER)
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_drho_div(Dev d, float dt) {
+  LOAD_I
+  float a = 0.f;
+  if (own) {
+    if (MODE == DRHO_WARM) d.kappa_v[i] = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
+    const float3 vi = xyz(d.vel[i]);
+    walk(d, i, pi,
+         [&](int j, float3 r, float r2, float m) {
+           a += m * d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(d.vel[j]), r);
+         },
+         [&](int, float3 r, float r2, float m) { a += m * d.VS0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
+    a = fmaxf(a, 0.0f);
+    if (d.ncount[i] < 20) a = 0.0f;  // raw list length, Q2
+    d.adv_rho[i] = a;
+    if (MODE == DRHO_BEGIN) { d.alpha[i] = d.alpha[i] / dt; d.kappa_v[i] = 0.0f; }
+  }
+  if (MODE == DRHO_ITER) block_accumulate(&d.acc[ACC_ERR], a);  // ref: dfsph.py:476 avg_density_err += adv_rho
+}
+
+// ref: dfsph.py:394-412 update_drho_pressure, inlined at :513 (BEGIN), :545 (ITER)
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_drho_press(Dev d, float dt) {
+  LOAD_I
+  float e = 0.f;
+  if (own) {
+    const float3 vi = xyz(d.vel[i]);
+    float t = 0.f;
+    walk(d, i, pi,
+         [&](int j, float3 r, float r2, float m) {
+           t += m * d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(d.vel[j]), r);
+         },
+         [&](int, float3 r, float r2, float m) { t += m * d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
+    float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
+    d.adv_rho[i] = a;
+    e = a - 1.0f;
+    if (MODE == DRHO_BEGIN) { d.alpha[i] = d.alpha[i] / dt / dt; d.kappa[i] = 0.0f; }
+  }
+  if (MODE == DRHO_ITER) block_accumulate(&d.acc[ACC_ERR], e);  // ref: dfsph.py:546
+}
+
+// first half of divergence_iter / pressure_iter, per-particle part (ref: dfsph.py:456-458, 525-527):
+// k_i = b_i * alpha_i ; kappa_i += k_i.  kbuf holds k for the neighbour loop that follows.
+__global__ void k_make_k(Dev d, float *kap, float bias) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  float k = (d.adv_rho[i] - bias) * d.alpha[i];
+  d.kbuf[i] = k;
+  if (d.oid[i] < d.n_owned) kap[i] += k;
+}
+
+// neighbour loop of divergence_iter / pressure_iter / warmstart_divergence_vel
+// (ref: dfsph.py:460-471, 529-541, 420-439): v_i += dt * sum (k_i + k_j) V gradW with the eps gates.
+// COND 0: always; COND 1: only where adv_rho_i > 0 (divergence warm start, :421)
+template <int COND>
+__global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float *kb, float dt) {
+  LOAD_I
+  if (!own) return;
+  if (COND == 1 && !(d.adv_rho[i] > 0.0f)) return;
+  const float ki = kb[i];
+  float3 acc = f3(0, 0, 0);
+  const bool ks = fabsf(ki) > d.eps;
+  walk(d, i, pi,
+       [&](int j, float3 r, float r2, float m) {
+         float s = ki + kb[j];
+         if (fabsf(s) > d.eps) acc = acc + r * (m * s * cubic_gradW_scale(d, r2));
+       },
+       [&](int, float3 r, float r2, float m) {
+         if (ks) acc = acc + r * (m * ki * (d.VS0 / d.VL0) * cubic_gradW_scale(d, r2));
+       });
+  float4 v = d.vel[i];
+  const float f = dt * d.VL0;
+  v.x += f * acc.x; v.y += f * acc.y; v.z += f * acc.z;
+  d.vel[i] = v;
+}
+
+// ref: dfsph.py:487-508 warmstart_pressure, literal (Q7: the gate adv_rho > rho_L0 practically never
+// opens; the solid branch reads kappa_v).  kappa is rescaled first (:490).
+__global__ void k_warm_press_scale(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  d.kappa[i] = fmaxf(d.kappa[i] / dt / dt, -0.5f * d.rho_L0 * d.rho_L0);
+}
+__global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
+  LOAD_I
+  if (!own) return;
+  if (!(d.adv_rho[i] > d.rho_L0)) return;
+  const float ki = d.kappa[i], kvi = d.kappa_v[i];
+  float3 acc = f3(0, 0, 0);
+  walk(d, i, pi,
+       [&](int j, float3 r, float r2, float m) {
+         float s = ki + d.kappa[j];
+         if (fabsf(s) > d.eps) acc = acc + r * (m * dt * s * d.VL0 * cubic_gradW_scale(d, r2));
+       },
+       [&](int, float3 r, float r2, float m) {
+         if (fabsf(ki) > d.eps) acc = acc + r * (m * dt * kvi * d.VS0 * cubic_gradW_scale(d, r2));
+       });
+  float4 v = d.vel[i];
+  v.x += acc.x; v.y += acc.y; v.z += acc.z;
+  d.vel[i] = v;
+}
+
+// ref: dfsph.py:480-484, 549-552
+__global__ void k_end_div(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  d.kappa_v[i] *= dt;
+  d.alpha[i] *= dt;
+}
+__global__ void k_end_press(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  d.kappa[i] *= dt * dt;
+}
+
+// ref: dfsph.py:167-178 reset_param
+__global__ void k_reset(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  d.vel[i] = make_float4(0, 0, 0, 0);
+  d.omega[i] = make_float4(0, 0, 0, 0);
+  d.pressure[i] = 0.f; d.kappa_v[i] = 0.f; d.kappa[i] = 0.f;
+}
+// ref: dfsph.py:333-336 clear_nonpressure
+__global__ void k_clear_nonpressure(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  d.d_vel[i] = make_float4(d.gx, d.gy, d.gz, 0);
+}
+
+// ---- surface tension (ref: dfsph.py:264-305) ------------------------------------------------
+// Fixed semantics (DESIGN.md "Quirks not reproduced"): the reference multiplies the running normal
+// by h once per list entry (Q8, order dependent garbage) and applies the curvature term to every raw
+// list entry; here n_i = h * sum_j (m/rho_j) gradW and the curvature term runs over the support.
+// The cohesion value is discarded exactly as in the reference (Q9).
+__global__ void __launch_bounds__(BLOCK) k_tension_normal(Dev d) {
+  LOAD_I
+  if (!own) return;
+  float3 n = f3(0, 0, 0);
+  walk(d, i, pi, [&](int j, float3 r, float r2, float m) { n = n + r * (m * d.mass / d.rho[j] * cubic_gradW_scale(d, r2)); },
+       [&](int, float3, float, float) {});
+  d.normal[i] = f4(n * d.h, 0);
+}
+// ref: kernels/AdhesionKernel.py:20-29
+__device__ __forceinline__ float adhesion_W(const Dev &d, float r) {
+  float res = 0.f;
+  if (r * r <= d.h2 && r > 0.5f * d.h) res = d.adh_mk * powf(-4.0f * r * r / d.h + 6.0f * r - 2.0f * d.h, 0.25f);
+  return res;
+}
+__global__ void __launch_bounds__(BLOCK) k_tension_accel(Dev d) {
+  LOAD_I
+  if (!own) return;
+  const float3 ni = xyz(d.normal[i]);
+  const float rhoi = d.rho[i];
+  float3 acc = f3(0, 0, 0);
+  walk(d, i, pi,
+       [&](int j, float3, float, float m) {
+         float kij = 2.0f * d.rho_L0 / (rhoi + d.rho[j]);
+         acc = acc + (ni - xyz(d.normal[j])) * (-d.tension * kij * m);
+       },
+       [&](int j, float3 r, float r2, float m) {
+         float3 pj = xyz(d.spos[j]);
+         float3 c = pj - f3(0.0f, 0.5f, 0.0f);
+         float dis = sqrtf(dot3(c, c));
+         if (r2 > d.eps && dis < 0.26f) {  // scene hack of the reference, dfsph.py:300-302
+           float rl = sqrtf(r2);
+           acc = acc + r * (m * -d.tension_b * d.rho_S0 * d.VS0 * adhesion_W(d, rl) / rl);
+         }
+       });
+  float4 a = d.d_vel[i];
+  a.x += acc.x; a.y += acc.y; a.z += acc.z;
+  d.d_vel[i] = a;
+}
+
+// ---- implicit viscosity PCG (ref: dfsph.py:181-246, 339-343) --------------------------------
+// ref: dfsph.py:181-195 get_viscosity_Ax
+__device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const float4 *x, float dt) {
+  const float3 xi = xyz(x[i]);
+  const float rhoi = d.rho[i];
+  const float e = 0.01f * d.h2;
+  float3 ret = f3(0, 0, 0);
+  const float cl = d.dim_coff * d.visc * d.mass;
+  const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
+  walk(d, i, pi,
+       [&](int j, float3 r, float r2, float m) {
+         float s = cl / d.rho[j] * dot3(xi - xyz(x[j]), r) / (r2 + e);
+         ret = ret + r * (m * s * cubic_gradW_scale(d, r2));
+       },
+       [&](int, float3 r, float r2, float m) {
+         float s = cs * dot3(xi, r) / (r2 + e);
+         ret = ret + r * (m * s * cubic_gradW_scale(d, r2));
+       });
+  return xi - ret * (dt / rhoi);
+}
+// ref: dfsph.py:199-200
+__global__ void k_visc_guess(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  float4 g = d.vel_guess[i], v = d.vel[i];
+  d.vel_guess[i] = make_float4(g.x + v.x, g.y + v.y, g.z + v.z, 0);
+}
+// ref: dfsph.py:202-215 block-Jacobi preconditioner (I - dt/rho_i * sum c gradW (x) r)^-1
+__global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
+  LOAD_I
+  if (!own) return;
+  const float rhoi = d.rho[i];
+  const float e = 0.01f * d.h2;
+  const float cl = d.dim_coff * d.visc * d.mass;
+  const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
+  float m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;  // gradW (x) r = g * r r^T is symmetric
+  auto accum = [&](float3 r, float s) {
+    m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
+    m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
+  };
+  walk(d, i, pi,
+       [&](int j, float3 r, float r2, float m) { accum(r, m * cl / d.rho[j] / (r2 + e) * cubic_gradW_scale(d, r2)); },
+       [&](int, float3 r, float r2, float m) { accum(r, m * cs / (r2 + e) * cubic_gradW_scale(d, r2)); });
+  const float f = dt / rhoi;
+  float a = 1.0f - m00 * f, b = -m01 * f, c = -m02 * f, dd = 1.0f - m11 * f, ee = -m12 * f, ff = 1.0f - m22 * f;
+  // inverse of the symmetric matrix [[a b c][b dd ee][c ee ff]] by adjugate / determinant
+  float A = dd * ff - ee * ee, B = -(b * ff - ee * c), C = b * ee - dd * c;
+  float id = 1.0f / (a * A + b * B + c * C);
+  float i11 = (a * ff - c * c) * id, i12 = -(a * ee - c * b) * id, i22 = (a * dd - b * b) * id;
+  d.minv0[i] = make_float4(A * id, B * id, C * id, 0);
+  d.minv1[i] = make_float4(B * id, i11, i12, 0);
+  d.minv2[i] = make_float4(C * id, i12, i22, 0);
+}
+__device__ __forceinline__ float3 minv_mul(const Dev &d, int i, float3 v) {
+  float4 r0 = d.minv0[i], r1 = d.minv1[i], r2 = d.minv2[i];
+  return f3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
+}
+// ref: dfsph.py:217-223: r = v - A(v_guess); d = Minv r; delta_zero = sum r.d
+__global__ void __launch_bounds__(BLOCK) k_visc_residual(Dev d, float dt) {
+  LOAD_I
+  float part = 0.f;
+  if (own) {
+    float3 ax = visc_Ax(d, i, pi, d.vel_guess, dt);
+    float3 r = xyz(d.vel[i]) - ax;
+    float3 dir = minv_mul(d, i, r);
+    d.cg_r[i] = f4(r, 0);
+    d.cg_dir[i] = f4(dir, 0);
+    part = dot3(r, dir);
+  }
+  block_accumulate(&d.acc[ACC_DZERO], part);
+}
+// ref: dfsph.py:227-230: Ad = A(dir); dAd = eps + sum dir.Ad
+__global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
+  LOAD_I
+  float part = 0.f;
+  if (own) {
+    float3 ad = visc_Ax(d, i, pi, d.cg_dir, dt);
+    d.cg_Ad[i] = f4(ad, 0);
+    part = dot3(xyz(d.cg_dir[i]), ad);
+  }
+  block_accumulate(&d.acc[ACC_DAD], part);
+}
+// ref: dfsph.py:233-240: alpha = delta / dAd; v_guess += alpha d; r -= alpha Ad; s = Minv r; delta' = sum r.s
+__global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float part = 0.f;
+  if (i < d.nl && d.oid[i] < d.n_owned) {
+    const float alpha = delta / (float)((double)d.eps + d.acc[ACC_DAD]);
+    float3 dir = xyz(d.cg_dir[i]);
+    d.vel_guess[i] = f4(xyz(d.vel_guess[i]) + dir * alpha, 0);
+    float3 r = xyz(d.cg_r[i]) - xyz(d.cg_Ad[i]) * alpha;
+    float3 s = minv_mul(d, i, r);
+    d.cg_r[i] = f4(r, 0);
+    d.cg_s[i] = f4(s, 0);
+    part = dot3(r, s);
+  }
+  block_accumulate(&d.acc[ACC_DNEW], part);
+}
+// ref: dfsph.py:243-246: beta = delta' / delta_old; d = s + beta d
+__global__ void k_visc_dir(Dev d, float delta_old) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  const float beta = (float)d.acc[ACC_DNEW] / delta_old;
+  d.cg_dir[i] = f4(xyz(d.cg_s[i]) + xyz(d.cg_dir[i]) * beta, 0);
+}
+// ref: dfsph.py:339-343 end_viscosity
+__global__ void k_visc_end(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  float3 g = xyz(d.vel_guess[i]), v = xyz(d.vel[i]);
+  float3 a = xyz(d.d_vel[i]) + (g - v) * (1.0f / dt);
+  d.d_vel[i] = f4(a, 0);
+  d.vel_guess[i] = f4(g - v, 0);
+}
+
+// ---- micropolar vorticity (ref: dfsph.py:307-330) -------------------------------------------
+// Q18: solid j => omega_j = vel_j = 0 (the reference indexes out of bounds there).
+// Q10: the damping term is added once per raw list entry => * neighborCount.
+__global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
+  LOAD_I
+  if (!own) return;
+  const float3 wi = xyz(d.omega[i]), vi = xyz(d.vel[i]);
+  const float rhoi = d.rho[i];
+  float3 dom = f3(0, 0, 0), dv = f3(0, 0, 0);
+  const float c1 = -1.0f / dt * d.vort_init * d.visc_omega * d.mass;
+  const float c2 = d.vort_coff / rhoi * d.mass;
+  const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
+  walk(d, i, pi,
+       [&](int j, float3 r, float r2, float m) {
+         float3 dw = wi - xyz(d.omega[j]);
+         float g = m * cubic_gradW_scale(d, r2);
+         dom = dom + dw * (m * c1 / d.rho[j] * cubic_W(d, r2));
+         dv = dv + cross3(dw, r) * (c2 * g);
+         dom = dom + cross3(vi - xyz(d.vel[j]), r) * (c3 * g);
+       },
+       [&](int, float3 r, float r2, float m) {
+         float g = m * cubic_gradW_scale(d, r2);
+         dv = dv + cross3(wi, r) * (d.vort_coff / rhoi * d.rho_L0 * d.VS0 * g);
+         dom = dom + cross3(vi, r) * (d.vort_coff / rhoi * d.vort_init * d.rho_L0 * d.VL0 * g);
+       });
+  dom = dom + wi * (-2.0f * d.vort_init * d.vort_coff * (float)d.ncount[i]);
+  d.d_omega[i] = f4(dom, 0);
+  float4 a = d.d_vel[i];
+  a.x += dv.x; a.y += dv.y; a.z += dv.z;
+  d.d_vel[i] = a;
+}
+// second loop of compute_vorticity (ref: dfsph.py:329-330); separate launch: omega_j is read above
+__global__ void k_vorticity_integrate(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  float4 w = d.omega[i], dw = d.d_omega[i];
+  d.omega[i] = make_float4(w.x + dw.x * dt, w.y + dw.y * dt, w.z + dw.z * dt, 0);
+}
+
+// ---- CFL (ref: dfsph.py:555-568 + :107-111) -------------------------------------------------
+// The reference's strided tree leaves max over original indices [0, 2^floor(log2(N-1))) in slot 0 (Q5).
+__global__ void __launch_bounds__(BLOCK) k_cfl(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float vm = 0.f;
+  if (i < d.nl) {
+    float3 v = xyz(d.vel[i]) + xyz(d.d_vel[i]) * dt;
+    float m = fmaxf(dot3(v, v), 0.1f);
+    d.vel_max[i] = m;
+    int o = d.oid[i];
+    if (o < d.cfl_prefix && o < d.n_owned) vm = m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_down(vm, o, WAVE));
+  if ((threadIdx.x & (WAVE - 1)) == 0 && vm > 0.f) atomicMax(&d.flags[FLAG_VMAX], __float_as_int(vm));
+}
+__global__ void k_cfl_store(Dev d) {  // slot 0 of the reference's vel_max field holds the result
+  if (d.nl > 0 && d.n_owned > 0) d.vel_max[d.where[0]] = __int_as_float(d.flags[FLAG_VMAX]);
+}
+
+// ref: dfsph.py:572-580
+__global__ void k_update_vel(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  float4 v = d.vel[i], a = d.d_vel[i];
+  d.vel[i] = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);
+}
+__global__ void k_update_pos(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  float4 p = d.pos[i], v = d.vel[i];
+  d.pos[i] = make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w);
+}
+
+// ---- sesph.py (ref: sesph.py:130-196); Dev.h/ml_h3/mk_h3 hold the script's private kernel constants --
+__global__ void k_ss_reset(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  d.vel[i] = make_float4(0, 0, 0, 0);
+  d.pressure[i] = 0.f;
+}
+__global__ void __launch_bounds__(BLOCK) k_ss_density(Dev d) {
+  LOAD_I
+  if (!own) return;
+  float sl = 0.f, ss = 0.f;
+  walk(d, i, pi, [&](int, float3, float r2, float m) { sl += m * cubic_W(d, r2); },
+       [&](int, float3, float r2, float m) { ss += m * cubic_W(d, r2); });
+  d.rho[i] = (d.ss_VL0 * (d.mk_h3 + sl) + d.ss_VS0 * ss) * d.ss_rho0;
+}
+__global__ void k_ss_pressure(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  float rho = fmaxf(d.rho[i], d.ss_rho0);
+  d.rho[i] = rho;
+  float q = rho / d.ss_rho0, qq = q * q, qqqq = qq * qq;
+  d.pressure[i] = d.ss_stiff * (qqqq * qq * q - 1.0f);
+}
+__global__ void __launch_bounds__(BLOCK) k_ss_force(Dev d) {
+  LOAD_I
+  if (!own) return;
+  const float3 vi = xyz(d.vel[i]);
+  const float rhoi = d.rho[i], prsi = d.pressure[i];
+  const float e = 0.01f * d.h2;
+  const float pi2 = prsi / (rhoi * rhoi);
+  float3 a = f3(d.gx, d.gy, d.gz);
+  walk(d, i, pi,
+       [&](int j, float3 r, float r2, float m) {
+         float g = m * cubic_gradW_scale(d, r2);
+         float rhoj = d.rho[j];
+         float visc = d.ss_dim * d.ss_visc * d.ss_mass / rhoj * dot3(vi - xyz(d.vel[j]), r) / (r2 + e);
+         float prs = -d.ss_rho0 * d.ss_VL0 * (pi2 + d.pressure[j] / (rhoj * rhoj));
+         a = a + r * ((visc + prs) * g);
+       },
+       [&](int, float3 r, float r2, float m) {
+         float g = m * cubic_gradW_scale(d, r2);
+         float visc = d.ss_dim * d.ss_visc_b * d.ss_VS0 * (rhoi / d.ss_rho0) * dot3(vi, r) / (r2 + e);
+         float prs = -d.ss_rho0 * d.ss_VS0 * (pi2 + prsi / (d.ss_rho0 * d.ss_rho0));
+         a = a + r * ((visc + prs) * g);
+       });
+  d.d_vel[i] = f4(a, 0);
+}
+__global__ void k_ss_integrate(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  float4 v = d.vel[i], a = d.d_vel[i], p = d.pos[i];
+  v = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);
+  d.vel[i] = v;
+  d.pos[i] = make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w);
+}

@@ -1,0 +1,319 @@
+// grid.h -- HashGrid replacement: dense z-fastest cell table, counting sort of the particles,
+// and (faithful mode) the reference hash table's aliasing reproduced as static per-cell
+// multiplicity tables + a box-filtered bucket-count field for the raw list length.
+// ref: HashGrid.py:44-124.
+#pragma once
+#include "device.h"
+
+// ref: HashGrid.py:108-114 -- int32 wrap-around products, xor, modulo normalised to [0, T)
+__device__ __forceinline__ int ref_hash(int x, int y, int z, int T) {
+  int p = (int)(73856093u * (unsigned)x) ^ (int)(19349663u * (unsigned)y) ^ (int)(83492791u * (unsigned)z);
+  return ((p % T) + T) % T;
+}
+
+// ref: HashGrid.py:68 -- ti.cast((pos - min) * invGridR, i32): f32 sub, f32 mul (no fma), trunc to zero
+__device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin) {
+  float fx = __fmul_rn(__fsub_rn(p.x, d.minx), d.inv_grid);
+  float fy = __fmul_rn(__fsub_rn(p.y, d.miny), d.inv_grid);
+  float fz = __fmul_rn(__fsub_rn(p.z, d.minz), d.inv_grid);
+  bool fin = (fabsf(fx) < 1e9f) && (fabsf(fy) < 1e9f) && (fabsf(fz) < 1e9f);  // NaN/inf => outside
+  int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+  bool in = fin && (unsigned)cx < (unsigned)d.nx && (unsigned)cy < (unsigned)d.ny && (unsigned)cz < (unsigned)d.nz;
+  *lin = in ? (cx * d.ny + cy) * d.nz + cz : d.ncell;
+  return in ? (cx | (cy << 10) | (cz << 20)) : -1;
+}
+
+// phase 1 of the counting sort (ref: HashGrid.py:67-76 "insert pos"): cell of every particle, slot in cell
+__global__ void k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pos[i];
+  int lin;
+  int w = cell_packed(d, xyz(p), &lin);
+  pw[i] = w;
+  slot[i] = atomicAdd(&cnt[lin], 1);
+  if (bcount && w >= 0) atomicAdd(&bcount[ref_hash(w & 1023, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+}
+
+__device__ __forceinline__ int lin_of(const Dev &d, int w) {
+  return w < 0 ? d.ncell : ((w & 1023) * d.ny + ((w >> 10) & 1023)) * d.nz + (w >> 20);
+}
+
+// phase 3: move every persistent liquid field to its cell-sorted position
+struct SortBuffers {
+  const float4 *pos, *vel, *vel_guess, *omega;
+  const float *kappa, *kappa_v;
+  const int *oid;
+  float4 *pos_o, *vel_o, *vel_guess_o, *omega_o;
+  float *kappa_o, *kappa_v_o;
+  int *oid_o, *where;
+};
+__global__ void k_scatter_liquid(Dev d, SortBuffers b, const int *cs, const int *pw, const int *slot) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  int w = pw[i];
+  int dst = cs[lin_of(d, w)] + slot[i];
+  float4 p = b.pos[i];
+  p.w = __int_as_float(w);
+  b.pos_o[dst] = p;
+  b.vel_o[dst] = b.vel[i];
+  b.vel_guess_o[dst] = b.vel_guess[i];
+  b.omega_o[dst] = b.omega[i];
+  b.kappa_o[dst] = b.kappa[i];
+  b.kappa_v_o[dst] = b.kappa_v[i];
+  int o = b.oid[i];
+  b.oid_o[dst] = o;
+  b.where[o] = dst;
+}
+__global__ void k_scatter_solid(Dev d, const float4 *pos, float4 *spos, const int *cs, const int *pw, const int *slot) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.ns) return;
+  int dst = cs[lin_of(d, pw[i])] + slot[i];
+  float4 p = pos[i];
+  p.w = __int_as_float(i);
+  spos[dst] = p;
+}
+
+// ---- exclusive scan over the cell counters (3 launches, 2048 elements per block) ----------
+#define SCAN_PER_THREAD 8
+#define SCAN_TILE (BLOCK * SCAN_PER_THREAD)
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
+  __shared__ int wsum[BLOCK / WAVE];
+  int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    int t = __shfl_up(inc, o, WAVE);
+    if (lane >= o) inc += t;
+  }
+  if (lane == WAVE - 1) wsum[w] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < BLOCK / WAVE; k++) {
+    if (k < w) off += wsum[k];
+    tot += wsum[k];
+  }
+  __syncthreads();
+  *total = tot;
+  return off + inc - v;
+}
+__global__ void k_scan_reduce(const int *in, int n, int *bsum) {
+  int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) s += (base + k < n) ? in[base + k] : 0;
+  int tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ void k_scan_bsums(int *bsum, int nb) {  // one block
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += BLOCK) {
+    int idx = base + threadIdx.x;
+    int v = idx < nb ? bsum[idx] : 0;
+    int tot;
+    int ex = block_exclusive_scan(v, &tot);
+    int c = carry;
+    if (idx < nb) bsum[idx] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+}
+__global__ void k_scan_final(const int *in, int n, const int *bsum, int *out) {
+  int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  int v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  int tot;
+  int ex = block_exclusive_scan(s, &tot) + bsum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+}
+
+// ---- static per-cell info ---------------------------------------------------------------
+// bit0: any solid particle inside the 5x5x5 walk of this cell (lets bulk particles skip the solid walk)
+__global__ void k_cell_solid_near(Dev d, int *cell_info) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.ncell) return;
+  int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
+  int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
+  int any = 0;
+  for (int dx = -2; dx <= 2; dx++) {
+    int x = cx + dx;
+    if ((unsigned)x >= (unsigned)d.nx) continue;
+    for (int dy = -2; dy <= 2; dy++) {
+      int y = cy + dy;
+      if ((unsigned)y >= (unsigned)d.ny) continue;
+      int base = (x * d.ny + y) * d.nz;
+      any |= (d.cs_s[base + z1] > d.cs_s[base + z0]);
+    }
+  }
+  cell_info[c] = (cell_info[c] & ~1) | (any ? 1 : 0);
+}
+
+// Faithful mode (Q1): which cells have two walked cells in one bucket?  64 cells per block, the 125
+// bucket ids of each cell in LDS ([k][lane], conflict free), all-pairs compare.
+#define ALIAS_TB 64
+__device__ __forceinline__ void alias_hashes(const Dev &d, int c, int (*hs)[ALIAS_TB]) {
+  int t = threadIdx.x;
+  int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
+  for (int k = 0; k < 125; k++) {
+    int x = cx + k / 25 - 2, y = cy + (k / 5) % 5 - 2, z = cz + k % 5 - 2;
+    bool in = (unsigned)x < (unsigned)d.nx && (unsigned)y < (unsigned)d.ny && (unsigned)z < (unsigned)d.nz;
+    hs[k][t] = in ? ref_hash(x, y, z, d.table_size) : (-1 - k);
+  }
+}
+__global__ void __launch_bounds__(ALIAS_TB) k_alias_detect(Dev d, int *cell_info, int *n_alias) {
+  __shared__ int hs[125][ALIAS_TB];
+  int c = blockIdx.x * ALIAS_TB + threadIdx.x, t = threadIdx.x;
+  if (c >= d.ncell) return;
+  alias_hashes(d, c, hs);
+  int dup = 0;
+  for (int a = 1; a < 125; a++) {
+    int ha = hs[a][t];
+    for (int b = 0; b < a; b++) dup |= (hs[b][t] == ha);
+  }
+  if (dup) {
+    int slot = atomicAdd(n_alias, 1);
+    cell_info[c] = (cell_info[c] & 1) | ((slot + 1) << 1);
+  }
+}
+__global__ void __launch_bounds__(ALIAS_TB) k_alias_fill(Dev d, const int *cell_info, uint16_t *alias) {
+  __shared__ int hs[125][ALIAS_TB];
+  int c = blockIdx.x * ALIAS_TB + threadIdx.x, t = threadIdx.x;
+  if (c >= d.ncell) return;
+  int info = cell_info[c];
+  if (!(info >> 1)) return;
+  alias_hashes(d, c, hs);
+  uint16_t *e = alias + (size_t)((info >> 1) - 1) * ALIAS_STRIDE;
+  int n = 0;
+  for (int a = 0; a < 125; a++) {
+    int ha = hs[a][t], m = 0;
+    if (ha < 0) continue;
+    for (int b = 0; b < 125; b++) m += (hs[b][t] == ha);
+    if (a == 62) e[1] = (uint16_t)m;  // multiplicity of the particle's own cell
+    if (m > 1) e[2 + n++] = (uint16_t)(a | ((m - 1) << 8));
+  }
+  e[0] = (uint16_t)n;
+}
+
+// ---- raw list length (HashGrid.neighborCount) --------------------------------------------
+// faithful: count_i = sum over the in-box walked cells c of gridCount[hash(c)]  -  (visits of the own bucket)
+// (ref: HashGrid.py:79-106).  cellval[c] = gridCount[hash(c)], then a separable 5x5x5 box sum.
+__global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.ncell) return;
+  int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
+  int v = bcount[ref_hash(cx, cy, cz, d.table_size)];
+  if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);  // ref: HashGrid.py:72-74 cannot be reproduced
+  cellval[c] = v;
+}
+__global__ void k_boxsum(const int *in, int *out, int n, int len, int stride) {
+  // 5-tap sum along one axis; len = cells along the axis, stride = element stride of the axis
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  int a = (c / stride) % len;
+  int s = 0;
+#pragma unroll
+  for (int k = -2; k <= 2; k++) {
+    int q = a + k;
+    if (q >= 0 && q < len) s += in[c + k * stride];
+  }
+  out[c] = s;
+}
+__global__ void k_ncount_faithful(Dev d, const int *boxsum) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  int w = __float_as_int(d.pos[i].w);
+  int cnt = 0;
+  if (w >= 0) {
+    int c = lin_of(d, w);
+    int info = d.cell_info[c];
+    int self = (info >> 1) ? d.alias[(size_t)((info >> 1) - 1) * ALIAS_STRIDE + 1] : 1;
+    cnt = boxsum[c] - self;
+  }
+  if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
+  d.ncount[i] = cnt;
+}
+// clean: every particle of the in-box 5x5x5 cells once, minus the particle itself
+__global__ void k_ncount_clean(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  int w = __float_as_int(d.pos[i].w);
+  int cnt = 0;
+  if (w >= 0) {
+    int cx = w & 1023, cy = (w >> 10) & 1023, cz = w >> 20;
+    int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
+    for (int dx = -2; dx <= 2; dx++) {
+      int x = cx + dx;
+      if ((unsigned)x >= (unsigned)d.nx) continue;
+      for (int dy = -2; dy <= 2; dy++) {
+        int y = cy + dy;
+        if ((unsigned)y >= (unsigned)d.ny) continue;
+        int base = (x * d.ny + y) * d.nz;
+        cnt += d.cs_l[base + z1] - d.cs_l[base + z0] + d.cs_s[base + z1] - d.cs_s[base + z0];
+      }
+    }
+    cnt -= 1;
+    int c = (cx * d.ny + cy) * d.nz + cz;
+    if (d.cs_l[c + 1] - d.cs_l[c] + d.cs_s[c + 1] - d.cs_s[c] > d.max_in_grid) atomicOr(&d.flags[FLAG_ERR], ERRBIT_BUCKET);
+  }
+  if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);
+  d.ncount[i] = cnt;
+}
+
+// ---- original-order <-> sorted-order field transfer ---------------------------------------
+__global__ void k_unpermute3(const float4 *f, const int *oid, int n, float *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 v = f[i];
+  int o = oid[i];
+  out[o * 3 + 0] = v.x; out[o * 3 + 1] = v.y; out[o * 3 + 2] = v.z;
+}
+__global__ void k_unpermute1(const float *f, const int *oid, int n, float *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[oid[i]] = f[i];
+}
+__global__ void k_permute3(float4 *f, const int *where, int n, const float *in) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  int i = where[o];
+  float4 v = f[i];  // keep .w (packed cell of pos)
+  v.x = in[o * 3 + 0]; v.y = in[o * 3 + 1]; v.z = in[o * 3 + 2];
+  f[i] = v;
+}
+__global__ void k_permute1(float *f, const int *where, int n, const float *in) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  f[where[o]] = in[o];
+}
+// rows by explicit ORIGINAL index list (halo pack / unpack)
+__global__ void k_gather_rows3(const float4 *f, const int *where, const int *idx, int n, float *out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  float4 v = f[where[idx[k]]];
+  out[k * 3 + 0] = v.x; out[k * 3 + 1] = v.y; out[k * 3 + 2] = v.z;
+}
+__global__ void k_gather_rows1(const float *f, const int *where, const int *idx, int n, float *out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  out[k] = f[where[idx[k]]];
+}
+__global__ void k_scatter_rows3(float4 *f, const int *where, const int *idx, int n, const float *in) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int i = where[idx[k]];
+  float4 v = f[i];
+  v.x = in[k * 3 + 0]; v.y = in[k * 3 + 1]; v.z = in[k * 3 + 2];
+  f[i] = v;
+}
+__global__ void k_scatter_rows1(float *f, const int *where, const int *idx, int n, const float *in) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  f[where[idx[k]]] = in[k];
+}

@@ -1,0 +1,813 @@
+// wcsph_hip.hip -- C ABI (include/wcsph.h) over the gfx950 kernels in grid.h / dfsph_kernels.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
+#include "../../include/wcsph.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "device.h"
+#include "grid.h"
+#include "dfsph_kernels.h"
+
+struct wcsph_ctx {
+  wcsph_params p;
+  Dev d;          // DFSPH view (CubicKernel with h = HashGrid.searchR)
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  std::string err;
+  bool is_setup = false, grid_valid = false;
+  // double buffers of the persistent fields (the *_b set is the scatter target)
+  float4 *pos_b = nullptr, *vel_b = nullptr, *vel_guess_b = nullptr, *omega_b = nullptr;
+  float *kappa_b = nullptr, *kappa_v_b = nullptr;
+  int *oid_b = nullptr;
+  // grid scratch
+  int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
+  int *bcount = nullptr, *bcount_s = nullptr, *cellval = nullptr, *celltmp = nullptr;
+  int n_alias = 0, scan_blocks = 0;
+  // staging for original-order transfers
+  float *stage = nullptr;  // [max(count*3, nl*9)] floats
+  std::vector<float> solid_host;  // original-order solid positions
+  double *h_acc = nullptr;        // pinned [8]
+  int *h_flags = nullptr;         // pinned [4]
+  // host-side solver state (ref: dfsph.py:36-41 module globals)
+  float dt = 0.0f;
+  float avg_density_err = 0.0f, cg_delta = 0.0f, cg_delta_old = 0.0f, cg_delta_zero = 0.0f, vel_max0 = 0.0f;
+  int vs_iter = 0, dv_iter = 0, pr_iter = 0;
+  int bs[3] = {0, 0, 0};
+  double grid_r = 0.0;
+  std::vector<void *> allocs;
+
+  int fail(int code, const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    err = buf;
+    return code;
+  }
+};
+
+#define HIPCHK(x)                                                    \
+  do {                                                               \
+    hipError_t e_ = (x);                                             \
+    if (e_ != hipSuccess) return ctx->fail(WCSPH_EHIP, #x, e_);      \
+  } while (0)
+#define LAUNCHCHK()                                                  \
+  do {                                                               \
+    hipError_t e_ = hipGetLastError();                               \
+    if (e_ != hipSuccess) return ctx->fail(WCSPH_EHIP, "kernel launch", e_); \
+  } while (0)
+#define NEED_SETUP()                                                                  \
+  if (!ctx) return WCSPH_EARG;                                                        \
+  if (!ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_setup() has not been called")
+#define NEED_GRID()                                                                   \
+  NEED_SETUP();                                                                       \
+  if (!ctx->grid_valid) return ctx->fail(WCSPH_EARG, "wcsph_grid_update() has not been called since setup")
+
+static inline int nblk(int n) { return (n + BLOCK - 1) / BLOCK; }
+// grids of the neighbour passes are a multiple of 8 blocks (XCD remap in sorted_index())
+static inline int nblk8(int n) { int b = nblk(n); return ((b + 7) / 8) * 8; }
+
+template <class T>
+static int dalloc(wcsph_ctx *ctx, T **p, size_t n) {
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+  HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), ctx->stream));
+  ctx->allocs.push_back((void *)*p);
+  return 0;
+}
+#define DALLOC(ptr, n) do { int rc_ = dalloc(ctx, &(ptr), (size_t)(n)); if (rc_) return rc_; } while (0)
+
+static int check_flags(wcsph_ctx *ctx) {
+  int f = ctx->h_flags[FLAG_ERR];
+  if (f & ERRBIT_BUCKET) return ctx->fail(WCSPH_EBUCKET, "more than maxInGrid particles in one hash bucket (ref: HashGrid.py:72-74)");
+  if (f & ERRBIT_NEIGH) return ctx->fail(WCSPH_ENEIGH, "more than maxNeighbour neighbour-list entries (ref: HashGrid.py:100-103)");
+  return 0;
+}
+// copy reduction slots + flags to the host and wait
+static int pull_scalars(wcsph_ctx *ctx) {
+  HIPCHK(hipMemcpyAsync(ctx->h_acc, ctx->d.acc, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_flags, ctx->d.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return check_flags(ctx);
+}
+static int zero_acc(wcsph_ctx *ctx, int slot) {
+  HIPCHK(hipMemsetAsync(ctx->d.acc + slot, 0, sizeof(double), ctx->stream));
+  return 0;
+}
+
+extern "C" {
+
+int wcsph_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *wcsph_last_error(wcsph_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
+  if (!p || !out || p->n_liquid < 0 || p->n_solid < 0) return WCSPH_EARG;
+  wcsph_ctx *ctx = new wcsph_ctx();
+  *out = ctx;  // returned even on failure so that wcsph_last_error() works
+  ctx->p = *p;
+  if (p->tension_fixed != 1 && (p->tension_coff != 0.0f))
+    return ctx->fail(WCSPH_EARG, "tension_fixed=0 (literal Q8 normals) is order dependent in the reference and not implemented");
+  HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  ctx->stream = ctx->own_stream;
+  Dev &d = ctx->d;
+  memset(&d, 0, sizeof d);
+  d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
+  d.faithful = (p->neighbor_mode == WCSPH_MODE_FAITHFUL);
+  d.table_size = p->hash_table_size > 0 ? p->hash_table_size : (p->n_liquid + p->n_solid);
+  if (d.table_size < 1) d.table_size = 1;
+  d.max_in_grid = p->max_in_grid; d.max_neighbour = p->max_neighbour;
+  // ref: HashGrid.py:16-19 gridR = 2*particleR, searchR = 2*gridR ; kernels/CubicKernel.py:12-17
+  ctx->grid_r = p->particle_radius * 2.0;
+  double h = ctx->grid_r * 2.0;
+  d.inv_grid = (float)(1.0 / ctx->grid_r);
+  d.h = (float)h; d.h2 = d.h * d.h; d.inv_h = 1.0f / d.h;
+  d.ml_h3 = (float)(48.0 / M_PI) * (float)(1.0 / (h * h * h));
+  d.mk_h3 = (float)(8.0 / M_PI) * (float)(1.0 / (h * h * h));
+  d.adh_mk = (float)(0.007 / pow(h, 3.25));
+  d.VL0 = p->VL0; d.VS0 = p->VS0; d.rho_L0 = p->rho_L0; d.rho_S0 = p->rho_S0; d.mass = p->liqiudMass; d.eps = p->eps;
+  d.gx = p->gravity[0]; d.gy = p->gravity[1]; d.gz = p->gravity[2];
+  d.dim_coff = p->dim_coff; d.visc = p->viscosity; d.visc_b = p->viscosity_b;
+  d.tension = p->tension_coff; d.tension_b = p->tension_coff_b;
+  d.visc_omega = p->viscosity_omega; d.vort_coff = p->vorticity_coff; d.vort_init = p->vorticity_init;
+  d.ss_VL0 = p->ss_VL0; d.ss_VS0 = p->ss_VS0; d.ss_mass = p->ss_mass; d.ss_rho0 = p->ss_rho0; d.ss_stiff = p->ss_stiff;
+  d.ss_dim = p->ss_dim; d.ss_visc = p->ss_visc; d.ss_visc_b = p->ss_visc_b;
+  // Q5: the reference CFL tree covers original indices [0, 2^floor(log2(N-1))); clean mode takes the true max
+  d.cfl_prefix = d.nl;
+  if (d.faithful && d.nl > 1) { int s = 1; while (s * 2 < d.nl) s *= 2; d.cfl_prefix = s; }
+  const size_t nl = (size_t)d.nl;
+  DALLOC(d.pos, nl); DALLOC(d.vel, nl); DALLOC(d.vel_guess, nl); DALLOC(d.omega, nl);
+  DALLOC(ctx->pos_b, nl); DALLOC(ctx->vel_b, nl); DALLOC(ctx->vel_guess_b, nl); DALLOC(ctx->omega_b, nl);
+  DALLOC(d.kappa, nl); DALLOC(d.kappa_v, nl); DALLOC(ctx->kappa_b, nl); DALLOC(ctx->kappa_v_b, nl);
+  DALLOC(d.oid, nl); DALLOC(ctx->oid_b, nl); DALLOC(d.where, nl);
+  DALLOC(d.d_vel, nl); DALLOC(d.d_omega, nl); DALLOC(d.normal, nl);
+  DALLOC(d.cg_r, nl); DALLOC(d.cg_dir, nl); DALLOC(d.cg_Ad, nl); DALLOC(d.cg_s, nl);
+  DALLOC(d.minv0, nl); DALLOC(d.minv1, nl); DALLOC(d.minv2, nl);
+  DALLOC(d.rho, nl); DALLOC(d.adv_rho, nl); DALLOC(d.pressure, nl); DALLOC(d.vel_max, nl); DALLOC(d.alpha, nl); DALLOC(d.kbuf, nl);
+  DALLOC(d.ncount, nl);
+  DALLOC(d.spos, (size_t)d.ns);
+  DALLOC(d.acc, 8); DALLOC(d.flags, 4);
+  size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
+  DALLOC(ctx->pw, nmax); DALLOC(ctx->slot, nmax);
+  size_t stage_n = (nl + d.ns) * 3 > nl * 9 ? (nl + d.ns) * 3 : nl * 9;
+  DALLOC(ctx->stage, stage_n);
+  HIPCHK(hipHostMalloc((void **)&ctx->h_acc, 8 * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **)&ctx->h_flags, 4 * sizeof(int)));
+  memset(ctx->h_acc, 0, 8 * sizeof(double)); memset(ctx->h_flags, 0, 4 * sizeof(int));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return WCSPH_OK;
+}
+
+int wcsph_destroy(wcsph_ctx *ctx) {
+  if (!ctx) return WCSPH_EARG;
+  if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
+  for (void *p : ctx->allocs) hipFree(p);
+  if (ctx->h_acc) hipHostFree(ctx->h_acc);
+  if (ctx->h_flags) hipHostFree(ctx->h_flags);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return WCSPH_OK;
+}
+
+int wcsph_set_stream(wcsph_ctx *ctx, void *s) {
+  if (!ctx) return WCSPH_EARG;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  return WCSPH_OK;
+}
+
+int wcsph_sync(wcsph_ctx *ctx) {
+  if (!ctx) return WCSPH_EARG;
+  return pull_scalars(ctx);
+}
+
+static int run_scan(wcsph_ctx *ctx, const int *in, int n, int *out) {
+  int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum);
+  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->bsum, nb);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out);
+  LAUNCHCHK();
+  return 0;
+}
+
+int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const float *minb) {
+  if (!ctx || !pos_xyz || !maxb || !minb) return WCSPH_EARG;
+  Dev &d = ctx->d;
+  if (ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_setup() called twice");
+  // ref: HashGrid.py:46-48 blockSize = int((max - min) / gridR + 1): f32 difference, double division
+  long ncell = 1;
+  for (int a = 0; a < 3; a++) {
+    ctx->bs[a] = (int)((double)(float)(maxb[a] - minb[a]) / ctx->grid_r + 1.0);
+    if (ctx->bs[a] < 1 || ctx->bs[a] > 1024) return ctx->fail(WCSPH_EARG, "grid blockSize must be in [1,1024] per axis");
+    ncell *= ctx->bs[a];
+  }
+  if (ncell > 0x7fff0000L) return ctx->fail(WCSPH_EARG, "grid has too many cells");
+  d.nx = ctx->bs[0]; d.ny = ctx->bs[1]; d.nz = ctx->bs[2]; d.ncell = (int)ncell;
+  d.minx = minb[0]; d.miny = minb[1]; d.minz = minb[2];
+  const int nscan = d.ncell + 2;
+  ctx->scan_blocks = (nscan + SCAN_TILE - 1) / SCAN_TILE;
+  DALLOC(ctx->cnt, nscan); DALLOC(d.cs_l, nscan); DALLOC(d.cs_s, nscan); DALLOC(ctx->bsum, ctx->scan_blocks + 1);
+  DALLOC(d.cell_info, d.ncell);
+  if (d.faithful) {
+    DALLOC(ctx->bcount, d.table_size); DALLOC(ctx->bcount_s, d.table_size);
+    DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->celltmp, d.ncell);
+  }
+  // liquids: identity order until the first grid update
+  std::vector<float4> tmp((size_t)(d.nl > d.ns ? d.nl : d.ns));
+  std::vector<int> ident((size_t)d.nl);
+  for (int i = 0; i < d.nl; i++) {
+    tmp[i] = make_float4(pos_xyz[3 * i], pos_xyz[3 * i + 1], pos_xyz[3 * i + 2], __builtin_bit_cast(float, (int)-1));
+    ident[i] = i;
+  }
+  HIPCHK(hipMemcpyAsync(d.pos, tmp.data(), (size_t)d.nl * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d.oid, ident.data(), (size_t)d.nl * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d.where, ident.data(), (size_t)d.nl * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // solids: static, sorted once (ref: ParticleData.py:120-126; they never move: dfsph.py:577-580 is liquid only)
+  ctx->solid_host.assign(pos_xyz + 3 * (size_t)d.nl, pos_xyz + 3 * ((size_t)d.nl + d.ns));
+  if (d.ns > 0) {
+    float4 *spos_in = ctx->pos_b;  // scratch large enough only if ns <= nl; otherwise a temporary
+    float4 *tmpdev = nullptr;
+    if (d.ns > d.nl) { HIPCHK(hipMalloc((void **)&tmpdev, (size_t)d.ns * sizeof(float4))); spos_in = tmpdev; }
+    for (int i = 0; i < d.ns; i++) {
+      const float *q = pos_xyz + 3 * ((size_t)d.nl + i);
+      tmp[i] = make_float4(q[0], q[1], q[2], 0.f);
+    }
+    HIPCHK(hipMemcpyAsync(spos_in, tmp.data(), (size_t)d.ns * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->cnt, 0, (size_t)nscan * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.ns)), dim3(BLOCK), 0, ctx->stream, d, (const float4 *)spos_in, d.ns, ctx->cnt,
+                       ctx->pw, ctx->slot, d.faithful ? ctx->bcount_s : (int *)nullptr);
+    LAUNCHCHK();
+    int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_solid, dim3(nblk(d.ns)), dim3(BLOCK), 0, ctx->stream, d, (const float4 *)spos_in, d.spos, d.cs_s,
+                       ctx->pw, ctx->slot);
+    LAUNCHCHK();
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (tmpdev) hipFree(tmpdev);
+  }
+  hipLaunchKernelGGL(k_cell_solid_near, dim3(nblk(d.ncell)), dim3(BLOCK), 0, ctx->stream, d, d.cell_info);
+  LAUNCHCHK();
+  if (d.faithful) {
+    int *d_n = nullptr;
+    HIPCHK(hipMalloc((void **)&d_n, sizeof(int)));
+    HIPCHK(hipMemsetAsync(d_n, 0, sizeof(int), ctx->stream));
+    int nb = (d.ncell + ALIAS_TB - 1) / ALIAS_TB;
+    hipLaunchKernelGGL(k_alias_detect, dim3(nb), dim3(ALIAS_TB), 0, ctx->stream, d, d.cell_info, d_n);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(&ctx->n_alias, d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d_n);
+    DALLOC(d.alias, (size_t)ctx->n_alias * ALIAS_STRIDE);
+    if (ctx->n_alias > 0) {
+      hipLaunchKernelGGL(k_alias_fill, dim3(nb), dim3(ALIAS_TB), 0, ctx->stream, d, (const int *)d.cell_info, d.alias);
+      LAUNCHCHK();
+    }
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->is_setup = true;
+  ctx->grid_valid = false;
+  return WCSPH_OK;
+}
+
+int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]) {
+  NEED_SETUP();
+  bs[0] = ctx->bs[0]; bs[1] = ctx->bs[1]; bs[2] = ctx->bs[2];
+  return WCSPH_OK;
+}
+
+// ---- HashGrid.update_grid -------------------------------------------------------------------
+int wcsph_grid_update(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  Dev &d = ctx->d;
+  const int nscan = d.ncell + 2;
+  hipStream_t s = ctx->stream;
+  HIPCHK(hipMemsetAsync(ctx->cnt, 0, (size_t)nscan * sizeof(int), s));
+  if (d.faithful) HIPCHK(hipMemcpyAsync(ctx->bcount, ctx->bcount_s, (size_t)d.table_size * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (d.nl > 0)
+    hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
+                       d.faithful ? ctx->bcount : (int *)nullptr);
+  int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l);
+  if (rc) return rc;
+  if (d.nl > 0) {
+    SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.oid,
+                     ctx->pos_b, ctx->vel_b, ctx->vel_guess_b, ctx->omega_b, ctx->kappa_b, ctx->kappa_v_b, ctx->oid_b, d.where};
+    hipLaunchKernelGGL(k_scatter_liquid, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, b, (const int *)d.cs_l, (const int *)ctx->pw,
+                       (const int *)ctx->slot);
+    std::swap(d.pos, ctx->pos_b); std::swap(d.vel, ctx->vel_b); std::swap(d.vel_guess, ctx->vel_guess_b);
+    std::swap(d.omega, ctx->omega_b); std::swap(d.kappa, ctx->kappa_b); std::swap(d.kappa_v, ctx->kappa_v_b);
+    std::swap(d.oid, ctx->oid_b);
+  }
+  // raw neighbour-list length (HashGrid.neighborCount)
+  if (d.faithful) {
+    hipLaunchKernelGGL(k_cellval, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags);
+    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, (const int *)ctx->cellval, ctx->celltmp, d.ncell, d.nz, 1);
+    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, (const int *)ctx->celltmp, ctx->cellval, d.ncell, d.ny, d.nz);
+    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, (const int *)ctx->cellval, ctx->celltmp, d.ncell, d.nx, d.ny * d.nz);
+    if (d.nl > 0) hipLaunchKernelGGL(k_ncount_faithful, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp);
+  } else if (d.nl > 0) {
+    hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
+  }
+  LAUNCHCHK();
+  ctx->grid_valid = true;
+  return WCSPH_OK;
+}
+
+// ---- field transfer ---------------------------------------------------------------------------
+struct FieldDesc { int kind; /*3 vec, 1 scalar, 9 mat, -1 int*/ void *ptr; };
+static FieldDesc field_desc(wcsph_ctx *ctx, int f) {
+  Dev &d = ctx->d;
+  switch (f) {
+    case WCSPH_F_POS: return {3, d.pos};
+    case WCSPH_F_VEL: return {3, d.vel};
+    case WCSPH_F_VEL_GUESS: return {3, d.vel_guess};
+    case WCSPH_F_D_VEL: return {3, d.d_vel};
+    case WCSPH_F_OMEGA: return {3, d.omega};
+    case WCSPH_F_D_OMEGA: return {3, d.d_omega};
+    case WCSPH_F_NORMAL: return {3, d.normal};
+    case WCSPH_F_CG_R: return {3, d.cg_r};
+    case WCSPH_F_CG_DIR: return {3, d.cg_dir};
+    case WCSPH_F_CG_AD: return {3, d.cg_Ad};
+    case WCSPH_F_CG_S: return {3, d.cg_s};
+    case WCSPH_F_RHO: return {1, d.rho};
+    case WCSPH_F_ADV_RHO: return {1, d.adv_rho};
+    case WCSPH_F_PRESSURE: return {1, d.pressure};
+    case WCSPH_F_VEL_MAX: return {1, d.vel_max};
+    case WCSPH_F_ALPHA: return {1, d.alpha};
+    case WCSPH_F_KAPPA: return {1, d.kappa};
+    case WCSPH_F_KAPPA_V: return {1, d.kappa_v};
+    case WCSPH_F_CG_MINV: return {9, nullptr};
+    case WCSPH_F_NEIGHBOR_COUNT: return {-1, d.ncount};
+  }
+  return {0, nullptr};
+}
+
+int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
+  NEED_SETUP();
+  if (!dst) return WCSPH_EARG;
+  Dev &d = ctx->d;
+  FieldDesc fd = field_desc(ctx, field);
+  if (!fd.kind) return ctx->fail(WCSPH_EARG, "unknown field id");
+  hipStream_t s = ctx->stream;
+  const int nl = d.nl;
+  size_t rows = (field == WCSPH_F_POS) ? (size_t)nl + d.ns : (size_t)nl;
+  size_t per = fd.kind == 3 ? 3 : fd.kind == 9 ? 9 : 1;
+  if (bytes != rows * per * 4) return ctx->fail(WCSPH_EARG, "wcsph_field_to_host: wrong byte count");
+  if (nl > 0) {
+    if (fd.kind == 3) hipLaunchKernelGGL(k_unpermute3, dim3(nblk(nl)), dim3(BLOCK), 0, s, (const float4 *)fd.ptr, (const int *)d.oid, nl, ctx->stage);
+    else if (fd.kind == 1 || fd.kind == -1)
+      hipLaunchKernelGGL(k_unpermute1, dim3(nblk(nl)), dim3(BLOCK), 0, s, (const float *)fd.ptr, (const int *)d.oid, nl, ctx->stage);
+    else {  // cg_Minv rows -> [n][3][3]
+      std::vector<float4> r0(nl), r1(nl), r2(nl);
+      std::vector<int> oid(nl);
+      HIPCHK(hipMemcpyAsync(r0.data(), d.minv0, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(r1.data(), d.minv1, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(r2.data(), d.minv2, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(oid.data(), d.oid, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      float *o = (float *)dst;
+      for (int i = 0; i < nl; i++) {
+        float *m = o + (size_t)oid[i] * 9;
+        m[0] = r0[i].x; m[1] = r0[i].y; m[2] = r0[i].z; m[3] = r1[i].x; m[4] = r1[i].y; m[5] = r1[i].z;
+        m[6] = r2[i].x; m[7] = r2[i].y; m[8] = r2[i].z;
+      }
+      return WCSPH_OK;
+    }
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(dst, ctx->stage, (size_t)nl * per * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  if (field == WCSPH_F_POS && d.ns > 0) memcpy((float *)dst + (size_t)nl * 3, ctx->solid_host.data(), (size_t)d.ns * 12);
+  return WCSPH_OK;
+}
+
+int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes) {
+  NEED_SETUP();
+  if (!src) return WCSPH_EARG;
+  Dev &d = ctx->d;
+  FieldDesc fd = field_desc(ctx, field);
+  if (!fd.kind || fd.kind == 9 || fd.kind == -1) return ctx->fail(WCSPH_EARG, "field is not writable from the host");
+  hipStream_t s = ctx->stream;
+  const int nl = d.nl;
+  size_t per = fd.kind == 3 ? 3 : 1;
+  size_t rows_full = (field == WCSPH_F_POS) ? (size_t)nl + d.ns : (size_t)nl;
+  if (bytes != rows_full * per * 4 && bytes != (size_t)nl * per * 4) return ctx->fail(WCSPH_EARG, "wcsph_field_from_host: wrong byte count");
+  if (nl == 0) return WCSPH_OK;
+  HIPCHK(hipMemcpyAsync(ctx->stage, src, (size_t)nl * per * 4, hipMemcpyHostToDevice, s));
+  if (fd.kind == 3) hipLaunchKernelGGL(k_permute3, dim3(nblk(nl)), dim3(BLOCK), 0, s, (float4 *)fd.ptr, (const int *)d.where, nl, (const float *)ctx->stage);
+  else hipLaunchKernelGGL(k_permute1, dim3(nblk(nl)), dim3(BLOCK), 0, s, (float *)fd.ptr, (const int *)d.where, nl, (const float *)ctx->stage);
+  LAUNCHCHK();
+  HIPCHK(hipStreamSynchronize(s));
+  if (field == WCSPH_F_POS) ctx->grid_valid = false;  // cells are stale until the next grid update
+  return WCSPH_OK;
+}
+
+int wcsph_field_gather_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, void *d_dst) {
+  NEED_SETUP();
+  FieldDesc fd = field_desc(ctx, field);
+  if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "gather_rows: vec3 / scalar fields only");
+  if (n <= 0) return WCSPH_OK;
+  if (fd.kind == 3) hipLaunchKernelGGL(k_gather_rows3, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, (const float4 *)fd.ptr, (const int *)ctx->d.where, d_idx, n, (float *)d_dst);
+  else hipLaunchKernelGGL(k_gather_rows1, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, (const float *)fd.ptr, (const int *)ctx->d.where, d_idx, n, (float *)d_dst);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_field_scatter_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, const void *d_src) {
+  NEED_SETUP();
+  FieldDesc fd = field_desc(ctx, field);
+  if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "scatter_rows: vec3 / scalar fields only");
+  if (n <= 0) return WCSPH_OK;
+  if (fd.kind == 3) hipLaunchKernelGGL(k_scatter_rows3, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, (float4 *)fd.ptr, (const int *)ctx->d.where, d_idx, n, (const float *)d_src);
+  else hipLaunchKernelGGL(k_scatter_rows1, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, (float *)fd.ptr, (const int *)ctx->d.where, d_idx, n, (const float *)d_src);
+  LAUNCHCHK();
+  if (field == WCSPH_F_POS) ctx->grid_valid = false;
+  return WCSPH_OK;
+}
+int wcsph_set_owned(wcsph_ctx *ctx, int32_t n_owned) {
+  if (!ctx || n_owned < 0 || n_owned > ctx->d.nl) return WCSPH_EARG;
+  ctx->d.n_owned = n_owned;
+  return WCSPH_OK;
+}
+
+int wcsph_get_scalar(wcsph_ctx *ctx, int id, float *v) {
+  if (!ctx || !v) return WCSPH_EARG;
+  switch (id) {
+    case WCSPH_S_DELTA_T: *v = ctx->dt; break;
+    case WCSPH_S_AVG_DENSITY_ERR: *v = ctx->avg_density_err; break;
+    case WCSPH_S_CG_DELTA: *v = ctx->cg_delta; break;
+    case WCSPH_S_CG_DELTA_OLD: *v = ctx->cg_delta_old; break;
+    case WCSPH_S_CG_DELTA_ZERO: *v = ctx->cg_delta_zero; break;
+    case WCSPH_S_VISCOSITY: *v = ctx->d.visc; break;
+    case WCSPH_S_VISCOSITY_B: *v = ctx->d.visc_b; break;
+    case WCSPH_S_TENSION: *v = ctx->d.tension; break;
+    case WCSPH_S_TENSION_B: *v = ctx->d.tension_b; break;
+    case WCSPH_S_VEL_MAX0: *v = ctx->vel_max0; break;
+    default: return ctx->fail(WCSPH_EARG, "unknown scalar id");
+  }
+  return WCSPH_OK;
+}
+int wcsph_set_scalar(wcsph_ctx *ctx, int id, float v) {
+  if (!ctx) return WCSPH_EARG;
+  switch (id) {
+    case WCSPH_S_DELTA_T: ctx->dt = v; break;
+    case WCSPH_S_AVG_DENSITY_ERR: ctx->avg_density_err = v; break;
+    case WCSPH_S_CG_DELTA: ctx->cg_delta = v; break;
+    case WCSPH_S_CG_DELTA_OLD: ctx->cg_delta_old = v; break;
+    case WCSPH_S_CG_DELTA_ZERO: ctx->cg_delta_zero = v; break;
+    case WCSPH_S_VISCOSITY: ctx->d.visc = v; break;
+    case WCSPH_S_VISCOSITY_B: ctx->d.visc_b = v; break;
+    case WCSPH_S_TENSION: ctx->d.tension = v; break;
+    case WCSPH_S_TENSION_B: ctx->d.tension_b = v; break;
+    default: return ctx->fail(WCSPH_EARG, "scalar is read-only or unknown");
+  }
+  return WCSPH_OK;
+}
+int wcsph_get_iters(wcsph_ctx *ctx, int32_t *vs, int32_t *dv, int32_t *pr) {
+  if (!ctx) return WCSPH_EARG;
+  if (vs) *vs = ctx->vs_iter;
+  if (dv) *dv = ctx->dv_iter;
+  if (pr) *pr = ctx->pr_iter;
+  return WCSPH_OK;
+}
+int wcsph_set_iters(wcsph_ctx *ctx, int32_t vs, int32_t dv, int32_t pr) {
+  if (!ctx) return WCSPH_EARG;
+  ctx->vs_iter = vs; ctx->dv_iter = dv; ctx->pr_iter = pr;
+  return WCSPH_OK;
+}
+
+// ---- dfsph.py kernels -------------------------------------------------------------------------
+#define PASS(kern, ...)                                                                           \
+  do {                                                                                            \
+    if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk8(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
+    LAUNCHCHK();                                                                                  \
+  } while (0)
+#define ELEM(kern, ...)                                                                           \
+  do {                                                                                            \
+    if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
+    LAUNCHCHK();                                                                                  \
+  } while (0)
+
+int wcsph_dfsph_reset_param(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  ELEM(k_reset);
+  ctx->dt = 0.001f;  // ref: dfsph.py:178
+  return WCSPH_OK;
+}
+int wcsph_dfsph_compute_density(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_density); return WCSPH_OK; }
+int wcsph_dfsph_compute_coff(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_coff); return WCSPH_OK; }
+
+int wcsph_dfsph_warmstart_divergence(wcsph_ctx *ctx) {
+  NEED_GRID();
+  PASS(k_drho_div<DRHO_WARM>, ctx->dt);
+  PASS(k_vel_from_k<1>, (const float *)ctx->d.kappa_v, ctx->dt);
+  return WCSPH_OK;
+}
+int wcsph_dfsph_begin_divergence(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_drho_div<DRHO_BEGIN>, ctx->dt); return WCSPH_OK; }
+
+// launches one iteration; the error sum lands in h_acc[ACC_ERR] after pull_scalars()
+static int divergence_iter_async(wcsph_ctx *ctx) {
+  ELEM(k_make_k, ctx->d.kappa_v, 0.0f);
+  PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, ctx->dt);
+  int rc = zero_acc(ctx, ACC_ERR);
+  if (rc) return rc;
+  PASS(k_drho_div<DRHO_ITER>, ctx->dt);
+  return 0;
+}
+static int pressure_iter_async(wcsph_ctx *ctx) {
+  ELEM(k_make_k, ctx->d.kappa, 1.0f);
+  PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, ctx->dt);
+  int rc = zero_acc(ctx, ACC_ERR);
+  if (rc) return rc;
+  PASS(k_drho_press<DRHO_ITER>, ctx->dt);
+  return 0;
+}
+int wcsph_dfsph_divergence_iter(wcsph_ctx *ctx) {
+  NEED_GRID();
+  int rc = divergence_iter_async(ctx);
+  if (rc) return rc;
+  rc = pull_scalars(ctx);
+  if (rc) return rc;
+  ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+  return WCSPH_OK;
+}
+int wcsph_dfsph_end_divergence(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_end_div, ctx->dt); return WCSPH_OK; }
+
+int wcsph_dfsph_warmstart_pressure(wcsph_ctx *ctx) {
+  NEED_GRID();
+  ELEM(k_warm_press_scale, ctx->dt);
+  PASS(k_warm_press_vel, ctx->dt);
+  return WCSPH_OK;
+}
+int wcsph_dfsph_begin_pressure(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_drho_press<DRHO_BEGIN>, ctx->dt); return WCSPH_OK; }
+int wcsph_dfsph_pressure_iter(wcsph_ctx *ctx) {
+  NEED_GRID();
+  int rc = pressure_iter_async(ctx);
+  if (rc) return rc;
+  rc = pull_scalars(ctx);
+  if (rc) return rc;
+  ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+  return WCSPH_OK;
+}
+int wcsph_dfsph_end_pressure(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_end_press, ctx->dt); return WCSPH_OK; }
+int wcsph_dfsph_clear_nonpressure(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_clear_nonpressure); return WCSPH_OK; }
+
+int wcsph_dfsph_tension(wcsph_ctx *ctx) {
+  NEED_GRID();
+  PASS(k_tension_normal);
+  PASS(k_tension_accel);
+  return WCSPH_OK;
+}
+
+int wcsph_dfsph_visc_init(wcsph_ctx *ctx) {
+  NEED_GRID();
+  ELEM(k_visc_guess);
+  PASS(k_visc_minv, ctx->dt);
+  int rc = zero_acc(ctx, ACC_DZERO);
+  if (rc) return rc;
+  PASS(k_visc_residual, ctx->dt);
+  rc = pull_scalars(ctx);
+  if (rc) return rc;
+  ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
+  ctx->cg_delta = ctx->cg_delta_zero;
+  return WCSPH_OK;
+}
+int wcsph_dfsph_visc_iter(wcsph_ctx *ctx) {
+  NEED_GRID();
+  int rc = zero_acc(ctx, ACC_DAD);
+  if (rc) return rc;
+  PASS(k_visc_Ad, ctx->dt);
+  rc = zero_acc(ctx, ACC_DNEW);
+  if (rc) return rc;
+  ELEM(k_visc_update, ctx->cg_delta);
+  ELEM(k_visc_dir, ctx->cg_delta);  // delta_old == the delta this iteration started with (dfsph.py:234)
+  rc = pull_scalars(ctx);
+  if (rc) return rc;
+  ctx->cg_delta_old = ctx->cg_delta;
+  ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+  return WCSPH_OK;
+}
+int wcsph_dfsph_visc_end(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_visc_end, ctx->dt); return WCSPH_OK; }
+
+int wcsph_dfsph_vorticity(wcsph_ctx *ctx) {
+  NEED_GRID();
+  PASS(k_vorticity, ctx->dt);
+  ELEM(k_vorticity_integrate, ctx->dt);
+  return WCSPH_OK;
+}
+
+int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  HIPCHK(hipMemsetAsync(ctx->d.flags + FLAG_VMAX, 0, sizeof(int), ctx->stream));
+  ELEM(k_cfl, ctx->dt);
+  hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(1), 0, ctx->stream, ctx->d);
+  LAUNCHCHK();
+  int rc = pull_scalars(ctx);
+  if (rc) return rc;
+  int bits = ctx->h_flags[FLAG_VMAX];
+  memcpy(&ctx->vel_max0, &bits, 4);
+  return WCSPH_OK;
+}
+int wcsph_dfsph_update_vel(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_update_vel, ctx->dt); return WCSPH_OK; }
+int wcsph_dfsph_update_pos(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  ELEM(k_update_pos, ctx->dt);
+  ctx->grid_valid = ctx->grid_valid;  // cells go stale, but the reference also keeps using the step's lists
+  return WCSPH_OK;
+}
+
+// ---- host-side control ------------------------------------------------------------------------
+int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84-103
+  NEED_GRID();
+  int rc;
+  if ((rc = wcsph_dfsph_clear_nonpressure(ctx))) return rc;
+  if ((rc = wcsph_dfsph_tension(ctx))) return rc;
+  if ((rc = wcsph_dfsph_visc_init(ctx))) return rc;
+  ctx->vs_iter = 0;
+  while (ctx->vs_iter < 100) {
+    if ((rc = wcsph_dfsph_visc_iter(ctx))) return rc;
+    ctx->vs_iter++;
+    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero ||
+        (double)ctx->cg_delta_zero < (double)ctx->p.eps)
+      break;
+  }
+  if ((rc = wcsph_dfsph_visc_end(ctx))) return rc;
+  return wcsph_dfsph_vorticity(ctx);
+}
+
+int wcsph_dfsph_optimize_time_step(wcsph_ctx *ctx) {  // ref: dfsph.py:107-129
+  NEED_SETUP();
+  int rc = wcsph_dfsph_cfl_reduce(ctx);
+  if (rc) return rc;
+  float vmax0 = ctx->vel_max0;
+  if ((double)vmax0 > (double)ctx->p.eps) {
+    double time_step = 0.5 * 0.4 * ctx->p.cfl_radius * 2.0 / sqrt((double)vmax0);
+    if (time_step > ctx->p.user_max_t) time_step = ctx->p.user_max_t;
+    if (time_step < ctx->p.user_min_t) time_step = ctx->p.user_min_t;
+    int it = ctx->vs_iter > ctx->pr_iter ? ctx->vs_iter : ctx->pr_iter;  // max(vs, max(pr, vs)), Q6
+    float dt = ctx->dt;
+    if (it > 10) dt = (float)((double)dt * 0.9);
+    else if (it < 5) dt = (float)((double)dt * 1.1);
+    if ((double)dt > time_step) dt = (float)time_step;
+    ctx->dt = dt;
+  }
+  return WCSPH_OK;
+}
+
+int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
+  NEED_GRID();
+  int rc;
+  ctx->dv_iter = 0;
+  if ((rc = wcsph_dfsph_warmstart_divergence(ctx))) return rc;
+  double err = -0.1;
+  if ((rc = wcsph_dfsph_begin_divergence(ctx))) return rc;
+  const float dt = ctx->dt;
+  while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
+    if ((rc = wcsph_dfsph_divergence_iter(ctx))) return rc;
+    err = 0.001 * (double)ctx->d.n_owned / (double)dt;
+    ctx->dv_iter++;
+  }
+  return wcsph_dfsph_end_divergence(ctx);
+}
+
+int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
+  NEED_GRID();
+  int rc;
+  if ((rc = wcsph_dfsph_warmstart_pressure(ctx))) return rc;
+  ctx->pr_iter = 0;
+  double err = 0.0;
+  if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
+  while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
+    if ((rc = wcsph_dfsph_pressure_iter(ctx))) return rc;
+    err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
+    ctx->pr_iter++;
+  }
+  return wcsph_dfsph_end_pressure(ctx);
+}
+
+int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
+  NEED_SETUP();
+  int rc;
+  if ((rc = wcsph_grid_update(ctx))) return rc;
+  PASS(k_density_coff);  // compute_density + compute_dfsph_coff in one walk
+  if ((rc = wcsph_dfsph_solve_divergence(ctx))) return rc;
+  if ((rc = wcsph_dfsph_compute_nonpressure_force(ctx))) return rc;
+  if ((rc = wcsph_dfsph_optimize_time_step(ctx))) return rc;
+  if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
+  if ((rc = wcsph_dfsph_solve_pressure(ctx))) return rc;
+  return wcsph_dfsph_update_pos(ctx);
+}
+
+// ---- sesph.py ---------------------------------------------------------------------------------
+static Dev sesph_view(const wcsph_ctx *ctx) {
+  Dev s = ctx->d;  // same arrays, the script's private kernel constants (sesph.py:40-45, pi = 3.1415926)
+  s.h = ctx->p.ss_searchR; s.h2 = s.h * s.h; s.inv_h = 1.0f / s.h;
+  s.mk_h3 = ctx->p.ss_mk; s.ml_h3 = ctx->p.ss_ml;
+  return s;
+}
+#define SPASS(kern, ...)                                                                          \
+  do {                                                                                            \
+    Dev sv_ = sesph_view(ctx);                                                                    \
+    if (sv_.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk8(sv_.nl)), dim3(BLOCK), 0, ctx->stream, sv_, ##__VA_ARGS__); \
+    LAUNCHCHK();                                                                                  \
+  } while (0)
+int wcsph_sesph_reset_param(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_reset); ctx->dt = 0.001f; return WCSPH_OK; }
+int wcsph_sesph_density(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_density); return WCSPH_OK; }
+int wcsph_sesph_pressure(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_pressure); return WCSPH_OK; }
+int wcsph_sesph_force(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_force); return WCSPH_OK; }
+int wcsph_sesph_integrate(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_integrate, ctx->dt); return WCSPH_OK; }
+int wcsph_sesph_step(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  int rc;
+  if ((rc = wcsph_grid_update(ctx))) return rc;
+  if ((rc = wcsph_sesph_density(ctx))) return rc;
+  if ((rc = wcsph_sesph_pressure(ctx))) return rc;
+  if ((rc = wcsph_sesph_force(ctx))) return rc;
+  return wcsph_sesph_integrate(ctx);
+}
+
+// ---- explicit neighbour list (debug / API parity) ----------------------------------------------
+__global__ void k_neighbor_lists(Dev d, int i0, int n, int cap, int *counts, int *lists) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  int o = i0 + t;
+  int i = d.where[o];
+  int *row = lists + (size_t)t * cap;
+  for (int k = 0; k < cap; k++) row[k] = -1;
+  counts[t] = d.ncount[i];
+  float4 pi = d.pos[i];
+  const int cw = __float_as_int(pi.w);
+  if (cw < 0) return;
+  const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
+  const int info = d.cell_info[(cx * d.ny + cy) * d.nz + cz];
+  const uint16_t *e = (info >> 1) ? d.alias + (size_t)((info >> 1) - 1) * ALIAS_STRIDE : nullptr;
+  int w = 0;
+  for (int k = 0; k < 125; k++) {
+    int x = cx + k / 25 - 2, y = cy + (k / 5) % 5 - 2, z = cz + k % 5 - 2;
+    if ((unsigned)x >= (unsigned)d.nx || (unsigned)y >= (unsigned)d.ny || (unsigned)z >= (unsigned)d.nz) continue;
+    int mult = 1;
+    if (e) for (int q = 0; q < e[0]; q++) if ((e[2 + q] & 0xff) == k) mult += e[2 + q] >> 8;
+    int c = (x * d.ny + y) * d.nz + z;
+    for (int rep = 0; rep < mult; rep++) {
+      for (int j = d.cs_l[c]; j < d.cs_l[c + 1]; j++) if (j != i) { if (w < cap) row[w] = d.oid[j]; w++; }
+      for (int j = d.cs_s[c]; j < d.cs_s[c + 1]; j++) { if (w < cap) row[w] = d.nl + __float_as_int(d.spos[j].w); w++; }
+    }
+  }
+}
+int wcsph_neighbors_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, int32_t *counts, int32_t *lists) {
+  NEED_GRID();
+  if (i0 < 0 || n < 0 || i0 + n > ctx->d.nl || cap < 1 || !counts || !lists) return WCSPH_EARG;
+  if (n == 0) return WCSPH_OK;
+  int *dc = nullptr, *dl = nullptr;
+  HIPCHK(hipMalloc((void **)&dc, (size_t)n * 4));
+  HIPCHK(hipMalloc((void **)&dl, (size_t)n * cap * 4));
+  hipLaunchKernelGGL(k_neighbor_lists, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, i0, n, cap, dc, dl);
+  hipError_t e1 = hipMemcpyAsync(counts, dc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipMemcpyAsync(lists, dl, (size_t)n * cap * 4, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e3 = hipStreamSynchronize(ctx->stream);
+  hipFree(dc); hipFree(dl);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ctx->fail(WCSPH_EHIP, "neighbors_to_host copy");
+  return WCSPH_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------
+int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
+  NEED_GRID();
+  if (!name || reps < 1 || !ms) return WCSPH_EARG;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  std::string nm(name);
+  int rc = 0;
+  auto one = [&]() -> int {
+    if (nm == "pressure_iter") return pressure_iter_async(ctx);
+    if (nm == "divergence_iter") return divergence_iter_async(ctx);
+    if (nm == "pressure_vel_loop") { PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, ctx->dt); return 0; }
+    if (nm == "pressure_drho_loop") { PASS(k_drho_press<DRHO_ITER>, ctx->dt); return 0; }
+    if (nm == "density") { PASS(k_density); return 0; }
+    if (nm == "density_coff") { PASS(k_density_coff); return 0; }
+    if (nm == "grid_update") return wcsph_grid_update(ctx);
+    if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
+    return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");
+  };
+  if ((rc = one())) return rc;  // warm-up
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < reps && !rc; r++) rc = one();
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float t = 0.f;
+  HIPCHK(hipEventElapsedTime(&t, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc) return rc;
+  *ms = t / (float)reps;
+  return WCSPH_OK;
+}
+
+}  // extern "C"
