@@ -64,7 +64,7 @@ typedef struct wcsph_params {
   float eps;
   /* sesph.py private constants (sesph.py:23-62) */
   float ss_searchR, ss_mk, ss_ml, ss_VL0, ss_VS0, ss_mass, ss_rho0, ss_stiff, ss_dim, ss_visc, ss_visc_b;
-  float reserved1;
+  float list_radius;         /* support radius of the compact per-step neighbour lists; 0 => HashGrid.searchR */
 } wcsph_params;
 
 /* field ids for wcsph_field_to_host / wcsph_field_from_host (ref: ParticleData.py:33-76, dfsph.py:46-48) */

@@ -262,7 +262,8 @@ static inline float Coh_W_norm(const orc_ctx *c, float r) {
 static inline float Adh_W_norm(const orc_ctx *c, float r) {
   float res = 0.0f, h = c->ck_h, radius2 = h * h, r2 = r * r;
   if (r2 <= radius2)
-    if (r > 0.5f * h) res = c->adh_mk * powf(-4.0f * r2 / h + 6.0f * r - 2.0f * h, 0.25f);
+    if (r > 0.5f * h) /* fmaxf: the polynomial cancels to -1e-9 at r == h in f32 and pow() would give NaN */
+      res = c->adh_mk * powf(fmaxf(-4.0f * r2 / h + 6.0f * r - 2.0f * h, 0.0f), 0.25f);
   return res;
 }
 /* exported scalar probes for the known-answer tests */

@@ -21,11 +21,14 @@ def test_sesph_steps(mode):
         if s == 0:
             np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)
         sesph.update_advection_density(); o.sesph_update_advection_density()
-        assert np.abs(sesph.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-5
+        drho = np.abs(sesph.rho.to_numpy() - o.rho).max()
+        assert drho / o.rho.max() < 1e-5
         sesph.update_pressure(); o.sesph_update_pressure()
-        # p = 50000 ((rho/rho0)^7 - 1): an fp32 density difference of 1 ulp-ish (1e-7 rho0) is 0.035 in p
+        # p = 50000 ((rho/rho0)^7 - 1) amplifies the (tolerated) fp32 density difference by 7 * 50000 * q^6 / rho0:
+        # the pressure difference must be explained by the density difference, plus fp32 rounding of q^7 itself
         dp = np.abs(sesph.pressure.to_numpy() - o.pressure).max()
-        assert dp < 0.2 + 2e-4 * np.abs(o.pressure).max()
+        q = float(o.rho.max()) / 1000.0
+        assert dp <= 7 * 50000 * q ** 6 * (1.5 * drho / 1000.0 + 4e-7)
         sesph.compute_force(); o.sesph_compute_force()
         assert rel_err(sesph.d_vel.to_numpy(), o.d_vel) < 1e-3
         sesph.integrator_sesph(); o.sesph_integrate()

@@ -1,0 +1,80 @@
+"""Host-side pieces that need no GPU: reference-named constants, point accumulation / bbox, the OBJ
+point-cloud loader, scene recipes, host kernel classes vs the oracle's kernels."""
+import numpy as np
+import pytest
+
+from oracle import Oracle
+from wcsph_amd import ParticleData, scene
+from wcsph_amd.kernels import AdhesionKernel, CohesionKernel, CubicKernel
+
+
+def test_particle_data_constants_match_reference():
+    pd = ParticleData(0.025)   # ref: ParticleData.py:12-31,61-87
+    assert pd.rho_L0 == 1000.0 and pd.rho_S0 == 1000.0
+    assert pd.VL0 == pytest.approx(0.025 ** 3 * 0.8 * 8.0) and pd.VS0 == pd.VL0
+    assert pd.liqiudMass == pytest.approx(pd.VL0 * 1000.0)
+    assert (pd.dim_coff, pd.viscosity, pd.viscosity_b, pd.viscosity_err) == (10.0, 10.0, 10.0, 0.05)
+    assert (pd.tension_coff, pd.tension_coff_b) == (0.0, 0.0)
+    assert (pd.viscosity_omega, pd.vorticity_coff, pd.vorticity_init) == (0.1, 0.01, 0.5)
+    hg = pd.hash_grid
+    assert (hg.gridR, hg.searchR, hg.invGridR) == (0.05, 0.1, 1.0 / 0.05)
+    assert (hg.maxInGrid, hg.maxNeighbour) == (64, 2048)
+    assert pd.kernel_c.searchR == hg.searchR
+    for name in ("pos vel vel_guess d_vel omega d_omega normal rho adv_rho pressure vel_max cg_Minv cg_r cg_dir "
+                 "cg_Ad cg_s avg_density_err cg_delta cg_delta_old cg_delta_zero").split():
+        assert hasattr(pd, name), name
+
+
+def test_point_accumulation_and_bbox(tmp_path):
+    pd = ParticleData(0.025)
+    pd.add_liquid_point([0.1, 0.2, 0.3])
+    pd.add_liquid_points(np.array([[0.5, -0.2, 0.0], [0.0, 0.9, -0.7]]))
+    obj = tmp_path / "b.obj"
+    obj.write_text("# comment\nv 1.0 2.0 3.0\n\nvn 0 0 1\nv -1.5 0 0 1.0\nf 1 2 3\n")
+    pd.add_obj(str(obj))       # ref: ParticleData.py:130-138: only `v` lines, first three numbers
+    assert (pd.count, pd.liquid_count, pd.solid_count) == (5, 3, 2)
+    np.testing.assert_allclose(pd.maxboundarynp, [[1.0, 2.0, 3.0]])
+    np.testing.assert_allclose(pd.minboundarynp, [[-1.5, -0.2, -0.7]])
+    assert pd.maxboundarynp.dtype == np.float32 and pd.maxboundarynp.shape == (1, 3)
+    p = pd._initial_positions()
+    assert p.dtype == np.float32 and p.shape == (5, 3)
+    np.testing.assert_allclose(p[3], [1, 2, 3])
+
+
+def test_scene_recipes():
+    l, s = scene.dam_break_dfsph(6)
+    L = 6 * 0.05
+    assert l.shape == (216, 3)
+    assert s[:, 0].min() == -L and s[:, 0].max() == L and s[:, 1].min() == 0.0 and s[:, 1].max() == 2 * L
+    assert len(np.unique(np.round(s, 9), axis=0)) == len(s)          # no duplicated edge points
+    on_face = (np.abs(np.abs(s[:, 0]) - L) < 1e-12) | (np.abs(np.abs(s[:, 2]) - L) < 1e-12) | \
+              (np.abs(s[:, 1]) < 1e-12) | (np.abs(s[:, 1] - 2 * L) < 1e-12)
+    assert on_face.all()
+    assert np.all(np.abs(l[:, 0]) < L) and np.all(l[:, 1] > 0)
+    assert scene.CONFIGS["C3"] ** 3 == 2000376 and scene.CONFIGS["C2"] ** 3 == 97336
+
+
+def test_host_kernel_classes_agree_with_the_oracle():
+    o = Oracle(np.zeros((8, 3), np.float32) + np.arange(8)[:, None] * 0.01, 4, 0.025, maxNeighbour=8)
+    k, coh, adh = CubicKernel(0.1), CohesionKernel(0.1), AdhesionKernel(0.1)
+    for r in np.linspace(0.0, 0.12, 25):
+        assert float(k.Cubic_W_norm(r)) == pytest.approx(o.W_norm(r), rel=2e-6, abs=1e-3)
+        assert float(coh.Cubic_W_norm(r)) == pytest.approx(o.coh_W(r), rel=1e-4, abs=1e-3)
+        assert float(adh.Cubic_W_norm(r)) == pytest.approx(o.adh_W(r), rel=1e-4, abs=1e-6)
+    rng = np.random.default_rng(0)
+    for v in rng.uniform(-0.08, 0.08, (30, 3)):
+        np.testing.assert_allclose(k.CubicGradW(v), o.gradW(v), rtol=5e-6, atol=5e-3)
+    assert k.m_k == pytest.approx(8 / np.pi) and k.m_l == pytest.approx(48 / np.pi) and k.h3 == pytest.approx(1000.0)
+
+
+def test_hashgrid_host_hash_matches_oracle():
+    from wcsph_amd import HashGrid
+    liquid, solid = scene.dam_break_dfsph(5)
+    pd = ParticleData(0.025)
+    pd.add_liquid_points(liquid); pd.add_solid_points(solid)
+    o = Oracle(np.concatenate([liquid, solid]), len(liquid), 0.025)
+    cells = np.random.default_rng(2).integers(0, 500, (100, 3))
+    got = pd.hash_grid.get_cell_hash(cells)
+    for c, h in zip(cells, got):
+        assert o.cell_hash(*c) == int(h)
+    assert isinstance(pd.hash_grid, HashGrid)

@@ -92,6 +92,7 @@ class ParticleData:
         self.eps = 1e-5
         self.sesph_particle_radius = 0.025
         self.hash_table_size = 0  # 0 => count (HashGrid.py:114)
+        self.list_radius = 0.0    # 0 => HashGrid.searchR; sesph.py sets its own (smaller) kernel support
         self._ctx = None
 
     # ---- point accumulation (ref: ParticleData.py:100-138) -------------------------------------
@@ -177,6 +178,7 @@ class ParticleData:
         p.ss_searchR, p.ss_mk, p.ss_ml = sr, 8.0 / (pi * h3), 48.0 / (pi * h3)
         p.ss_VL0, p.ss_VS0, p.ss_mass, p.ss_rho0 = VL0, VL0 * 2.0, VL0 * 1000.0, 1000.0
         p.ss_stiff, p.ss_dim, p.ss_visc, p.ss_visc_b = 50000.0, 10.0, 0.1, 0.0
+        p.list_radius = float(self.list_radius)
         return p
 
     def setup_data_gpu(self):

@@ -28,7 +28,7 @@ class Params(C.Structure):
         ("eps", C.c_float),
         ("ss_searchR", C.c_float), ("ss_mk", C.c_float), ("ss_ml", C.c_float), ("ss_VL0", C.c_float),
         ("ss_VS0", C.c_float), ("ss_mass", C.c_float), ("ss_rho0", C.c_float), ("ss_stiff", C.c_float),
-        ("ss_dim", C.c_float), ("ss_visc", C.c_float), ("ss_visc_b", C.c_float), ("reserved1", C.c_float),
+        ("ss_dim", C.c_float), ("ss_visc", C.c_float), ("ss_visc_b", C.c_float), ("list_radius", C.c_float),
     ]
 
 

@@ -43,6 +43,11 @@ struct Dev {
   float4 *minv0, *minv1, *minv2;          // rows of cg_Minv
   float *rho, *adv_rho, *pressure, *vel_max, *alpha, *kbuf;
   int *ncount;                            // HashGrid.neighborCount (raw list length)
+  // compact per-step neighbour lists (k-major: entry k of particle i at [k * nbr_stride + i])
+  int *nbr_l, *nbr_s;                     // sorted liquid index / sorted solid index
+  int *ncl, *ncs;                         // entries per particle
+  int nbr_stride, nbr_cap;
+  float list_r2;                          // squared support radius the lists are built with
   // solids, cell-sorted once
   float4 *spos;
   // cell tables
@@ -57,7 +62,7 @@ struct Dev {
 
 enum { ACC_ERR = 0, ACC_DAD = 1, ACC_DNEW = 2, ACC_DZERO = 3 };
 enum { FLAG_ERR = 0, FLAG_VMAX = 1 };
-enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2 };
+enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2, ERRBIT_LISTCAP = 4 };
 
 __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
 __device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -118,13 +123,13 @@ __device__ __forceinline__ void block_accumulate(double *dst, float v) {
   }
 }
 
-// The neighbour walk.  fl(j, r, r2, m) is called for every liquid list entry j != i inside the
-// support (r = x_i - x_j, m = multiplicity of the entry in the reference's bucket multiset),
+// The cell walk (grid update only).  fl(j, r, r2, m) is called for every liquid list entry j != i
+// inside the support (r = x_i - x_j, m = multiplicity of the entry in the reference's bucket multiset),
 // fs(j, r, r2, m) likewise for solid entries.  Entries outside the support contribute exactly zero
 // to every kernel-weighted sum of the reference (compact support) and are skipped here; the raw
 // list LENGTH the reference also uses (Q2/Q10) is d.ncount[i], built by the grid update.
 template <class FL, class FS>
-__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, FL &&fl, FS &&fs) {
+__device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, FL &&fl, FS &&fs) {
   const int cw = __float_as_int(pi.w);
   if (cw < 0) return;  // outside the grid box: no neighbours (ref: HashGrid.py:80-81, Q4)
   const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
@@ -145,7 +150,7 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, FL &&fl, FS
         const float4 pj = d.pos[j];
         const float3 r = xi - xyz(pj);
         const float r2 = dot3(r, r);
-        if (r2 <= d.h2 && j != i) fl(j, r, r2, 1.0f);
+        if (r2 <= d.list_r2 && j != i) fl(j, r, r2, 1.0f);
       }
     }
   }
@@ -164,7 +169,7 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, FL &&fl, FS
           const float4 pj = d.spos[j];
           const float3 r = xi - xyz(pj);
           const float r2 = dot3(r, r);
-          if (r2 <= d.h2) fs(j, r, r2, 1.0f);
+          if (r2 <= d.list_r2) fs(j, r, r2, 1.0f);
         }
       }
     }
@@ -183,13 +188,53 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, FL &&fl, FS
       for (int j = d.cs_l[c]; j < d.cs_l[c + 1]; j++) {
         const float3 r = xi - xyz(d.pos[j]);
         const float r2 = dot3(r, r);
-        if (r2 <= d.h2 && j != i) fl(j, r, r2, m);
+        if (r2 <= d.list_r2 && j != i) fl(j, r, r2, m);
       }
       for (int j = d.cs_s[c]; j < d.cs_s[c + 1]; j++) {
         const float3 r = xi - xyz(d.spos[j]);
         const float r2 = dot3(r, r);
-        if (r2 <= d.h2) fs(j, r, r2, m);
+        if (r2 <= d.list_r2) fs(j, r, r2, m);
       }
     }
+  }
+}
+
+// The neighbour loop of every pass: iterate the compact list the grid update built for this step
+// (the in-support subset of the reference's HashGrid.neighbor row, duplicates included, so m == 1).
+// As in the reference the list is frozen until the next update_grid() while r is recomputed from the
+// current positions (ref: dfsph.py:254-256 and every other `while k < cur_neighbor` loop).
+// Two entries are fetched per trip so that their gathers are in flight together.
+template <class FL, class FS>
+__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, FL &&fl, FS &&fs) {
+  const float3 xi = xyz(pi);
+  const int *nl = d.nbr_l + i;
+  const size_t st = (size_t)d.nbr_stride;
+  const int cl = d.ncl[i];
+  int k = 0;
+  for (; k + 1 < cl; k += 2) {
+    const int j0 = nl[k * st], j1 = nl[(k + 1) * st];
+    const float4 p0 = d.pos[j0], p1 = d.pos[j1];
+    const float3 r0 = xi - xyz(p0), r1 = xi - xyz(p1);
+    fl(j0, r0, dot3(r0, r0), 1.0f);
+    fl(j1, r1, dot3(r1, r1), 1.0f);
+  }
+  if (k < cl) {
+    const int j0 = nl[k * st];
+    const float3 r0 = xi - xyz(d.pos[j0]);
+    fl(j0, r0, dot3(r0, r0), 1.0f);
+  }
+  const int cs = d.ncs[i];
+  const int *ns = d.nbr_s + i;
+  for (k = 0; k + 1 < cs; k += 2) {
+    const int j0 = ns[k * st], j1 = ns[(k + 1) * st];
+    const float4 p0 = d.spos[j0], p1 = d.spos[j1];
+    const float3 r0 = xi - xyz(p0), r1 = xi - xyz(p1);
+    fs(j0, r0, dot3(r0, r0), 1.0f);
+    fs(j1, r1, dot3(r1, r1), 1.0f);
+  }
+  if (k < cs) {
+    const int j0 = ns[k * st];
+    const float3 r0 = xi - xyz(d.spos[j0]);
+    fs(j0, r0, dot3(r0, r0), 1.0f);
   }
 }

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_normal(Dev d) {
 // ref: kernels/AdhesionKernel.py:20-29
 __device__ __forceinline__ float adhesion_W(const Dev &d, float r) {
   float res = 0.f;
-  if (r * r <= d.h2 && r > 0.5f * d.h) res = d.adh_mk * powf(-4.0f * r * r / d.h + 6.0f * r - 2.0f * d.h, 0.25f);
+  if (r * r <= d.h2 && r > 0.5f * d.h) res = d.adh_mk * powf(fmaxf(-4.0f * r * r / d.h + 6.0f * r - 2.0f * d.h, 0.0f), 0.25f);
   return res;
 }
 __global__ void __launch_bounds__(BLOCK) k_tension_accel(Dev d) {
@@ -219,9 +219,9 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel(Dev d) {
   const float rhoi = d.rho[i];
   float3 acc = f3(0, 0, 0);
   walk(d, i, pi,
-       [&](int j, float3, float, float m) {
+       [&](int j, float3, float r2, float m) {
          float kij = 2.0f * d.rho_L0 / (rhoi + d.rho[j]);
-         acc = acc + (ni - xyz(d.normal[j])) * (-d.tension * kij * m);
+         if (r2 <= d.h2) acc = acc + (ni - xyz(d.normal[j])) * (-d.tension * kij * m);
        },
        [&](int j, float3 r, float r2, float m) {
          float3 pj = xyz(d.spos[j]);
@@ -405,7 +405,16 @@ __global__ void __launch_bounds__(BLOCK) k_cfl(Dev d, float dt) {
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_down(vm, o, WAVE));
-  if ((threadIdx.x & (WAVE - 1)) == 0 && vm > 0.f) atomicMax(&d.flags[FLAG_VMAX], __float_as_int(vm));
+  __shared__ float sh[BLOCK / WAVE];
+  if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE] = vm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 1; k < BLOCK / WAVE; k++) vm = fmaxf(vm, sh[k]);
+    // positive floats order like their bit patterns; skip the atomic when this block cannot raise the max
+    if (vm > 0.f && __float_as_int(vm) > __hip_atomic_load(&d.flags[FLAG_VMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(&d.flags[FLAG_VMAX], __float_as_int(vm));
+  }
 }
 __global__ void k_cfl_store(Dev d) {  // slot 0 of the reference's vel_max field holds the result
   if (d.nl > 0 && d.n_owned > 0) d.vel_max[d.where[0]] = __int_as_float(d.flags[FLAG_VMAX]);

@@ -266,6 +266,27 @@ __global__ void k_ncount_clean(Dev d) {
   d.ncount[i] = cnt;
 }
 
+// Compact per-step neighbour lists: the in-support entries of the reference's neighbour row, with the
+// bucket-multiset multiplicity expanded into repeated entries (ref: HashGrid.py:88-106).
+__global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d) {
+  const int i = sorted_index();
+  if (i >= d.nl) return;
+  const float4 pi = d.pos[i];
+  const size_t st = (size_t)d.nbr_stride;
+  int cl = 0, cs = 0;
+  const int cap = d.nbr_cap;
+  walk_cells(d, i, pi,
+             [&](int j, float3, float, float m) {
+               for (int rep = (int)m; rep > 0; rep--) { if (cl < cap) d.nbr_l[cl * st + i] = j; cl++; }
+             },
+             [&](int j, float3, float, float m) {
+               for (int rep = (int)m; rep > 0; rep--) { if (cs < cap) d.nbr_s[cs * st + i] = j; cs++; }
+             });
+  if (cl > cap || cs > cap) { atomicOr(&d.flags[FLAG_ERR], ERRBIT_LISTCAP); cl = min(cl, cap); cs = min(cs, cap); }
+  d.ncl[i] = cl;
+  d.ncs[i] = cs;
+}
+
 // ---- original-order <-> sorted-order field transfer ---------------------------------------
 __global__ void k_unpermute3(const float4 *f, const int *oid, int n, float *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -86,6 +86,7 @@ static int check_flags(wcsph_ctx *ctx) {
   int f = ctx->h_flags[FLAG_ERR];
   if (f & ERRBIT_BUCKET) return ctx->fail(WCSPH_EBUCKET, "more than maxInGrid particles in one hash bucket (ref: HashGrid.py:72-74)");
   if (f & ERRBIT_NEIGH) return ctx->fail(WCSPH_ENEIGH, "more than maxNeighbour neighbour-list entries (ref: HashGrid.py:100-103)");
+  if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "more than 128 in-support neighbours of one kind for a particle (compact list capacity)");
   return 0;
 }
 // copy reduction slots + flags to the host and wait
@@ -134,6 +135,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   d.ml_h3 = (float)(48.0 / M_PI) * (float)(1.0 / (h * h * h));
   d.mk_h3 = (float)(8.0 / M_PI) * (float)(1.0 / (h * h * h));
   d.adh_mk = (float)(0.007 / pow(h, 3.25));
+  { float lr = p->list_radius > 0.0f ? p->list_radius : d.h; d.list_r2 = lr * lr * 1.00001f; }
   d.VL0 = p->VL0; d.VS0 = p->VS0; d.rho_L0 = p->rho_L0; d.rho_S0 = p->rho_S0; d.mass = p->liqiudMass; d.eps = p->eps;
   d.gx = p->gravity[0]; d.gy = p->gravity[1]; d.gz = p->gravity[2];
   d.dim_coff = p->dim_coff; d.visc = p->viscosity; d.visc_b = p->viscosity_b;
@@ -153,7 +155,11 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.cg_r, nl); DALLOC(d.cg_dir, nl); DALLOC(d.cg_Ad, nl); DALLOC(d.cg_s, nl);
   DALLOC(d.minv0, nl); DALLOC(d.minv1, nl); DALLOC(d.minv2, nl);
   DALLOC(d.rho, nl); DALLOC(d.adv_rho, nl); DALLOC(d.pressure, nl); DALLOC(d.vel_max, nl); DALLOC(d.alpha, nl); DALLOC(d.kbuf, nl);
-  DALLOC(d.ncount, nl);
+  DALLOC(d.ncount, nl); DALLOC(d.ncl, nl); DALLOC(d.ncs, nl);
+  d.nbr_stride = (int)((nl + 63) / 64 * 64);
+  d.nbr_cap = p->max_neighbour < 128 ? p->max_neighbour : 128;
+  if (d.nbr_cap < 1) d.nbr_cap = 1;
+  DALLOC(d.nbr_l, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.nbr_s, (size_t)d.nbr_stride * d.nbr_cap);
   DALLOC(d.spos, (size_t)d.ns);
   DALLOC(d.acc, 8); DALLOC(d.flags, 4);
   size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
@@ -317,6 +323,7 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
   }
+  if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d);
   LAUNCHCHK();
   ctx->grid_valid = true;
   return WCSPH_OK;
@@ -385,9 +392,10 @@ int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(dst, ctx->stage, (size_t)nl * per * 4, hipMemcpyDeviceToHost, s));
   }
+  HIPCHK(hipMemcpyAsync(ctx->h_flags, d.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (field == WCSPH_F_POS && d.ns > 0) memcpy((float *)dst + (size_t)nl * 3, ctx->solid_host.data(), (size_t)d.ns * 12);
-  return WCSPH_OK;
+  return check_flags(ctx);
 }
 
 int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes) {
@@ -562,6 +570,9 @@ int wcsph_dfsph_clear_nonpressure(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_clear_n
 
 int wcsph_dfsph_tension(wcsph_ctx *ctx) {
   NEED_GRID();
+  // gamma = gamma_b = 0 (the reference default): both loops add exactly +-0 to d_vel; `normal` (order
+  // dependent garbage in the reference, Q8) is then left untouched.
+  if (ctx->d.tension == 0.0f && ctx->d.tension_b == 0.0f) return WCSPH_OK;
   PASS(k_tension_normal);
   PASS(k_tension_accel);
   return WCSPH_OK;

@@ -50,6 +50,7 @@ def init_particle(filename=None, neighbor_mode="faithful"):
     current_time = 0.0
     particle_data = ParticleData(gridR, neighbor_mode=neighbor_mode)  # the DIAMETER, as the reference does (Q11)
     particle_data.sesph_particle_radius = particleRadius
+    particle_data.list_radius = searchR  # the script's kernel support (0.1), not the hash grid's 0.2 walk radius
     liquid, solid = scene.sesph_scene(particleRadius, particleDimX, boundary)
     particle_data.add_liquid_points(liquid)
     particle_data.add_solid_points(solid)
