@@ -77,6 +77,7 @@ enum wcsph_field {
   WCSPH_F_ADV_RHO, WCSPH_F_PRESSURE, WCSPH_F_VEL_MAX, WCSPH_F_ALPHA, WCSPH_F_KAPPA, WCSPH_F_KAPPA_V,
   WCSPH_F_CG_MINV,     /* [n_liquid][3][3] f32 */
   WCSPH_F_NEIGHBOR_COUNT, /* [n_liquid] i32  (HashGrid.neighborCount) */
+  WCSPH_F_KBUF,        /* [n_liquid] f32 scratch: k_i = b_i * alpha_i of the running iteration (dfsph.py:456,525) */
   WCSPH_F__COUNT
 };
 
@@ -157,7 +158,53 @@ int wcsph_sesph_step(wcsph_ctx *ctx);          /* ref: sesph.py:217-225 */
  * "grid_update", "visc_iter".  State is not preserved across the call. */
 int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms_per_launch);
 
-/* ---- slab decomposition helpers; device pointers are caller-owned -------- */
+/* ---- slab decomposition: one context per GPU, host code exchanges halos between phases -- */
+/* Restrict the dense cell table to global cell columns [x0, x1) along x; call BEFORE wcsph_setup().  Cell
+ * coordinates (and the reference hash) stay global, so every rank sees the same cells (HashGrid.py:68). */
+int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1);
+/* Replace the liquid set: d_rows is a DEVICE array [n_total][14] f32 = pos3 vel3 omega3 vel_guess3 kappa kappa_v
+ * (the fields the reference carries across steps).  Rows [0,n_owned) are this rank's particles, the rest are
+ * ghost copies: read as neighbours, never updated, excluded from reductions.  n_total <= params.n_liquid. */
+int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows);
+int wcsph_store_state(wcsph_ctx *ctx, float *d_rows /* device [n_owned][14] */);
+/* reduction slots of the running phase (double): 0 density-error sum, 1 d.Ad, 2 r.s, 3 delta_zero */
+int wcsph_get_acc(wcsph_ctx *ctx, int slot, double *v);   /* synchronises */
+int wcsph_set_acc(wcsph_ctx *ctx, int slot, double v);
+/* One launch group of the DFSPH step without any host synchronisation (ids: enum wcsph_phase).  The fused
+ * entry points above are sequences of these; a slab driver interleaves halo exchanges and all-reduces. */
+enum wcsph_phase {
+  WCSPH_PH_DENSITY_COFF = 0,  /* dfsph.py:248-262 + 345-372 in one walk */
+  WCSPH_PH_DRHO_DIV_WARM,     /* dfsph.py:417-418 */
+  WCSPH_PH_VEL_WARM,          /* dfsph.py:420-439 */
+  WCSPH_PH_DRHO_DIV_BEGIN,    /* dfsph.py:441-446 */
+  WCSPH_PH_MAKE_K_DIV,        /* dfsph.py:454-458 (k_i, kappa_v += k_i) */
+  WCSPH_PH_VEL_ITER,          /* dfsph.py:460-471 / 529-541 */
+  WCSPH_PH_DRHO_DIV_ITER,     /* dfsph.py:474-477, slot 0 <- local sum */
+  WCSPH_PH_END_DIV,           /* dfsph.py:480-484 */
+  WCSPH_PH_WARM_PRESS_SCALE,  /* dfsph.py:489-490 */
+  WCSPH_PH_WARM_PRESS_VEL,    /* dfsph.py:492-508 */
+  WCSPH_PH_DRHO_PRESS_BEGIN,  /* dfsph.py:511-516 */
+  WCSPH_PH_MAKE_K_PRESS,      /* dfsph.py:523-527 */
+  WCSPH_PH_DRHO_PRESS_ITER,   /* dfsph.py:544-547, slot 0 <- local sum */
+  WCSPH_PH_END_PRESS,         /* dfsph.py:549-552 */
+  WCSPH_PH_CLEAR,             /* dfsph.py:333-336 */
+  WCSPH_PH_TENSION_NORMAL,    /* dfsph.py:266-279 */
+  WCSPH_PH_TENSION_ACCEL,     /* dfsph.py:281-305 */
+  WCSPH_PH_VISC_GUESS,        /* dfsph.py:199-200 */
+  WCSPH_PH_VISC_MINV,         /* dfsph.py:202-215 */
+  WCSPH_PH_VISC_RESIDUAL,     /* dfsph.py:217-223, slot 3 <- local sum */
+  WCSPH_PH_VISC_AD,           /* dfsph.py:227-230, slot 1 <- local sum */
+  WCSPH_PH_VISC_UPDATE,       /* dfsph.py:233-240, reads slot 1 and scalar cg_delta, slot 2 <- local sum */
+  WCSPH_PH_VISC_DIR,          /* dfsph.py:243-246, reads slot 2 and scalar cg_delta (as delta_old) */
+  WCSPH_PH_VISC_END,          /* dfsph.py:339-343 */
+  WCSPH_PH_VORTICITY,         /* dfsph.py:309-327 */
+  WCSPH_PH_VORTICITY_INT,     /* dfsph.py:329-330 */
+  WCSPH_PH_UPDATE_VEL,        /* dfsph.py:572-575 */
+  WCSPH_PH_UPDATE_POS,        /* dfsph.py:577-580 */
+  WCSPH_PH__COUNT
+};
+int wcsph_phase(wcsph_ctx *ctx, int phase);
+
 /* gather / scatter `n` rows of a field by ORIGINAL liquid indices (device int32 array) into / from a
  * packed device buffer (rows of 3 f32 for vec3 fields, 1 f32 for scalar fields) for halo exchange */
 int wcsph_field_gather_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, void *d_dst);

@@ -17,9 +17,9 @@ _SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_z
             "tension_coff", "tension_coff_b", "VL0", "VS0", "liqiudMass", "searchR", "gridR", "invGridR", "rho_L0",
             "viscosity_err", "vorticity_coff", "viscosity_omega", "vorticity_init"]
 _INTS = ["vs_iter", "dv_iter", "pr_iter", "overflow_grid", "overflow_neighbor", "table_size", "bs0", "bs1", "bs2",
-         "tension_fixed", "mode"]
+         "tension_fixed", "mode", "n_reduce"]
 _VEC3 = ["vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s"]
-_SCAL = ["rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v"]
+_SCAL = ["rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "kbuf"]
 _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff", "update_drho_divergence",
           "update_drho_pressure", "warmstart_divergence_vel", "begin_divergence_iter", "divergence_iter",
           "end_divergence_iter", "warmstart_pressure", "begin_pressure_iter", "pressure_iter", "end_pressure_iter",
@@ -27,7 +27,12 @@ _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff",
           "compute_vorticity", "cfl_reduce", "optimize_time_step", "update_vel", "update_pos",
           "compute_nonpressure_force", "solve_vel_divergence", "solve_pressure", "dfsph_step",
           "sesph_reset_param", "sesph_update_advection_density", "sesph_update_pressure", "sesph_compute_force",
-          "sesph_integrate", "sesph_step"]
+          "sesph_integrate", "sesph_step",
+          # loop-boundary splits of the fused kernels (used by the slab-decomposition tests)
+          "warmstart_divergence_drho", "warmstart_divergence_velloop", "make_k_div", "make_k_press", "vel_iter",
+          "drho_div_iter", "drho_press_iter", "warmstart_pressure_scale", "warmstart_pressure_vel", "tension_normal",
+          "tension_accel", "visc_guess", "visc_minv", "visc_residual", "visc_Ad", "visc_update", "visc_dir",
+          "vorticity_accumulate", "vorticity_integrate"]
 
 
 def build_oracle(force=False):
@@ -67,6 +72,10 @@ def _load():
         lib.orc_get_int.argtypes = [C.c_void_p, C.c_int]
         lib.orc_get_int.restype = C.c_int
         lib.orc_set_int.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for nm in ("dAd", "dnew"):
+            getattr(lib, "orc_get_" + nm).argtypes = [C.c_void_p]
+            getattr(lib, "orc_get_" + nm).restype = C.c_double
+            getattr(lib, "orc_set_" + nm).argtypes = [C.c_void_p, C.c_double]
         for s in _STEPS:
             getattr(lib, "orc_" + s).argtypes = [C.c_void_p]
             getattr(lib, "orc_" + s).restype = None
@@ -142,7 +151,7 @@ class Oracle:
     def __setattr__(self, name, v):
         if name in _SCALARS:
             self.lib.orc_set_scalar(self.h, _SCALARS.index(name), float(v))
-        elif name in ("vs_iter", "dv_iter", "pr_iter", "tension_fixed"):
+        elif name in ("vs_iter", "dv_iter", "pr_iter", "tension_fixed", "n_reduce"):
             self.lib.orc_set_int(self.h, _INTS.index(name), int(v))
         elif name in self.__dict__ and isinstance(self.__dict__[name], np.ndarray):
             self.__dict__[name][...] = v  # field assignment copies into the C array
@@ -175,6 +184,11 @@ class Oracle:
 
     def adh_W(self, r):
         return float(self.lib.orc_adh_W(self.h, float(r)))
+
+    def get_dAd(self): return float(self.lib.orc_get_dAd(self.h))          # noqa: E704
+    def set_dAd(self, v): self.lib.orc_set_dAd(self.h, float(v))           # noqa: E704
+    def get_dnew(self): return float(self.lib.orc_get_dnew(self.h))        # noqa: E704
+    def set_dnew(self, v): self.lib.orc_set_dnew(self.h, float(v))         # noqa: E704
 
     def sesph_init(self, particleRadius=0.025):
         self.lib.orc_sesph_init(self.h, float(particleRadius))

@@ -58,8 +58,11 @@ typedef struct orc_ctx {
   float *cg_Minv;                                       /* [liquid*9] row-major */
   v3 *cg_r, *cg_dir, *cg_Ad, *cg_s;
   float avg_density_err, cg_delta, cg_delta_old, cg_delta_zero;
+  double cg_dAd, cg_dnew; /* local reductions of the running PCG iteration */
   /* ---- dfsph.py module globals (ref: dfsph.py:42-48) ---- */
   float *alpha_coff, *kappa, *kappa_v;
+  float *kbuf;     /* k_i = b_i * alpha_i of the running iteration (dfsph.py:456, 525) */
+  int n_reduce;    /* reductions cover particles [0, n_reduce): all liquid, or the owned rows of a slab test */
   float deltaT;
   int vs_iter, dv_iter, pr_iter;
   double particleRadius, user_max_t, user_min_t; /* python-scope doubles, dfsph.py:27,39-40 */
@@ -116,7 +119,8 @@ orc_ctx *orc_create(int n_liquid, int n_solid, double particleR, int maxInGrid, 
   AL1(rho); AL1(adv_rho); AL1(pressure); AL1(vel_max);
   c->cg_Minv = (float *)calloc(nl * 9, sizeof(float));
   AL3(cg_r); AL3(cg_dir); AL3(cg_Ad); AL3(cg_s);
-  AL1(alpha_coff); AL1(kappa); AL1(kappa_v);
+  AL1(alpha_coff); AL1(kappa); AL1(kappa_v); AL1(kbuf);
+  c->n_reduce = n_liquid;
   c->neighborCount = (int *)calloc(nl, sizeof(int));
   c->neighbor = (int *)malloc(nl * (size_t)maxNeighbour * sizeof(int));
   c->deltaT = 0.0f;
@@ -128,7 +132,7 @@ void orc_destroy(orc_ctx *c) {
   free(c->pos); free(c->vel); free(c->vel_guess); free(c->d_vel); free(c->omega); free(c->d_omega);
   free(c->normal); free(c->rho); free(c->adv_rho); free(c->pressure); free(c->vel_max); free(c->cg_Minv);
   free(c->cg_r); free(c->cg_dir); free(c->cg_Ad); free(c->cg_s); free(c->alpha_coff); free(c->kappa);
-  free(c->kappa_v); free(c->neighborCount); free(c->neighbor); free(c->gridCount); free(c->grid);
+  free(c->kappa_v); free(c->kbuf); free(c->neighborCount); free(c->neighbor); free(c->gridCount); free(c->grid);
   free(c);
 }
 
@@ -348,27 +352,35 @@ static inline void update_drho_pressure(orc_ctx *c, int i) {
 void orc_update_drho_divergence(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) update_drho_divergence(c, i); }
 void orc_update_drho_pressure(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) update_drho_pressure(c, i); }
 
-/* ref: dfsph.py:415-439 */
-void orc_warmstart_divergence_vel(orc_ctx *c) {
+/* ref: dfsph.py:415-439, first parallel loop (:417-418) */
+void orc_warmstart_divergence_drho(orc_ctx *c) {
   PFOR for (int i = 0; i < NL; i++) {
     c->kappa_v[i] = 0.5f * fmaxf(c->kappa_v[i] / c->deltaT, -0.5f * c->rho_L0 * c->rho_L0);
     update_drho_divergence(c, i);
   }
-  /* second parallel loop: vel[i] written, kappa_v[j] read (never vel[j]) => order free */
+}
+/* neighbour loop shared by warmstart_divergence_vel (:420-439, kb = kappa_v, only where adv_rho > 0),
+ * divergence_iter (:460-471) and pressure_iter (:529-541) (kb = k of the iteration):
+ * vel[i] written, kb[j] read (never vel[j]) => order free */
+static void vel_from_k(orc_ctx *c, const float *kb, int only_positive_adv) {
   PFOR for (int i = 0; i < NL; i++) {
-    if (c->adv_rho[i] > 0.0f) {
-      v3 v = c->vel[i];
-      float ki = c->kappa_v[i];
-      NB_BEGIN(i)
-        v3 gradV = CubicGradW(c, r);
-        if (j < NL) {
-          float sum = ki + c->kappa_v[j];
-          if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
-        } else if (fabsf(ki) > c->eps) v = add(v, mul(gradV, c->deltaT * ki * c->VS0));
-      NB_END
-      c->vel[i] = v;
-    }
+    if (only_positive_adv && !(c->adv_rho[i] > 0.0f)) continue;
+    v3 v = c->vel[i];
+    float ki = kb[i];
+    NB_BEGIN(i)
+      v3 gradV = CubicGradW(c, r);
+      if (j < NL) {
+        float sum = ki + kb[j];
+        if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
+      } else if (fabsf(ki) > c->eps) v = add(v, mul(gradV, c->deltaT * ki * c->VS0));
+    NB_END
+    c->vel[i] = v;
   }
+}
+void orc_warmstart_divergence_velloop(orc_ctx *c) { vel_from_k(c, c->kappa_v, 1); }
+void orc_warmstart_divergence_vel(orc_ctx *c) {
+  orc_warmstart_divergence_drho(c);
+  orc_warmstart_divergence_velloop(c);
 }
 
 /* ref: dfsph.py:441-446 */
@@ -380,25 +392,27 @@ void orc_begin_divergence_iter(orc_ctx *c) {
   }
 }
 
-/* ref: dfsph.py:449-477 */
-void orc_divergence_iter(orc_ctx *c) {
+/* ref: dfsph.py:449-477, split at the loop boundaries */
+void orc_make_k(orc_ctx *c, float *kap, float bias) { /* :454-458 / :523-527: k_i = b_i alpha_i ; kappa_i += k_i */
   PFOR for (int i = 0; i < NL; i++) {
-    float ki = c->adv_rho[i] * c->alpha_coff[i];
-    c->kappa_v[i] += ki;
-    v3 v = c->vel[i];
-    NB_BEGIN(i)
-      v3 gradV = CubicGradW(c, r);
-      if (j < NL) {
-        float sum = ki + c->alpha_coff[j] * c->adv_rho[j];
-        if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
-      } else if (fabsf(ki) > c->eps) v = add(v, mul(gradV, c->deltaT * ki * c->VS0));
-    NB_END
-    c->vel[i] = v;
+    float k = (c->adv_rho[i] - bias) * c->alpha_coff[i];
+    c->kbuf[i] = k;
+    kap[i] += k;
   }
+}
+void orc_make_k_div(orc_ctx *c) { orc_make_k(c, c->kappa_v, 0.0f); }
+void orc_make_k_press(orc_ctx *c) { orc_make_k(c, c->kappa, 1.0f); }
+void orc_vel_iter(orc_ctx *c) { vel_from_k(c, c->kbuf, 0); } /* :460-471 / :529-541 */
+void orc_drho_div_iter(orc_ctx *c) { /* :474-477 */
   double err = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : err)
-  for (int i = 0; i < NL; i++) { update_drho_divergence(c, i); err += (double)c->adv_rho[i]; }
+  for (int i = 0; i < NL; i++) { update_drho_divergence(c, i); if (i < c->n_reduce) err += (double)c->adv_rho[i]; }
   c->avg_density_err = (float)err;
+}
+void orc_divergence_iter(orc_ctx *c) {
+  orc_make_k_div(c);
+  orc_vel_iter(c);
+  orc_drho_div_iter(c);
 }
 
 /* ref: dfsph.py:480-484 */
@@ -407,9 +421,11 @@ void orc_end_divergence_iter(orc_ctx *c) {
 }
 
 /* ref: dfsph.py:487-508 (kept literally, including the kappa_v typo in the solid branch, Q7) */
-void orc_warmstart_pressure(orc_ctx *c) {
+void orc_warmstart_pressure_scale(orc_ctx *c) {
   PFOR for (int i = 0; i < NL; i++)
     c->kappa[i] = fmaxf(c->kappa[i] / c->deltaT / c->deltaT, -0.5f * c->rho_L0 * c->rho_L0);
+}
+void orc_warmstart_pressure_vel(orc_ctx *c) {
   PFOR for (int i = 0; i < NL; i++) {
     if (c->adv_rho[i] > c->rho_L0) {
       v3 v = c->vel[i];
@@ -424,6 +440,7 @@ void orc_warmstart_pressure(orc_ctx *c) {
     }
   }
 }
+void orc_warmstart_pressure(orc_ctx *c) { orc_warmstart_pressure_scale(c); orc_warmstart_pressure_vel(c); }
 
 /* ref: dfsph.py:511-516 */
 void orc_begin_pressure_iter(orc_ctx *c) {
@@ -434,28 +451,17 @@ void orc_begin_pressure_iter(orc_ctx *c) {
   }
 }
 
-/* ref: dfsph.py:518-547 */
-void orc_pressure_iter(orc_ctx *c) {
-  PFOR for (int i = 0; i < NL; i++) {
-    float bi = c->adv_rho[i] - 1.0f;
-    float ki = bi * c->alpha_coff[i];
-    c->kappa[i] += ki;
-    v3 v = c->vel[i];
-    NB_BEGIN(i)
-      v3 gradV = CubicGradW(c, r);
-      if (j < NL) {
-        float bj = c->adv_rho[j] - 1.0f;
-        float kj = bj * c->alpha_coff[j];
-        float sum = ki + kj;
-        if (fabsf(sum) > c->eps) v = add(v, mul(gradV, c->deltaT * sum * c->VL0));
-      } else if (fabsf(ki) > c->eps) v = add(v, mul(gradV, c->deltaT * ki * c->VS0));
-    NB_END
-    c->vel[i] = v;
-  }
+/* ref: dfsph.py:518-547, split at the loop boundaries (first loop: orc_make_k_press + orc_vel_iter) */
+void orc_drho_press_iter(orc_ctx *c) { /* :544-547 */
   double err = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : err)
-  for (int i = 0; i < NL; i++) { update_drho_pressure(c, i); err += (double)(c->adv_rho[i] - 1.0f); }
+  for (int i = 0; i < NL; i++) { update_drho_pressure(c, i); if (i < c->n_reduce) err += (double)(c->adv_rho[i] - 1.0f); }
   c->avg_density_err = (float)err;
+}
+void orc_pressure_iter(orc_ctx *c) {
+  orc_make_k_press(c);
+  orc_vel_iter(c);
+  orc_drho_press_iter(c);
 }
 
 /* ref: dfsph.py:549-552 */
@@ -471,7 +477,7 @@ void orc_clear_nonpressure(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) c->d_
  * curvature term over EVERY liquid list entry, cohesion overwritten, Q9).
  * tension_fixed == 1 is the documented repair: n_i = h * sum (m/rho_j) gradW, curvature
  * term only for entries inside the support. */
-void orc_compute_tension(orc_ctx *c) {
+void orc_tension_normal(orc_ctx *c) {
   const float h = c->ck_h;
   PFOR for (int i = 0; i < NL; i++) {
     v3 n = V(0, 0, 0);
@@ -483,6 +489,9 @@ void orc_compute_tension(orc_ctx *c) {
     if (c->tension_fixed) n = mul(n, h);
     c->normal[i] = n;
   }
+}
+void orc_tension_accel(orc_ctx *c) {
+  const float h = c->ck_h;
   PFOR for (int i = 0; i < NL; i++) {
     v3 dv = c->d_vel[i];
     NB_BEGIN(i)
@@ -504,6 +513,7 @@ void orc_compute_tension(orc_ctx *c) {
     c->d_vel[i] = dv;
   }
 }
+void orc_compute_tension(orc_ctx *c) { orc_tension_normal(c); orc_tension_accel(c); }
 
 /* ref: dfsph.py:181-195.  x is vel_guess or cg_dir. */
 static inline v3 viscosity_Ax(const orc_ctx *c, const v3 *x, int i) {
@@ -534,8 +544,10 @@ static inline v3 matvec(const float *m, v3 v) {
 }
 
 /* ref: dfsph.py:197-223 */
-void orc_init_viscosity_para(orc_ctx *c) {
+void orc_visc_guess(orc_ctx *c) { /* :199-200 */
   PFOR for (int i = 0; i < NL; i++) c->vel_guess[i] = add(c->vel_guess[i], c->vel[i]);
+}
+void orc_visc_minv(orc_ctx *c) { /* :202-215 */
   const float e = 0.01f * c->searchR * c->searchR;
   PFOR for (int i = 0; i < NL; i++) {
     float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -553,39 +565,49 @@ void orc_init_viscosity_para(orc_ctx *c) {
     for (int a = 0; a < 9; a++) t[a] = ((a % 4 == 0) ? 1.0f : 0.0f) - m[a] * f;
     inv3(t, c->cg_Minv + (long)i * 9);
   }
+}
+void orc_visc_residual(orc_ctx *c) { /* :217-223 */
   double dz = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : dz)
   for (int i = 0; i < NL; i++) {
     c->cg_r[i] = sub(c->vel[i], viscosity_Ax(c, c->vel_guess, i));
     c->cg_dir[i] = matvec(c->cg_Minv + (long)i * 9, c->cg_r[i]);
-    dz += (double)dot(c->cg_r[i], c->cg_dir[i]);
+    if (i < c->n_reduce) dz += (double)dot(c->cg_r[i], c->cg_dir[i]);
   }
   c->cg_delta_zero = (float)dz;
   c->cg_delta = c->cg_delta_zero;
 }
+void orc_init_viscosity_para(orc_ctx *c) { orc_visc_guess(c); orc_visc_minv(c); orc_visc_residual(c); }
 
-/* ref: dfsph.py:225-246 */
-void orc_compute_viscosity_force(orc_ctx *c) {
-  double dAd = (double)c->eps;
+/* ref: dfsph.py:225-246, split at the loop boundaries.  cg_dAd is the kernel-local scalar of the reference. */
+void orc_visc_Ad(orc_ctx *c) { /* :227-230 */
+  double dAd = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : dAd)
   for (int i = 0; i < NL; i++) {
     c->cg_Ad[i] = viscosity_Ax(c, c->cg_dir, i);
-    dAd += (double)dot(c->cg_dir[i], c->cg_Ad[i]);
+    if (i < c->n_reduce) dAd += (double)dot(c->cg_dir[i], c->cg_Ad[i]);
   }
-  float alpha = c->cg_delta / (float)dAd;
-  c->cg_delta_old = c->cg_delta;
+  c->cg_dAd = dAd;   /* without the eps start value; added where it is used */
+}
+void orc_visc_update(orc_ctx *c) { /* :233-240 */
+  float alpha = c->cg_delta / (float)((double)c->eps + c->cg_dAd);
   double dl = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : dl)
   for (int i = 0; i < NL; i++) {
     c->vel_guess[i] = add(c->vel_guess[i], mul(c->cg_dir[i], alpha));
     c->cg_r[i] = sub(c->cg_r[i], mul(c->cg_Ad[i], alpha));
     c->cg_s[i] = matvec(c->cg_Minv + (long)i * 9, c->cg_r[i]);
-    dl += (double)dot(c->cg_r[i], c->cg_s[i]);
+    if (i < c->n_reduce) dl += (double)dot(c->cg_r[i], c->cg_s[i]);
   }
-  c->cg_delta = (float)dl;
+  c->cg_dnew = dl;
+}
+void orc_visc_dir(orc_ctx *c) { /* :234-235, 243-246 */
+  c->cg_delta_old = c->cg_delta;
+  c->cg_delta = (float)c->cg_dnew;
   float beta = c->cg_delta / c->cg_delta_old;
   PFOR for (int i = 0; i < NL; i++) c->cg_dir[i] = add(c->cg_s[i], mul(c->cg_dir[i], beta));
 }
+void orc_compute_viscosity_force(orc_ctx *c) { orc_visc_Ad(c); orc_visc_update(c); orc_visc_dir(c); }
 
 /* ref: dfsph.py:339-343 */
 void orc_end_viscosity(orc_ctx *c) {
@@ -598,7 +620,7 @@ void orc_end_viscosity(orc_ctx *c) {
 /* ref: dfsph.py:307-330.  Q18: for a solid j the reference indexes omega[j] / vel[j] out of
  * bounds; restated with omega_j = vel_j = 0 (static wall) -- unreproducible otherwise.
  * Q10: the damping term is added once per list entry. */
-void orc_compute_vorticity(orc_ctx *c) {
+void orc_vorticity_accumulate(orc_ctx *c) {
   PFOR for (int i = 0; i < NL; i++) {
     v3 dom = V(0, 0, 0), dv = c->d_vel[i];
     NB_BEGIN(i)
@@ -616,13 +638,25 @@ void orc_compute_vorticity(orc_ctx *c) {
     NB_END
     c->d_omega[i] = dom; c->d_vel[i] = dv;
   }
+}
+void orc_vorticity_integrate(orc_ctx *c) { /* :329-330 */
   PFOR for (int i = 0; i < NL; i++) c->omega[i] = add(c->omega[i], mul(c->d_omega[i], c->deltaT));
 }
+void orc_compute_vorticity(orc_ctx *c) { orc_vorticity_accumulate(c); orc_vorticity_integrate(c); }
 
 /* ref: dfsph.py:555-568 + host loop :107-111.  Literal strided tree (covers the first
  * 2^floor(log2(N-1)) particles, Q5); out-of-range reads return the element itself. */
 void orc_cfl_reduce(orc_ctx *c) {
   int N = NL;
+  if (c->mode == 1) { /* clean: the true maximum (over the reduction range) lands in slot 0 */
+    float m = 0.0f;
+    for (int i = 0; i < N; i++) {
+      c->vel_max[i] = fmaxf(nsq(add(c->vel[i], mul(c->d_vel[i], c->deltaT))), 0.1f);
+      if (i < c->n_reduce && c->vel_max[i] > m) m = c->vel_max[i];
+    }
+    if (N > 0) c->vel_max[0] = m;
+    return;
+  }
   for (int size = 1; size < N; size *= 2) {
     if (size == 1) {
       PFOR for (int i = 0; i < N; i++)
@@ -811,7 +845,7 @@ void orc_sesph_step(orc_ctx *c) {
 PTR(pos, float) PTR(vel, float) PTR(vel_guess, float) PTR(d_vel, float) PTR(omega, float) PTR(d_omega, float)
 PTR(normal, float) PTR(rho, float) PTR(adv_rho, float) PTR(pressure, float) PTR(vel_max, float)
 PTR(cg_Minv, float) PTR(cg_r, float) PTR(cg_dir, float) PTR(cg_Ad, float) PTR(cg_s, float)
-PTR(alpha_coff, float) PTR(kappa, float) PTR(kappa_v, float)
+PTR(alpha_coff, float) PTR(kappa, float) PTR(kappa_v, float) PTR(kbuf, float)
 PTR(gridCount, int) PTR(grid, int) PTR(neighborCount, int) PTR(neighbor, int)
 
 enum { S_deltaT = 0, S_avg_density_err, S_cg_delta, S_cg_delta_old, S_cg_delta_zero, S_viscosity, S_viscosity_b,
@@ -834,19 +868,24 @@ static float *sptr(orc_ctx *c, int id) {
 float orc_get_scalar(orc_ctx *c, int id) { float *p = sptr(c, id); return p ? *p : NAN; }
 void orc_set_scalar(orc_ctx *c, int id, float v) { float *p = sptr(c, id); if (p) *p = v; }
 enum { I_vs_iter = 0, I_dv_iter, I_pr_iter, I_overflow_grid, I_overflow_neighbor, I_table_size, I_bs0, I_bs1, I_bs2,
-       I_tension_fixed, I_mode };
+       I_tension_fixed, I_mode, I_n_reduce };
 int orc_get_int(orc_ctx *c, int id) {
   switch (id) {
     case I_vs_iter: return c->vs_iter; case I_dv_iter: return c->dv_iter; case I_pr_iter: return c->pr_iter;
     case I_overflow_grid: return c->overflow_grid; case I_overflow_neighbor: return c->overflow_neighbor;
     case I_table_size: return c->table_size; case I_bs0: return c->blockSize[0]; case I_bs1: return c->blockSize[1];
-    case I_bs2: return c->blockSize[2]; case I_tension_fixed: return c->tension_fixed; case I_mode: return c->mode;
+    case I_bs2: return c->blockSize[2]; case I_tension_fixed: return c->tension_fixed; case I_mode: return c->mode; case I_n_reduce: return c->n_reduce;
   }
   return -1;
 }
 void orc_set_int(orc_ctx *c, int id, int v) {
   switch (id) {
     case I_vs_iter: c->vs_iter = v; break; case I_dv_iter: c->dv_iter = v; break; case I_pr_iter: c->pr_iter = v; break;
-    case I_tension_fixed: c->tension_fixed = v; break;
+    case I_tension_fixed: c->tension_fixed = v; break; case I_n_reduce: c->n_reduce = v; break;
   }
 }
+
+double orc_get_dAd(orc_ctx *c) { return c->cg_dAd; }
+void orc_set_dAd(orc_ctx *c, double v) { c->cg_dAd = v; }
+double orc_get_dnew(orc_ctx *c) { return c->cg_dnew; }
+void orc_set_dnew(orc_ctx *c, double v) { c->cg_dnew = v; }

@@ -1,0 +1,125 @@
+"""Checker backend for the slab-decomposition choreography (wcsph_amd/slab.py): the same backend protocol
+as HipBackend, computed by the CPU oracle in clean mode on CPU tensors.  TEST INFRASTRUCTURE ONLY."""
+import numpy as np
+import torch
+
+from oracle import Oracle
+from wcsph_amd import _lib
+
+_PH = {
+    "DENSITY_COFF": ["compute_density", "compute_dfsph_coff"], "DRHO_DIV_WARM": ["warmstart_divergence_drho"],
+    "VEL_WARM": ["warmstart_divergence_velloop"], "DRHO_DIV_BEGIN": ["begin_divergence_iter"],
+    "MAKE_K_DIV": ["make_k_div"], "VEL_ITER": ["vel_iter"], "DRHO_DIV_ITER": ["drho_div_iter"],
+    "END_DIV": ["end_divergence_iter"], "WARM_PRESS_SCALE": ["warmstart_pressure_scale"],
+    "WARM_PRESS_VEL": ["warmstart_pressure_vel"], "DRHO_PRESS_BEGIN": ["begin_pressure_iter"],
+    "MAKE_K_PRESS": ["make_k_press"], "DRHO_PRESS_ITER": ["drho_press_iter"], "END_PRESS": ["end_pressure_iter"],
+    "CLEAR": ["clear_nonpressure"], "TENSION_NORMAL": ["tension_normal"], "TENSION_ACCEL": ["tension_accel"],
+    "VISC_GUESS": ["visc_guess"], "VISC_MINV": ["visc_minv"], "VISC_RESIDUAL": ["visc_residual"], "VISC_AD": ["visc_Ad"],
+    "VISC_UPDATE": ["visc_update"], "VISC_DIR": ["visc_dir"], "VISC_END": ["end_viscosity"],
+    "VORTICITY": ["vorticity_accumulate"], "VORTICITY_INT": ["vorticity_integrate"], "UPDATE_VEL": ["update_vel"],
+    "UPDATE_POS": ["update_pos"],
+}
+
+
+class OracleBackend:
+    def __init__(self, capacity, solid_local, bounds, window, particleR=0.025, device=None):
+        self.solid = np.asarray(solid_local, np.float64).astype(np.float32)
+        self.bounds, self.particleR = bounds, particleR
+        self.device = torch.device("cpu")
+        self.o = None
+        self.scal = {"deltaT": 0.001, "cg_delta": 0.0}
+        self.avg_density_err = 0.0
+
+    def load_state(self, n_owned, rows):
+        r = rows.numpy()
+        pos = np.concatenate([r[:, 0:3], self.solid]).astype(np.float32)
+        if self.o is not None:
+            self.avg_density_err = self.o.avg_density_err
+            self.o.close()
+        o = Oracle(pos, len(r), self.particleR, mode="clean", maxNeighbour=640, bounds=(self.bounds[1], self.bounds[0]))
+        o.vel[:] = r[:, 3:6]; o.omega[:] = r[:, 6:9]; o.vel_guess[:] = r[:, 9:12]
+        o.kappa[:] = r[:, 12]; o.kappa_v[:] = r[:, 13]
+        o.n_reduce = int(n_owned)
+        o.deltaT = self.scal["deltaT"]
+        o.avg_density_err = self.avg_density_err
+        self.o, self.n_owned = o, int(n_owned)
+
+    def store_state(self):
+        o, n = self.o, self.n_owned
+        r = np.concatenate([o.pos[:n], o.vel[:n], o.omega[:n], o.vel_guess[:n], o.kappa[:n, None], o.kappa_v[:n, None]], 1)
+        return torch.from_numpy(np.ascontiguousarray(r, np.float32))
+
+    def grid_update(self):
+        self.o.update_grid()
+        assert self.o.overflow_neighbor == 0 and self.o.overflow_grid == 0
+
+    def phase(self, name):
+        for f in _PH[name]:
+            getattr(self.o, f)()
+
+    def cfl_local_max(self):
+        self.o.cfl_reduce()
+        return float(self.o.vel_max[0])
+
+    def get_acc(self, slot):
+        o = self.o
+        return {_lib.ACC_ERR: o.avg_density_err, _lib.ACC_DAD: o.get_dAd(), _lib.ACC_DNEW: o.get_dnew(),
+                _lib.ACC_DZERO: o.cg_delta_zero}[slot]
+
+    def set_acc(self, slot, v):
+        if slot == _lib.ACC_DAD:
+            self.o.set_dAd(v)
+        elif slot == _lib.ACC_DNEW:
+            self.o.set_dnew(v)
+
+    def set_scalar(self, name, v):
+        self.scal[name] = float(v)
+        setattr(self.o, name, float(v))
+
+    def gather_rows(self, field, idx):
+        full = getattr(self.o, field)
+        w = 1 if full.ndim == 1 else full.shape[1]
+        a = full[idx.numpy().astype(np.int64)]
+        return torch.from_numpy(np.ascontiguousarray(a.reshape(len(a), w), np.float32))
+
+    def scatter_rows(self, field, idx, rows):
+        a = getattr(self.o, field)
+        if idx.numel():
+            a[idx.numpy().astype(np.int64)] = rows.numpy().reshape((-1,) + a.shape[1:])
+
+    def sync(self):
+        pass
+
+    def close(self):
+        if self.o is not None:
+            self.o.close()
+
+
+def test_scene(n=8, vx=0.0, jitter=0.2, seed=3):
+    from wcsph_amd import scene
+    liquid, solid = scene.dam_break_dfsph(n)
+    rng = np.random.default_rng(seed)
+    liquid = liquid + rng.uniform(-jitter, jitter, liquid.shape) * scene.PARTICLE_RADIUS
+    L = n * 0.05
+    bounds = (np.array([-L, 0.0, -L], np.float32), np.array([L, 2 * L, L], np.float32))
+    return liquid, solid, bounds
+
+
+def split_scene(liquid, bounds, world, particleR=0.025):
+    """cuts + per-rank liquid subsets, as bench / a driver would prepare them"""
+    from wcsph_amd.slab import balanced_cuts
+    inv = np.float32(1.0 / (2 * particleR))
+    cx = np.trunc((liquid[:, 0].astype(np.float32) - bounds[0][0]) * inv).astype(np.int64)
+    nx = int(float(bounds[1][0] - bounds[0][0]) / (2 * particleR) + 1.0)
+    cuts = balanced_cuts(np.bincount(cx, minlength=nx), world)
+    parts = [liquid[(cx >= cuts[r]) & (cx < cuts[r + 1])] for r in range(world)]
+    return cuts, parts
+
+
+def match_rows(a, b):
+    """max position / velocity mismatch between two row sets after nearest-position matching"""
+    from scipy.spatial import cKDTree
+    assert len(a) == len(b)
+    d, j = cKDTree(b[:, :3]).query(a[:, :3])
+    assert len(np.unique(j)) == len(a), "particles do not match one-to-one"
+    return float(d.max()), float(np.abs(a[:, 3:6] - b[j, 3:6]).max()), j

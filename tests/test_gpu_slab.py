@@ -1,0 +1,83 @@
+"""GPU: the slab path with the real HIP backend.  (a) one rank, phase-by-phase, against the checker backend;
+(b) two gloo ranks SHARING the one GPU of the test box (halo buffers staged through the host) against one rank."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+pytestmark = pytest.mark.gpu
+STEPS, VX = 6, 4.0
+
+
+def _hip_run(rank, world, port, outdir, n):
+    import slab_util
+    from wcsph_amd.slab import SlabSim, HipBackend
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    liquid, solid, bounds = slab_util.test_scene(n)
+    cuts, parts = slab_util.split_scene(liquid, bounds, world)
+    sim = SlabSim(lambda **kw: HipBackend(**kw), parts[rank], solid, bounds, cuts, len(liquid), rank, world,
+                  device=dev, comm_device=torch.device("cpu"))
+    sim.rows[:, 3] = VX
+    torch.cuda.synchronize()
+    log = []
+    for _ in range(STEPS):
+        sim.step()
+        log.append((sim.vs_iter, sim.dv_iter, sim.pr_iter, float(sim.dt), sim.n_owned))
+    torch.cuda.synchronize()
+    np.save(os.path.join(outdir, "hrows_w%d_r%d.npy" % (world, rank)), sim.rows.cpu().numpy())
+    np.save(os.path.join(outdir, "hlog_w%d_r%d.npy" % (world, rank)), np.array(log))
+    sim.B.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_hip_slab_one_rank_matches_checker(tmp_path):
+    import slab_util
+    from wcsph_amd.slab import SlabSim
+    n = 8
+    _hip_run(0, 1, 0, str(tmp_path), n)
+    liquid, solid, bounds = slab_util.test_scene(n)
+    ref = SlabSim(lambda **kw: slab_util.OracleBackend(**kw), liquid, solid, bounds, [0, 10 ** 6], len(liquid), 0, 1)
+    ref.rows[:, 3] = VX
+    rlog = []
+    for _ in range(STEPS):
+        ref.step()
+        rlog.append((ref.vs_iter, ref.dv_iter, ref.pr_iter, float(ref.dt), ref.n_owned))
+    got = np.load(os.path.join(str(tmp_path), "hrows_w1_r0.npy"))
+    exp = ref.rows.numpy()
+    assert np.abs(got[:, :3] - exp[:, :3]).max() < 5e-6
+    assert np.abs(got[:, 3:6] - exp[:, 3:6]).max() < 1e-3
+    glog = np.load(os.path.join(str(tmp_path), "hlog_w1_r0.npy"))
+    np.testing.assert_array_equal(glog[:, :3], np.array(rlog)[:, :3])
+    np.testing.assert_allclose(glog[:, 3], np.array(rlog)[:, 3], rtol=1e-6)
+
+
+def test_hip_slab_two_ranks_match_one_rank(tmp_path):
+    import slab_util
+    from test_slab_gloo import _free_port
+    n, out = 8, str(tmp_path)
+    _hip_run(0, 1, 0, out, n)
+    mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+    one = np.load(os.path.join(out, "hrows_w1_r0.npy"))
+    two = np.concatenate([np.load(os.path.join(out, "hrows_w2_r%d.npy" % r)) for r in range(2)])
+    assert len(one) == len(two) == n ** 3
+    dpos, dvel, _ = slab_util.match_rows(one, two)
+    assert dpos < 5e-6 and dvel < 1e-3
+    l1 = np.load(os.path.join(out, "hlog_w1_r0.npy"))
+    l2 = [np.load(os.path.join(out, "hlog_w2_r%d.npy" % r)) for r in range(2)]
+    np.testing.assert_array_equal(l1[:, :3], l2[0][:, :3])
+    np.testing.assert_array_equal(l2[0][:, :3], l2[1][:, :3])
+    assert (l2[0][:, 4] + l2[1][:, 4] == n ** 3).all()
+    assert l2[0][0, 4] != l2[0][-1, 4]

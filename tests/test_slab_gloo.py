@@ -1,0 +1,98 @@
+"""N > 1 path on CPU: two gloo ranks run wcsph_amd.slab.SlabSim (partition, migration, ghost rebuild,
+halo refreshes between phases, scalar all-reduces) with the checker backend and must reproduce the
+single-rank run of the same scene; the single-rank SlabSim must in turn reproduce oracle.dfsph_step()."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+STEPS = 6
+VX = 4.0   # initial x velocity: particles cross the cut within a few steps => exercises migration
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, outdir, n):
+    import slab_util
+    from wcsph_amd.slab import SlabSim
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    liquid, solid, bounds = slab_util.test_scene(n)
+    cuts, parts = slab_util.split_scene(liquid, bounds, world)
+    sim = SlabSim(lambda **kw: slab_util.OracleBackend(**kw), parts[rank], solid, bounds, cuts, len(liquid), rank, world)
+    sim.rows[:, 3] = VX
+    log = []
+    for _ in range(STEPS):
+        sim.step()
+        log.append((sim.vs_iter, sim.dv_iter, sim.pr_iter, float(sim.dt), sim.n_owned))
+    np.save(os.path.join(outdir, "rows_w%d_r%d.npy" % (world, rank)), sim.rows.numpy())
+    np.save(os.path.join(outdir, "log_w%d_r%d.npy" % (world, rank)), np.array(log))
+    sim.B.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_one_rank(tmp_path):
+    import slab_util
+    n = 8
+    out = str(tmp_path)
+    _run(0, 1, 0, out, n)
+    mp.spawn(_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+    one = np.load(os.path.join(out, "rows_w1_r0.npy"))
+    two = np.concatenate([np.load(os.path.join(out, "rows_w2_r%d.npy" % r)) for r in range(2)])
+    assert len(one) == len(two) == n ** 3
+    dpos, dvel, _ = slab_util.match_rows(one, two)
+    assert dpos < 2e-6 and dvel < 2e-4
+    l1 = np.load(os.path.join(out, "log_w1_r0.npy"))
+    l2 = [np.load(os.path.join(out, "log_w2_r%d.npy" % r)) for r in range(2)]
+    np.testing.assert_array_equal(l1[:, :3], l2[0][:, :3])          # same iteration counts on every rank
+    np.testing.assert_array_equal(l2[0][:, :3], l2[1][:, :3])
+    np.testing.assert_allclose(l1[:, 3], l2[0][:, 3], rtol=1e-6)    # same dt
+    assert (l2[0][:, 4] + l2[1][:, 4] == n ** 3).all()              # nobody lost or duplicated
+    assert l2[0][0, 4] != l2[0][-1, 4]                              # and ownership really migrated
+
+
+def test_single_rank_slab_equals_plain_oracle_step(tmp_path):
+    """world = 1: the phase-by-phase choreography is the reference main-loop body."""
+    import slab_util
+    from oracle import Oracle
+    from wcsph_amd.slab import SlabSim
+    liquid, solid, bounds = slab_util.test_scene(7)
+    sim = SlabSim(lambda **kw: slab_util.OracleBackend(**kw), liquid, solid, bounds, [0, 10 ** 6], len(liquid), 0, 1)
+    o = Oracle(np.concatenate([liquid, solid]), len(liquid), 0.025, mode="clean", maxNeighbour=640,
+               bounds=(bounds[1], bounds[0]))
+    o.reset_param()
+    for _ in range(3):
+        sim.step(); o.dfsph_step()
+        assert (sim.vs_iter, sim.dv_iter, sim.pr_iter) == (o.vs_iter, o.dv_iter, o.pr_iter)
+        assert float(sim.dt) == pytest.approx(o.deltaT, rel=1e-6)
+        r = sim.rows.numpy()
+        assert np.abs(r[:, :3] - o.pos[:len(liquid)]).max() < 1e-6
+        assert np.abs(r[:, 3:6] - o.vel).max() < 1e-4
+    sim.B.close()
+
+
+def test_balanced_cuts():
+    from wcsph_amd.slab import balanced_cuts
+    hist = np.array([0, 0, 5, 5, 5, 5, 5, 5, 5, 5, 0, 0])
+    assert balanced_cuts(hist, 2) == [0, 6, 12]
+    assert balanced_cuts(hist, 4) == [0, 4, 6, 8, 12]
+    c = balanced_cuts(np.array([100, 0, 0, 0, 0, 0]), 3)
+    assert c[0] == 0 and c[-1] == 6 and all(b - a >= 2 for a, b in zip(c[:-1], c[1:-1]))

@@ -34,7 +34,7 @@ class Params(C.Structure):
 
 # enum wcsph_field
 FIELDS = ["pos", "vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s",
-          "rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "cg_Minv", "neighborCount"]
+          "rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "cg_Minv", "neighborCount", "kbuf"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 # enum wcsph_scalar
 SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
@@ -58,8 +58,16 @@ CTX_ONLY = [
 OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_count", "wcsph_setup",
          "wcsph_get_block_size", "wcsph_field_to_host", "wcsph_field_from_host", "wcsph_get_scalar",
          "wcsph_set_scalar", "wcsph_get_iters", "wcsph_set_iters", "wcsph_neighbors_to_host", "wcsph_time_kernel",
-         "wcsph_field_gather_rows", "wcsph_field_scatter_rows", "wcsph_set_owned"]
+         "wcsph_field_gather_rows", "wcsph_field_scatter_rows", "wcsph_set_owned", "wcsph_set_cell_window",
+         "wcsph_load_state", "wcsph_store_state", "wcsph_get_acc", "wcsph_set_acc", "wcsph_phase"]
 ALL_SYMBOLS = CTX_ONLY + OTHER
+
+PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
+          "WARM_PRESS_SCALE", "WARM_PRESS_VEL", "DRHO_PRESS_BEGIN", "MAKE_K_PRESS", "DRHO_PRESS_ITER", "END_PRESS", "CLEAR",
+          "TENSION_NORMAL", "TENSION_ACCEL", "VISC_GUESS", "VISC_MINV", "VISC_RESIDUAL", "VISC_AD", "VISC_UPDATE", "VISC_DIR",
+          "VISC_END", "VORTICITY", "VORTICITY_INT", "UPDATE_VEL", "UPDATE_POS"]
+PHASE_ID = {n: i for i, n in enumerate(PHASES)}
+ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = 0, 1, 2, 3
 
 _lib = None
 
@@ -93,6 +101,12 @@ def load():
     lib.wcsph_field_gather_rows.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
     lib.wcsph_field_scatter_rows.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
     lib.wcsph_set_owned.argtypes = [vp, C.c_int32]
+    lib.wcsph_set_cell_window.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.wcsph_load_state.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.wcsph_store_state.argtypes = [vp, vp]
+    lib.wcsph_get_acc.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    lib.wcsph_set_acc.argtypes = [vp, C.c_int, C.c_double]
+    lib.wcsph_phase.argtypes = [vp, C.c_int]
     for name in CTX_ONLY:
         getattr(lib, name).argtypes = [vp]
     for name in ALL_SYMBOLS:

@@ -18,6 +18,7 @@ struct Dev {
   // counts
   int nl, ns, n_owned;
   int nx, ny, nz, ncell;
+  int x0;          // first global cell column of this context's window (slab decomposition); 0 otherwise
   int table_size;  // reference hash table size (HashGrid.py:114)
   int faithful;
   int cfl_prefix;  // Q5: CFL max covers original indices [0, cfl_prefix)

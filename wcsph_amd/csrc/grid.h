@@ -17,7 +17,7 @@ __device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin) {
   float fy = __fmul_rn(__fsub_rn(p.y, d.miny), d.inv_grid);
   float fz = __fmul_rn(__fsub_rn(p.z, d.minz), d.inv_grid);
   bool fin = (fabsf(fx) < 1e9f) && (fabsf(fy) < 1e9f) && (fabsf(fz) < 1e9f);  // NaN/inf => outside
-  int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+  int cx = (int)fx - d.x0, cy = (int)fy, cz = (int)fz;  // truncation toward zero BEFORE the window shift (Q4)
   bool in = fin && (unsigned)cx < (unsigned)d.nx && (unsigned)cy < (unsigned)d.ny && (unsigned)cz < (unsigned)d.nz;
   *lin = in ? (cx * d.ny + cy) * d.nz + cz : d.ncell;
   return in ? (cx | (cy << 10) | (cz << 20)) : -1;
@@ -32,7 +32,7 @@ __global__ void k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw
   int w = cell_packed(d, xyz(p), &lin);
   pw[i] = w;
   slot[i] = atomicAdd(&cnt[lin], 1);
-  if (bcount && w >= 0) atomicAdd(&bcount[ref_hash(w & 1023, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+  if (bcount && w >= 0) atomicAdd(&bcount[ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
 }
 
 __device__ __forceinline__ int lin_of(const Dev &d, int w) {
@@ -164,7 +164,7 @@ __device__ __forceinline__ void alias_hashes(const Dev &d, int c, int (*hs)[ALIA
   for (int k = 0; k < 125; k++) {
     int x = cx + k / 25 - 2, y = cy + (k / 5) % 5 - 2, z = cz + k % 5 - 2;
     bool in = (unsigned)x < (unsigned)d.nx && (unsigned)y < (unsigned)d.ny && (unsigned)z < (unsigned)d.nz;
-    hs[k][t] = in ? ref_hash(x, y, z, d.table_size) : (-1 - k);
+    hs[k][t] = in ? ref_hash(x + d.x0, y, z, d.table_size) : (-1 - k);
   }
 }
 __global__ void __launch_bounds__(ALIAS_TB) k_alias_detect(Dev d, int *cell_info, int *n_alias) {
@@ -208,7 +208,7 @@ __global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.ncell) return;
   int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
-  int v = bcount[ref_hash(cx, cy, cz, d.table_size)];
+  int v = bcount[ref_hash(cx + d.x0, cy, cz, d.table_size)];
   if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);  // ref: HashGrid.py:72-74 cannot be reproduced
   cellval[c] = v;
 }
@@ -285,6 +285,32 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d) {
   if (cl > cap || cs > cap) { atomicOr(&d.flags[FLAG_ERR], ERRBIT_LISTCAP); cl = min(cl, cap); cs = min(cs, cap); }
   d.ncl[i] = cl;
   d.ncs[i] = cs;
+}
+
+// ---- slab decomposition: whole-state load / store in original (row) order -----------------------
+#define STATE_W 14
+__global__ void k_load_state(Dev d, const float *rows, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *r = rows + (size_t)i * STATE_W;
+  d.pos[i] = make_float4(r[0], r[1], r[2], __int_as_float(-1));
+  d.vel[i] = make_float4(r[3], r[4], r[5], 0);
+  d.omega[i] = make_float4(r[6], r[7], r[8], 0);
+  d.vel_guess[i] = make_float4(r[9], r[10], r[11], 0);
+  d.kappa[i] = r[12];
+  d.kappa_v[i] = r[13];
+  d.oid[i] = i;
+  d.where[i] = i;
+}
+__global__ void k_store_state(Dev d, float *rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  int o = d.oid[i];
+  if (o >= d.n_owned) return;
+  float *r = rows + (size_t)o * STATE_W;
+  float4 p = d.pos[i], v = d.vel[i], w = d.omega[i], g = d.vel_guess[i];
+  r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = v.x; r[4] = v.y; r[5] = v.z; r[6] = w.x; r[7] = w.y; r[8] = w.z;
+  r[9] = g.x; r[10] = g.y; r[11] = g.z; r[12] = d.kappa[i]; r[13] = d.kappa_v[i];
 }
 
 // ---- original-order <-> sorted-order field transfer ---------------------------------------

@@ -39,6 +39,8 @@ struct wcsph_ctx {
   float avg_density_err = 0.0f, cg_delta = 0.0f, cg_delta_old = 0.0f, cg_delta_zero = 0.0f, vel_max0 = 0.0f;
   int vs_iter = 0, dv_iter = 0, pr_iter = 0;
   int bs[3] = {0, 0, 0};
+  int win_x0 = 0, win_x1 = -1;  // cell-x window (slab decomposition); x1 < 0 => whole box
+  int capacity = 0;
   double grid_r = 0.0;
   std::vector<void *> allocs;
 
@@ -123,6 +125,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   Dev &d = ctx->d;
   memset(&d, 0, sizeof d);
   d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
+  ctx->capacity = p->n_liquid;
   d.faithful = (p->neighbor_mode == WCSPH_MODE_FAITHFUL);
   d.table_size = p->hash_table_size > 0 ? p->hash_table_size : (p->n_liquid + p->n_solid);
   if (d.table_size < 1) d.table_size = 1;
@@ -144,7 +147,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   d.ss_VL0 = p->ss_VL0; d.ss_VS0 = p->ss_VS0; d.ss_mass = p->ss_mass; d.ss_rho0 = p->ss_rho0; d.ss_stiff = p->ss_stiff;
   d.ss_dim = p->ss_dim; d.ss_visc = p->ss_visc; d.ss_visc_b = p->ss_visc_b;
   // Q5: the reference CFL tree covers original indices [0, 2^floor(log2(N-1))); clean mode takes the true max
-  d.cfl_prefix = d.nl;
+  d.cfl_prefix = 0x7fffffff;
   if (d.faithful && d.nl > 1) { int s = 1; while (s * 2 < d.nl) s *= 2; d.cfl_prefix = s; }
   const size_t nl = (size_t)d.nl;
   DALLOC(d.pos, nl); DALLOC(d.vel, nl); DALLOC(d.vel_guess, nl); DALLOC(d.omega, nl);
@@ -216,8 +219,15 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
     if (ctx->bs[a] < 1 || ctx->bs[a] > 1024) return ctx->fail(WCSPH_EARG, "grid blockSize must be in [1,1024] per axis");
     ncell *= ctx->bs[a];
   }
+  d.nx = ctx->bs[0]; d.ny = ctx->bs[1]; d.nz = ctx->bs[2]; d.x0 = 0;
+  if (ctx->win_x1 >= 0) {  // slab: only columns [x0, x1) of the global grid live in this context
+    int x0 = ctx->win_x0 < 0 ? 0 : ctx->win_x0, x1 = ctx->win_x1 > ctx->bs[0] ? ctx->bs[0] : ctx->win_x1;
+    if (x1 <= x0) return ctx->fail(WCSPH_EARG, "empty cell window");
+    d.x0 = x0; d.nx = x1 - x0;
+    ncell = (long)d.nx * d.ny * d.nz;
+  }
   if (ncell > 0x7fff0000L) return ctx->fail(WCSPH_EARG, "grid has too many cells");
-  d.nx = ctx->bs[0]; d.ny = ctx->bs[1]; d.nz = ctx->bs[2]; d.ncell = (int)ncell;
+  d.ncell = (int)ncell;
   d.minx = minb[0]; d.miny = minb[1]; d.minz = minb[2];
   const int nscan = d.ncell + 2;
   ctx->scan_blocks = (nscan + SCAN_TILE - 1) / SCAN_TILE;
@@ -354,6 +364,7 @@ static FieldDesc field_desc(wcsph_ctx *ctx, int f) {
     case WCSPH_F_KAPPA_V: return {1, d.kappa_v};
     case WCSPH_F_CG_MINV: return {9, nullptr};
     case WCSPH_F_NEIGHBOR_COUNT: return {-1, d.ncount};
+    case WCSPH_F_KBUF: return {1, d.kbuf};
   }
   return {0, nullptr};
 }
@@ -786,6 +797,85 @@ int wcsph_neighbors_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, 
   hipError_t e3 = hipStreamSynchronize(ctx->stream);
   hipFree(dc); hipFree(dl);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ctx->fail(WCSPH_EHIP, "neighbors_to_host copy");
+  return WCSPH_OK;
+}
+
+// ---- slab decomposition -----------------------------------------------------------------------------
+int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1) {
+  if (!ctx || x1 <= x0) return WCSPH_EARG;
+  if (ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_set_cell_window() must precede wcsph_setup()");
+  ctx->win_x0 = x0; ctx->win_x1 = x1;
+  return WCSPH_OK;
+}
+int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows) {
+  NEED_SETUP();
+  if (n_owned < 0 || n_total < n_owned || n_total > ctx->capacity) return ctx->fail(WCSPH_EARG, "load_state: counts exceed the context capacity");
+  ctx->d.nl = n_total; ctx->d.n_owned = n_owned;
+  if (n_total > 0) {
+    if (!d_rows) return WCSPH_EARG;
+    hipLaunchKernelGGL(k_load_state, dim3(nblk(n_total)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows, n_total);
+    LAUNCHCHK();
+  }
+  ctx->grid_valid = false;
+  return WCSPH_OK;
+}
+int wcsph_store_state(wcsph_ctx *ctx, float *d_rows) {
+  NEED_SETUP();
+  if (ctx->d.nl > 0) {
+    if (!d_rows) return WCSPH_EARG;
+    hipLaunchKernelGGL(k_store_state, dim3(nblk(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows);
+    LAUNCHCHK();
+  }
+  return WCSPH_OK;
+}
+int wcsph_get_acc(wcsph_ctx *ctx, int slot, double *v) {
+  if (!ctx || slot < 0 || slot >= 8 || !v) return WCSPH_EARG;
+  int rc = pull_scalars(ctx);
+  if (rc) return rc;
+  *v = ctx->h_acc[slot];
+  return WCSPH_OK;
+}
+int wcsph_set_acc(wcsph_ctx *ctx, int slot, double v) {
+  if (!ctx || slot < 0 || slot >= 8) return WCSPH_EARG;
+  HIPCHK(hipMemcpyAsync(ctx->d.acc + slot, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // v lives on the caller's stack
+  return WCSPH_OK;
+}
+int wcsph_phase(wcsph_ctx *ctx, int ph) {
+  NEED_GRID();
+  int rc = 0;
+  const float dt = ctx->dt;
+  switch (ph) {
+    case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); break;
+    case WCSPH_PH_DRHO_DIV_WARM: PASS(k_drho_div<DRHO_WARM>, dt); break;
+    case WCSPH_PH_VEL_WARM: PASS(k_vel_from_k<1>, (const float *)ctx->d.kappa_v, dt); break;
+    case WCSPH_PH_DRHO_DIV_BEGIN: PASS(k_drho_div<DRHO_BEGIN>, dt); break;
+    case WCSPH_PH_MAKE_K_DIV: ELEM(k_make_k, ctx->d.kappa_v, 0.0f); break;
+    case WCSPH_PH_VEL_ITER: PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, dt); break;
+    case WCSPH_PH_DRHO_DIV_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; PASS(k_drho_div<DRHO_ITER>, dt); break;
+    case WCSPH_PH_END_DIV: ELEM(k_end_div, dt); break;
+    case WCSPH_PH_WARM_PRESS_SCALE: ELEM(k_warm_press_scale, dt); break;
+    case WCSPH_PH_WARM_PRESS_VEL: PASS(k_warm_press_vel, dt); break;
+    case WCSPH_PH_DRHO_PRESS_BEGIN: PASS(k_drho_press<DRHO_BEGIN>, dt); break;
+    case WCSPH_PH_MAKE_K_PRESS: ELEM(k_make_k, ctx->d.kappa, 1.0f); break;
+    case WCSPH_PH_DRHO_PRESS_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; PASS(k_drho_press<DRHO_ITER>, dt); break;
+    case WCSPH_PH_END_PRESS: ELEM(k_end_press, dt); break;
+    case WCSPH_PH_CLEAR: ELEM(k_clear_nonpressure); break;
+    case WCSPH_PH_TENSION_NORMAL: PASS(k_tension_normal); break;
+    case WCSPH_PH_TENSION_ACCEL: PASS(k_tension_accel); break;
+    case WCSPH_PH_VISC_GUESS: ELEM(k_visc_guess); break;
+    case WCSPH_PH_VISC_MINV: PASS(k_visc_minv, dt); break;
+    case WCSPH_PH_VISC_RESIDUAL: if ((rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_residual, dt); break;
+    case WCSPH_PH_VISC_AD: if ((rc = zero_acc(ctx, ACC_DAD))) return rc; PASS(k_visc_Ad, dt); break;
+    case WCSPH_PH_VISC_UPDATE: if ((rc = zero_acc(ctx, ACC_DNEW))) return rc; ELEM(k_visc_update, ctx->cg_delta); break;
+    case WCSPH_PH_VISC_DIR: ELEM(k_visc_dir, ctx->cg_delta); break;
+    case WCSPH_PH_VISC_END: ELEM(k_visc_end, dt); break;
+    case WCSPH_PH_VORTICITY: PASS(k_vorticity, dt); break;
+    case WCSPH_PH_VORTICITY_INT: ELEM(k_vorticity_integrate, dt); break;
+    case WCSPH_PH_UPDATE_VEL: ELEM(k_update_vel, dt); break;
+    case WCSPH_PH_UPDATE_POS: ELEM(k_update_pos, dt); break;
+    default: return ctx->fail(WCSPH_EARG, "unknown phase id");
+  }
   return WCSPH_OK;
 }
 

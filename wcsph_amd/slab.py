@@ -1,0 +1,465 @@
+"""1-D slab decomposition of the DFSPH step across the GPUs of one node.
+
+The reference is single-device; this module is new work with no reference counterpart.  One process per
+GPU (torch.distributed; backend "nccl" == RCCL over xGMI on ROCm, "gloo" in the CPU tests).  The fluid
+domain is cut along x on hash-cell boundaries; rank r owns the liquid particles whose cell column lies in
+[cut[r], cut[r+1]) and holds GHOST copies of the neighbours' particles within two cell columns (= the
+kernel support h) of each cut, plus the static boundary particles of its columns +- 2.
+
+Per step (the reference main-loop body, dfsph.py:606-617, with the exchanges it needs once the neighbour
+loops read particles another rank owns):
+  migrate owners that crossed a cut -> rebuild ghosts -> grid update -> [phase, halo refresh of the field
+  the NEXT phase reads from neighbours j]* -> scalar all-reduces where the reference reads a global sum / max.
+Every exchange is a pair of point-to-point messages with the two slab neighbours (batch_isend_irecv:
+ncclSend/ncclRecv grouped), 0.1-2 MB each; the only collectives are all-reduces of one double.
+
+The choreography is written against a small backend protocol so that the CPU tests can drive it with a
+checker backend; the product backend is HipBackend (libwcsph_hip.so through the C ABI) and nothing else.
+"""
+import ctypes as C
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, scene
+
+STATE_W = 14  # pos3 vel3 omega3 vel_guess3 kappa kappa_v  (the fields the reference carries across steps)
+GHOST_CELLS = 2  # support h = 2 hash cells (HashGrid.py:18: searchR = 2 * gridR)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class HipBackend:
+    """Compute backend of one rank: a libwcsph_hip.so context with a slab-local cell window."""
+
+    def __init__(self, capacity, solid_local, bounds, window, particleR=0.025, device=None, **attrs):
+        from .ParticleData import ParticleData
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.lib = _lib.load()
+        pd = ParticleData(particleR, neighbor_mode="clean")
+        for k, v in attrs.items():
+            setattr(pd, k, v)
+        # capacity rows of liquid; positions are loaded per step (load_state)
+        pd.liquid_count = pd.count = int(capacity)
+        pd._chunks = [np.zeros((int(capacity), 3))]
+        pd.add_solid_points(solid_local)
+        pd.maxboundarynp[0] = np.asarray(bounds[1], np.float32)
+        pd.minboundarynp[0] = np.asarray(bounds[0], np.float32)
+        pd.setup_data_gpu()
+        self.ctx = pd._need_ctx()
+        _lib.check(self.ctx, self.lib.wcsph_set_cell_window(self.ctx, int(window[0]), int(window[1])))
+        # one HIP stream for everything this rank does: the library's kernels, torch's row shuffling and the
+        # RCCL calls torch.distributed enqueues are ordered by it (SlabSim.step runs under torch.cuda.stream)
+        self.stream = torch.cuda.Stream(self.device)
+        _lib.check(self.ctx, self.lib.wcsph_set_stream(self.ctx, C.c_void_p(self.stream.cuda_stream)))
+        pd.setup_data_cpu()
+        torch.cuda.synchronize(self.device)
+        self.pd = pd
+        self.capacity = int(capacity)
+        self.n_owned = 0
+
+    def _chk(self, rc):
+        _lib.check(self.ctx, rc)
+
+    def load_state(self, n_owned, rows):
+        rows = rows.contiguous()
+        if rows.shape[0] > self.capacity:
+            raise RuntimeError("slab capacity %d exceeded (%d rows)" % (self.capacity, rows.shape[0]))
+        self.n_owned = int(n_owned)
+        self._chk(self.lib.wcsph_load_state(self.ctx, int(n_owned), int(rows.shape[0]), C.c_void_p(rows.data_ptr())))
+        self._keep = rows  # keep alive until the stream has consumed it
+
+    def store_state(self):
+        out = torch.empty((self.n_owned, STATE_W), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.wcsph_store_state(self.ctx, C.c_void_p(out.data_ptr())))
+        return out
+
+    def grid_update(self):
+        self._chk(self.lib.wcsph_grid_update(self.ctx))
+
+    def phase(self, name):
+        self._chk(self.lib.wcsph_phase(self.ctx, _lib.PHASE_ID[name]))
+
+    def cfl_local_max(self):
+        self._chk(self.lib.wcsph_dfsph_cfl_reduce(self.ctx))
+        v = C.c_float()
+        self._chk(self.lib.wcsph_get_scalar(self.ctx, _lib.SCALAR_ID["vel_max0"], C.byref(v)))
+        return float(v.value)
+
+    def get_acc(self, slot):
+        v = C.c_double()
+        self._chk(self.lib.wcsph_get_acc(self.ctx, slot, C.byref(v)))
+        return v.value
+
+    def set_acc(self, slot, v):
+        self._chk(self.lib.wcsph_set_acc(self.ctx, slot, float(v)))
+
+    def set_scalar(self, name, v):
+        self._chk(self.lib.wcsph_set_scalar(self.ctx, _lib.SCALAR_ID[name], float(v)))
+
+    def gather_rows(self, field, idx):
+        w = 3 if field in ("vel", "vel_guess", "cg_dir", "omega", "normal") else 1
+        out = torch.empty((idx.numel(), w), dtype=torch.float32, device=self.device)
+        if idx.numel():
+            self._chk(self.lib.wcsph_field_gather_rows(self.ctx, _lib.FIELD_ID[field], C.c_void_p(idx.data_ptr()),
+                                                       idx.numel(), C.c_void_p(out.data_ptr())))
+        return out
+
+    def scatter_rows(self, field, idx, rows):
+        if idx.numel():
+            rows = rows.contiguous()
+            self._chk(self.lib.wcsph_field_scatter_rows(self.ctx, _lib.FIELD_ID[field], C.c_void_p(idx.data_ptr()),
+                                                        idx.numel(), C.c_void_p(rows.data_ptr())))
+            self._keep2 = rows
+
+    def sync(self):
+        self._chk(self.lib.wcsph_sync(self.ctx))
+
+    def close(self):
+        self.pd.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def balanced_cuts(cellx_hist, world):
+    """Cell-column cuts [world+1] giving ~equal particle counts per slab; cut[0] = 0, cut[-1] = nx."""
+    nx = len(cellx_hist)
+    cum = np.concatenate([[0], np.cumsum(cellx_hist)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(cum, total * r / world, side="left"))
+        c = max(c, cuts[-1] + GHOST_CELLS)   # a slab is at least one ghost layer wide
+        cuts.append(min(c, nx))
+    cuts.append(nx)
+    return cuts
+
+
+class SlabSim:
+    """The DFSPH step of dfsph.py:606-617 on one slab, with halo exchanges between phases."""
+
+    def __init__(self, backend_factory, liquid_local, solid_all, bounds, cuts, n_global, rank, world,
+                 particleR=0.025, device=None, capacity_factor=1.6, group=None, comm_device=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.device = device if device is not None else torch.device("cpu")
+        # tensors handed to torch.distributed live here: the compute device for nccl (RCCL moves them over
+        # xGMI directly), the host for gloo (tests: two ranks sharing one GPU, or CPU-only checker runs)
+        self.comm_device = comm_device if comm_device is not None else self.device
+        self.minb = np.asarray(bounds[0], np.float32)
+        self.maxb = np.asarray(bounds[1], np.float32)
+        self.particleR = particleR
+        grid_r = particleR * 2.0
+        self.inv_grid = np.float32(1.0 / grid_r)
+        self.nx = int(float(self.maxb[0] - self.minb[0]) / grid_r + 1.0)   # HashGrid.py:46-48
+        self.cuts = list(cuts)
+        self.lo, self.hi = self.cuts[rank], self.cuts[rank + 1]
+        self.n_global = int(n_global)
+        # static boundary particles of the cell window
+        w0, w1 = max(self.lo - GHOST_CELLS, 0), min(self.hi + GHOST_CELLS, self.nx)
+        self.window = (w0, w1)
+        scx = self._cellx_np(np.asarray(solid_all, np.float64).astype(np.float32)[:, 0])
+        solid_local = np.asarray(solid_all)[(scx >= w0) & (scx < w1)]
+        n_local = len(liquid_local)
+        capacity = int(max(n_local, n_global // world) * capacity_factor) + 4096
+        self.B = backend_factory(capacity=capacity, solid_local=solid_local, bounds=(self.minb, self.maxb),
+                                 window=self.window, particleR=particleR, device=self.device)
+        rows = np.zeros((n_local, STATE_W), np.float32)
+        rows[:, 0:3] = np.asarray(liquid_local, np.float64).astype(np.float32)
+        self.rows = torch.from_numpy(rows).to(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        # reference module globals (dfsph.py:36-41,178)
+        self.dt = np.float32(0.001)
+        self.vs_iter = self.dv_iter = self.pr_iter = 0
+        self.avg_density_err = np.float32(0.0)
+        self.cg_delta = self.cg_delta_zero = np.float32(0.0)
+        self.eps, self.viscosity_err = 1e-5, 0.05
+        self.user_max_t, self.user_min_t = 0.005, 0.0001
+        self.tension = False
+        self.n_exchanges = 0
+
+    # ---- geometry -------------------------------------------------------------------------------------
+    def _cellx_np(self, x):
+        return np.trunc((x.astype(np.float32) - self.minb[0]) * self.inv_grid).astype(np.int64)
+
+    def _cellx(self, rows):
+        # ref: HashGrid.py:68 -- f32 subtract, f32 multiply, truncation toward zero
+        f = (rows[:, 0] - float(self.minb[0])) * float(self.inv_grid)
+        return torch.trunc(f).to(torch.int64)
+
+    # ---- communication ----------------------------------------------------------------------------------
+    def _neighbours(self):
+        return (self.rank - 1 if self.rank > 0 else None, self.rank + 1 if self.rank < self.world - 1 else None)
+
+    def _exchange_var(self, to_left, to_right):
+        """Variable-size row exchange with the two slab neighbours; returns (from_left, from_right)."""
+        left, right = self._neighbours()
+        w = to_left.shape[1]
+        sizes = torch.tensor([to_left.shape[0], to_right.shape[0]], dtype=torch.int64, device=self.comm_device)
+        allsz = [torch.zeros(2, dtype=torch.int64, device=self.comm_device) for _ in range(self.world)]
+        dist.all_gather(allsz, sizes, group=self.group)
+        n_from_left = int(allsz[left][1]) if left is not None else 0
+        n_from_right = int(allsz[right][0]) if right is not None else 0
+        from_left = torch.empty((n_from_left, w), dtype=torch.float32, device=self.device)
+        from_right = torch.empty((n_from_right, w), dtype=torch.float32, device=self.device)
+        self._sendrecv(to_left, to_right, from_left, from_right)
+        return from_left, from_right
+
+    def _sendrecv(self, to_left, to_right, from_left, from_right):
+        left, right = self._neighbours()
+        staged = self.comm_device != self.device
+        if staged:
+            dst_l, dst_r = from_left, from_right
+            to_left, to_right = to_left.to(self.comm_device), to_right.to(self.comm_device)
+            from_left, from_right = torch.empty_like(dst_l, device=self.comm_device), torch.empty_like(dst_r, device=self.comm_device)
+        ops = []
+        if left is not None:
+            if to_left.numel():
+                ops.append(dist.P2POp(dist.isend, to_left.contiguous(), left, group=self.group))
+            if from_left.numel():
+                ops.append(dist.P2POp(dist.irecv, from_left, left, group=self.group))
+        if right is not None:
+            if to_right.numel():
+                ops.append(dist.P2POp(dist.isend, to_right.contiguous(), right, group=self.group))
+            if from_right.numel():
+                ops.append(dist.P2POp(dist.irecv, from_right, right, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if staged:
+            dst_l.copy_(from_left); dst_r.copy_(from_right)
+        self.n_exchanges += 1
+
+    def xchg(self, field):
+        """Refresh the ghost rows of `field` from their owners (one halo exchange)."""
+        if self.world == 1:
+            return
+        B = self.B
+        bl, br = B.gather_rows(field, self.send_l), B.gather_rows(field, self.send_r)
+        w = bl.shape[1]
+        gl = torch.empty((self.ghost_l.numel(), w), dtype=torch.float32, device=self.device)
+        gr = torch.empty((self.ghost_r.numel(), w), dtype=torch.float32, device=self.device)
+        self._sendrecv(bl, br, gl, gr)
+        B.scatter_rows(field, self.ghost_l, gl)
+        B.scatter_rows(field, self.ghost_r, gr)
+
+    def _allreduce(self, v, op):
+        if self.world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.comm_device)
+        dist.all_reduce(t, op=op, group=self.group)
+        return float(t.item())
+
+    def allsum(self, v): return self._allreduce(v, dist.ReduceOp.SUM)   # noqa: E704
+    def allmax(self, v): return self._allreduce(v, dist.ReduceOp.MAX)   # noqa: E704
+
+    # ---- ownership ----------------------------------------------------------------------------------------
+    def redistribute(self):
+        """Migrate particles that crossed a cut, then rebuild the ghost layers and load the backend."""
+        rows = self.rows
+        i32 = torch.int32
+        if self.world > 1:
+            cx = self._cellx(rows)
+            go_l = (cx < self.lo) if self.rank > 0 else torch.zeros_like(cx, dtype=torch.bool)
+            go_r = (cx >= self.hi) if self.rank < self.world - 1 else torch.zeros_like(cx, dtype=torch.bool)
+            in_l, in_r = self._exchange_var(rows[go_l], rows[go_r])
+            rows = torch.cat([rows[~(go_l | go_r)], in_l, in_r], 0)
+            cx = self._cellx(rows)
+            near_l = (cx < self.lo + GHOST_CELLS) if self.rank > 0 else torch.zeros_like(cx, dtype=torch.bool)
+            near_r = (cx >= self.hi - GHOST_CELLS) if self.rank < self.world - 1 else torch.zeros_like(cx, dtype=torch.bool)
+            self.send_l = torch.nonzero(near_l).flatten().to(i32)
+            self.send_r = torch.nonzero(near_r).flatten().to(i32)
+            gl, gr = self._exchange_var(rows[near_l], rows[near_r])
+            n = rows.shape[0]
+            self.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=self.device)
+            self.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=self.device)
+            allrows = torch.cat([rows, gl, gr], 0)
+        else:
+            n = rows.shape[0]
+            empty = torch.zeros(0, dtype=i32, device=self.device)
+            self.send_l = self.send_r = self.ghost_l = self.ghost_r = empty
+            allrows = rows
+        self.rows = rows
+        self.n_owned = rows.shape[0]
+        self.B.load_state(self.n_owned, allrows)
+
+    # ---- the step -------------------------------------------------------------------------------------------
+    def step(self):
+        stream = getattr(self.B, "stream", None)
+        if stream is None:
+            return self._step()
+        with torch.cuda.stream(stream):
+            return self._step()
+
+    def _step(self):
+        B, ph, x = self.B, self.B.phase, self.xchg
+        ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = _lib.ACC_ERR, _lib.ACC_DAD, _lib.ACC_DNEW, _lib.ACC_DZERO
+        N = float(self.n_global)
+        self.redistribute()
+        B.set_scalar("deltaT", self.dt)
+        B.grid_update()                                   # particle_data.hash_grid.update_grid()
+        ph("DENSITY_COFF"); x("rho")                      # compute_density(); compute_dfsph_coff()
+
+        # solve_vel_divergence()  (dfsph.py:131-146)
+        self.dv_iter = 0
+        ph("DRHO_DIV_WARM"); x("kappa_v")
+        ph("VEL_WARM"); x("vel")
+        err = -0.1
+        ph("DRHO_DIV_BEGIN")
+        dt = float(self.dt)
+        while float(self.avg_density_err) > err and self.dv_iter < 10:
+            ph("MAKE_K_DIV"); x("kbuf")
+            ph("VEL_ITER"); x("vel")
+            ph("DRHO_DIV_ITER")
+            self.avg_density_err = np.float32(self.allsum(B.get_acc(ACC_ERR)))
+            err = 0.001 * N / dt
+            self.dv_iter += 1
+        ph("END_DIV")
+
+        # compute_nonpressure_force()  (dfsph.py:84-103)
+        ph("CLEAR")
+        if self.tension:
+            ph("TENSION_NORMAL"); x("normal"); ph("TENSION_ACCEL")
+        ph("VISC_GUESS"); x("vel_guess")
+        ph("VISC_MINV")
+        ph("VISC_RESIDUAL")
+        self.cg_delta_zero = np.float32(self.allsum(B.get_acc(ACC_DZERO)))
+        self.cg_delta = self.cg_delta_zero
+        x("cg_dir")
+        self.vs_iter = 0
+        while self.vs_iter < 100:
+            B.set_scalar("cg_delta", self.cg_delta)
+            ph("VISC_AD")
+            B.set_acc(ACC_DAD, self.allsum(B.get_acc(ACC_DAD)))
+            ph("VISC_UPDATE")
+            dnew = self.allsum(B.get_acc(ACC_DNEW))
+            B.set_acc(ACC_DNEW, dnew)
+            ph("VISC_DIR"); x("cg_dir")
+            self.cg_delta = np.float32(dnew)
+            self.vs_iter += 1
+            if float(self.cg_delta) <= self.viscosity_err * float(self.cg_delta_zero) or float(self.cg_delta_zero) < self.eps:
+                break
+        ph("VISC_END")
+        ph("VORTICITY"); ph("VORTICITY_INT")
+
+        # optimize_time_step()  (dfsph.py:107-129)
+        vmax = np.float32(self.allmax(B.cfl_local_max()))
+        if vmax > self.eps:
+            time_step = 0.5 * 0.4 * self.particleR * 2.0 / math.sqrt(vmax)
+            time_step = max(min(time_step, self.user_max_t), self.user_min_t)
+            it = max(self.vs_iter, max(self.pr_iter, self.vs_iter))
+            d = self.dt
+            if it > 10:
+                d = np.float32(d * 0.9)
+            elif it < 5:
+                d = np.float32(d * 1.1)
+            self.dt = np.float32(min(d, time_step))
+            B.set_scalar("deltaT", self.dt)
+        ph("UPDATE_VEL"); x("vel")
+
+        # solve_pressure()  (dfsph.py:150-164); the warm start is a no-op in the reference (Q7): its gate
+        # adv_rho > rho_L0 never opens, so kappa_j of ghosts is not refreshed for it
+        ph("WARM_PRESS_SCALE"); ph("WARM_PRESS_VEL")
+        self.pr_iter = 0
+        err = 0.0
+        ph("DRHO_PRESS_BEGIN")
+        while (err > 0.001 or self.pr_iter < 2) and self.pr_iter < 100:
+            ph("MAKE_K_PRESS"); x("kbuf")
+            ph("VEL_ITER"); x("vel")
+            ph("DRHO_PRESS_ITER")
+            self.avg_density_err = np.float32(self.allsum(B.get_acc(ACC_ERR)))
+            err = float(self.avg_density_err) / N
+            self.pr_iter += 1
+        ph("END_PRESS")
+        ph("UPDATE_POS")
+        self.rows = B.store_state()
+        return float(self.dt)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def dam_break_slab(n, rank, world, particleRadius=scene.PARTICLE_RADIUS):
+    """This rank's share of the n^3 dam break (dfsph.py:59-82 recipe) without building the whole scene:
+    returns (liquid_local, solid_all, bounds, cuts, n_global)."""
+    dis = particleRadius * 2.0
+    L = n * dis
+    solid = scene.box_shell(L)
+    minb = np.array([-L, 0.0, -L], np.float32)
+    maxb = np.array([L, 2 * L, L], np.float32)
+    inv = np.float32(1.0 / dis)
+    xs = (np.arange(n) - n / 2).astype(np.float64) * dis + dis * 0.5            # lattice x planes
+    cellx = np.trunc((xs.astype(np.float32) - minb[0]) * inv).astype(np.int64)
+    nx = int(float(maxb[0] - minb[0]) / dis + 1.0)
+    hist = np.bincount(cellx, minlength=nx) * (n * n)
+    cuts = balanced_cuts(hist, world)
+    mine = np.nonzero((cellx >= cuts[rank]) & (cellx < cuts[rank + 1]))[0]
+    j = np.arange(n * n)
+    y = (j // n).astype(np.float64) * dis + 0.2
+    z = (j % n - n / 2).astype(np.float64) * dis + dis * 0.5
+    liquid = np.empty((len(mine) * n * n, 3))
+    for k, ix in enumerate(mine):
+        blk = liquid[k * n * n:(k + 1) * n * n]
+        blk[:, 0] = xs[ix]; blk[:, 1] = y; blk[:, 2] = z
+    return liquid, solid, (minb, maxb), cuts, n ** 3
+
+
+def bench_main(args):
+    """bench.py --gpus N (N > 1): weak scaling, ~2 M liquid particles per GPU (config C4 at N = 8)."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    # WCSPH_BENCH_COMM=gloo: dry run of this path with every rank on ONE GPU (halo buffers staged through the
+    # host); the real thing is RCCL (backend "nccl") with one GPU per rank
+    comm = os.environ.get("WCSPH_BENCH_COMM", "nccl")
+    if comm == "gloo":
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if comm == "gloo":
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    dist.barrier()
+    # weak scaling: n^3 ~ world * 126^3  (C3 per GPU; world = 8 gives the 252^3 of config C4)
+    n_base = scene.CONFIGS.get(args.config) or int(args.config)
+    n = int(round(n_base * world ** (1.0 / 3.0)))
+    liquid, solid, bounds, cuts, n_global = dam_break_slab(n, rank, world)
+    sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, cuts, n_global, rank, world, device=dev,
+                  comm_device=torch.device("cpu") if comm == "gloo" else dev)
+    cdev = sim.comm_device
+    iters = []
+    for _ in range(args.warmup):
+        sim.step()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+        iters.append((sim.vs_iter, sim.dv_iter, sim.pr_iter))
+    dist.barrier(); torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    cnt = torch.tensor([sim.n_owned], dtype=torch.int64, device=cdev)
+    allc = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(allc, cnt)
+    if rank == 0:
+        import json
+        elapsed = float(el.item())
+        it = np.array(iters, dtype=np.float64)
+        out = {
+            "metric": "M particle-steps/sec, DFSPH dam-break", "value": round(n_global * args.steps / elapsed / 1e6, 3),
+            "unit": "M particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DFSPH 3D dam-break %d^3 = %d liquid particles over %d x-slabs (C3 load per GPU; C4 at 8 "
+                                   "GPUs), ghost halos over RCCL send/recv, viscosity PCG + vorticity on" % (n, n_global, world),
+                       "neighbor_mode": "clean", "n_liquid": n_global, "cuts": cuts, "comm": comm,
+                       "owned_per_rank": [int(c.item()) for c in allc],
+                       "halo_exchanges_per_step": round(sim.n_exchanges / float(args.steps + args.warmup), 1),
+                       "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)}},
+        }
+        print(json.dumps(out))
+    sim.B.close()
+    dist.destroy_process_group()
