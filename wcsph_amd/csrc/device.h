@@ -43,12 +43,17 @@ struct Dev {
   float4 *d_vel, *d_omega, *normal, *cg_r, *cg_dir, *cg_Ad, *cg_s;
   float4 *minv0, *minv1, *minv2;          // rows of cg_Minv
   float *rho, *adv_rho, *pressure, *vel_max, *alpha, *kbuf;
+  float4 *pk;                             // per-pass packed gather record (pos.xyz, payload)
   int *ncount;                            // HashGrid.neighborCount (raw list length)
   // compact per-step neighbour lists (k-major: entry k of particle i at [k * nbr_stride + i])
   int *nbr_l, *nbr_s;                     // sorted liquid index / sorted solid index
   int *ncl, *ncs;                         // entries per particle
   int nbr_stride, nbr_cap;
   float list_r2;                          // squared support radius the lists are built with
+  // LDS tiles (tile.h): active-tile list of the step, tile-local 16-bit neighbour lists
+  int ntx, nty, ntz, ntile;
+  int *tile_list, *tile_qoff, *tile_meta; // [ntile] tile ids / first list slot; meta[0] = active tiles
+  uint16_t *nbr16, *cnt16;                // [nbr_cap][nbr_stride] staged indices, [nl] entries
   // solids, cell-sorted once
   float4 *spos;
   // cell tables
@@ -130,13 +135,14 @@ __device__ __forceinline__ void block_accumulate(double *dst, float v) {
 // to every kernel-weighted sum of the reference (compact support) and are skipped here; the raw
 // list LENGTH the reference also uses (Q2/Q10) is d.ncount[i], built by the grid update.
 template <class FL, class FS>
-__device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, FL &&fl, FS &&fs) {
+__device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool liquids, FL &&fl, FS &&fs) {
   const int cw = __float_as_int(pi.w);
   if (cw < 0) return;  // outside the grid box: no neighbours (ref: HashGrid.py:80-81, Q4)
   const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
   const int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
   const float3 xi = xyz(pi);
   const int info = d.cell_info[(cx * d.ny + cy) * d.nz + cz];
+  if (liquids)
 #pragma unroll 1
   for (int dx = -2; dx <= 2; dx++) {
     const int x = cx + dx;
@@ -186,6 +192,7 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, FL &&
       const float m = (float)(e[2 + t] >> 8);
       const int x = cx + k / 25 - 2, y = cy + (k / 5) % 5 - 2, z = cz + k % 5 - 2;
       const int c = (x * d.ny + y) * d.nz + z;
+      if (liquids)
       for (int j = d.cs_l[c]; j < d.cs_l[c + 1]; j++) {
         const float3 r = xi - xyz(d.pos[j]);
         const float r2 = dot3(r, r);
@@ -201,41 +208,62 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, FL &&
 }
 
 // The neighbour loop of every pass: iterate the compact list the grid update built for this step
-// (the in-support subset of the reference's HashGrid.neighbor row, duplicates included, so m == 1).
+// (the in-support subset of the reference's HashGrid.neighbor row, duplicates included).
 // As in the reference the list is frozen until the next update_grid() while r is recomputed from the
 // current positions (ref: dfsph.py:254-256 and every other `while k < cur_neighbor` loop).
-// Two entries are fetched per trip so that their gathers are in flight together.
-template <class FL, class FS>
-__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, FL &&fl, FS &&fs) {
+//
+// Latency structure: entry k of particle i sits in a 16-byte block of four ([k/4][i][k%4]); one trip
+// fetches U entries with U/4 coalesced 16-byte loads, then issues all U position gathers AND all U payload
+// gathers gl(j) (whatever the pass reads from neighbour j: vel_j, k_j, rho_j ...) before any arithmetic, so
+// a trip costs two dependent memory round trips instead of 2 per entry.
+// fl(j, r, r2, payload) / fs(j, r, r2) are called for the liquid / solid entries.
+#define NBR_AT(k, stride, i) ((((size_t)((k) >> 2)) * (stride) + (i)) * 4 + ((k) & 3))
+// P: the float4 array positions are gathered from (d.pos, or a per-pass packed copy whose .w already holds
+// the neighbour payload so that one 16-byte gather per entry suffices); gl(j, p4) builds the payload.
+template <int U, class GL, class FL, class FS>
+__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
+  static_assert(U == 4 || U == 8, "U entries per trip");
   const float3 xi = xyz(pi);
-  const int *nl = d.nbr_l + i;
   const size_t st = (size_t)d.nbr_stride;
   const int cl = d.ncl[i];
-  int k = 0;
-  for (; k + 1 < cl; k += 2) {
-    const int j0 = nl[k * st], j1 = nl[(k + 1) * st];
-    const float4 p0 = d.pos[j0], p1 = d.pos[j1];
-    const float3 r0 = xi - xyz(p0), r1 = xi - xyz(p1);
-    fl(j0, r0, dot3(r0, r0), 1.0f);
-    fl(j1, r1, dot3(r1, r1), 1.0f);
-  }
-  if (k < cl) {
-    const int j0 = nl[k * st];
-    const float3 r0 = xi - xyz(d.pos[j0]);
-    fl(j0, r0, dot3(r0, r0), 1.0f);
+  const int4 *L = reinterpret_cast<const int4 *>(d.nbr_l) + i;
+  for (int k = 0; k < cl; k += U) {
+    int j[U];
+    {
+      const int4 e0 = L[(size_t)(k >> 2) * st];
+      j[0] = e0.x; j[1] = e0.y; j[2] = e0.z; j[3] = e0.w;
+      if (U == 8) {
+        const int4 e1 = (k + 4 < cl) ? L[(size_t)((k >> 2) + 1) * st] : e0;  // tail: re-use valid indices
+        j[4] = e1.x; j[5] = e1.y; j[6] = e1.z; j[7] = e1.w;
+      }
+    }
+    float4 p[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) p[u] = P[j[u]];
+    decltype(gl(0, p[0])) b[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) b[u] = gl(j[u], p[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (k + u < cl) {
+        const float3 r = xi - xyz(p[u]);
+        fl(j[u], r, dot3(r, r), b[u]);
+      }
   }
   const int cs = d.ncs[i];
-  const int *ns = d.nbr_s + i;
-  for (k = 0; k + 1 < cs; k += 2) {
-    const int j0 = ns[k * st], j1 = ns[(k + 1) * st];
-    const float4 p0 = d.spos[j0], p1 = d.spos[j1];
-    const float3 r0 = xi - xyz(p0), r1 = xi - xyz(p1);
-    fs(j0, r0, dot3(r0, r0), 1.0f);
-    fs(j1, r1, dot3(r1, r1), 1.0f);
-  }
-  if (k < cs) {
-    const int j0 = ns[k * st];
-    const float3 r0 = xi - xyz(d.spos[j0]);
-    fs(j0, r0, dot3(r0, r0), 1.0f);
+  const int4 *S = reinterpret_cast<const int4 *>(d.nbr_s) + i;
+  for (int k = 0; k < cs; k += 4) {
+    const int4 e = S[(size_t)(k >> 2) * st];
+    const int j[4] = {e.x, e.y, e.z, e.w};
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) p[u] = d.spos[j[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (k + u < cs) {
+        const float3 r = xi - xyz(p[u]);
+        fs(j[u], r, dot3(r, r));
+      }
   }
 }
+struct NoPayload {};

@@ -15,8 +15,8 @@ __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
   LOAD_I
   if (!own) return;
   float sl = 0.f, ss = 0.f;
-  walk(d, i, pi, [&](int, float3, float r2, float m) { sl += m * cubic_W(d, r2); },
-       [&](int, float3, float r2, float m) { ss += m * cubic_W(d, r2); });
+  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
+          [&](int, float3, float r2) { ss += cubic_W(d, r2); });
   d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
 }
 
@@ -26,13 +26,13 @@ __global__ void __launch_bounds__(BLOCK) k_coff(Dev d) {
   if (!own) return;
   float3 sg = f3(0, 0, 0);
   float sq = 0.f;
-  walk(d, i, pi,
-       [&](int, float3 r, float r2, float m) {
-         float g = cubic_gradW_scale(d, r2) * d.VL0;
-         sq += m * g * g * r2;
-         sg = sg + r * (m * g);
-       },
-       [&](int, float3 r, float r2, float m) { sg = sg + r * (m * cubic_gradW_scale(d, r2) * d.VS0); });
+  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+          [&](int, float3 r, float r2, NoPayload) {
+            float g = cubic_gradW_scale(d, r2) * d.VL0;
+            sq += g * g * r2;
+            sg = sg + r * g;
+          },
+          [&](int, float3 r, float r2) { sg = sg + r * (cubic_gradW_scale(d, r2) * d.VS0); });
   sq += dot3(sg, sg);
   d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
 }
@@ -43,17 +43,17 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
   if (!own) return;
   float sl = 0.f, ss = 0.f, sq = 0.f;
   float3 sg = f3(0, 0, 0);
-  walk(d, i, pi,
-       [&](int, float3 r, float r2, float m) {
-         sl += m * cubic_W(d, r2);
-         float g = cubic_gradW_scale(d, r2) * d.VL0;
-         sq += m * g * g * r2;
-         sg = sg + r * (m * g);
-       },
-       [&](int, float3 r, float r2, float m) {
-         ss += m * cubic_W(d, r2);
-         sg = sg + r * (m * cubic_gradW_scale(d, r2) * d.VS0);
-       });
+  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+          [&](int, float3 r, float r2, NoPayload) {
+            sl += cubic_W(d, r2);
+            float g = cubic_gradW_scale(d, r2) * d.VL0;
+            sq += g * g * r2;
+            sg = sg + r * g;
+          },
+          [&](int, float3 r, float r2) {
+            ss += cubic_W(d, r2);
+            sg = sg + r * (cubic_gradW_scale(d, r2) * d.VS0);
+          });
   d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
   sq += dot3(sg, sg);
   d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
@@ -70,11 +70,9 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div(Dev d, float dt) {
   if (own) {
     if (MODE == DRHO_WARM) d.kappa_v[i] = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
     const float3 vi = xyz(d.vel[i]);
-    walk(d, i, pi,
-         [&](int j, float3 r, float r2, float m) {
-           a += m * d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(d.vel[j]), r);
-         },
-         [&](int, float3 r, float r2, float m) { a += m * d.VS0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.vel[j]; },
+            [&](int, float3 r, float r2, float4 vj) { a += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
+            [&](int, float3 r, float r2) { a += d.VS0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     a = fmaxf(a, 0.0f);
     if (d.ncount[i] < 20) a = 0.0f;  // raw list length, Q2
     d.adv_rho[i] = a;
@@ -91,11 +89,9 @@ __global__ void __launch_bounds__(BLOCK) k_drho_press(Dev d, float dt) {
   if (own) {
     const float3 vi = xyz(d.vel[i]);
     float t = 0.f;
-    walk(d, i, pi,
-         [&](int j, float3 r, float r2, float m) {
-           t += m * d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(d.vel[j]), r);
-         },
-         [&](int, float3 r, float r2, float m) { t += m * d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.vel[j]; },
+            [&](int, float3 r, float r2, float4 vj) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
+            [&](int, float3 r, float r2) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
     d.adv_rho[i] = a;
     e = a - 1.0f;
@@ -111,28 +107,38 @@ __global__ void k_make_k(Dev d, float *kap, float bias) {
   if (i >= d.nl) return;
   float k = (d.adv_rho[i] - bias) * d.alpha[i];
   d.kbuf[i] = k;
+  float4 p = d.pos[i];
+  d.pk[i] = make_float4(p.x, p.y, p.z, k);  // (pos, k) record: one 16-byte gather per neighbour in k_vel_from_k
   if (d.oid[i] < d.n_owned) kap[i] += k;
+}
+
+// (pos.xyz, kb) records for k_vel_from_k when k comes from an existing array (warm start: kappa_v)
+__global__ void k_pack_k(Dev d, const float *kb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  float4 p = d.pos[i];
+  d.pk[i] = make_float4(p.x, p.y, p.z, kb[i]);
 }
 
 // neighbour loop of divergence_iter / pressure_iter / warmstart_divergence_vel
 // (ref: dfsph.py:460-471, 529-541, 420-439): v_i += dt * sum (k_i + k_j) V gradW with the eps gates.
 // COND 0: always; COND 1: only where adv_rho_i > 0 (divergence warm start, :421)
 template <int COND>
-__global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float *kb, float dt) {
+__global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, float dt) {
   LOAD_I
   if (!own) return;
   if (COND == 1 && !(d.adv_rho[i] > 0.0f)) return;
-  const float ki = kb[i];
+  const float ki = pk[i].w;
   float3 acc = f3(0, 0, 0);
   const bool ks = fabsf(ki) > d.eps;
-  walk(d, i, pi,
-       [&](int j, float3 r, float r2, float m) {
-         float s = ki + kb[j];
-         if (fabsf(s) > d.eps) acc = acc + r * (m * s * cubic_gradW_scale(d, r2));
-       },
-       [&](int, float3 r, float r2, float m) {
-         if (ks) acc = acc + r * (m * ki * (d.VS0 / d.VL0) * cubic_gradW_scale(d, r2));
-       });
+  walk<8>(d, i, pi, pk, [](int, float4 p) { return p.w; },
+          [&](int, float3 r, float r2, float kj) {
+            float s = ki + kj;
+            if (fabsf(s) > d.eps) acc = acc + r * (s * cubic_gradW_scale(d, r2));
+          },
+          [&](int, float3 r, float r2) {
+            if (ks) acc = acc + r * (ki * (d.VS0 / d.VL0) * cubic_gradW_scale(d, r2));
+          });
   float4 v = d.vel[i];
   const float f = dt * d.VL0;
   v.x += f * acc.x; v.y += f * acc.y; v.z += f * acc.z;
@@ -152,14 +158,14 @@ __global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
   if (!(d.adv_rho[i] > d.rho_L0)) return;
   const float ki = d.kappa[i], kvi = d.kappa_v[i];
   float3 acc = f3(0, 0, 0);
-  walk(d, i, pi,
-       [&](int j, float3 r, float r2, float m) {
-         float s = ki + d.kappa[j];
-         if (fabsf(s) > d.eps) acc = acc + r * (m * dt * s * d.VL0 * cubic_gradW_scale(d, r2));
-       },
-       [&](int, float3 r, float r2, float m) {
-         if (fabsf(ki) > d.eps) acc = acc + r * (m * dt * kvi * d.VS0 * cubic_gradW_scale(d, r2));
-       });
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { return d.kappa[j]; },
+          [&](int, float3 r, float r2, float kj) {
+            float s = ki + kj;
+            if (fabsf(s) > d.eps) acc = acc + r * (dt * s * d.VL0 * cubic_gradW_scale(d, r2));
+          },
+          [&](int, float3 r, float r2) {
+            if (fabsf(ki) > d.eps) acc = acc + r * (dt * kvi * d.VS0 * cubic_gradW_scale(d, r2));
+          });
   float4 v = d.vel[i];
   v.x += acc.x; v.y += acc.y; v.z += acc.z;
   d.vel[i] = v;
@@ -202,8 +208,9 @@ __global__ void __launch_bounds__(BLOCK) k_tension_normal(Dev d) {
   LOAD_I
   if (!own) return;
   float3 n = f3(0, 0, 0);
-  walk(d, i, pi, [&](int j, float3 r, float r2, float m) { n = n + r * (m * d.mass / d.rho[j] * cubic_gradW_scale(d, r2)); },
-       [&](int, float3, float, float) {});
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.rho[j]; },
+          [&](int, float3 r, float r2, float rhoj) { n = n + r * (d.mass / rhoj * cubic_gradW_scale(d, r2)); },
+          [&](int, float3, float) {});
   d.normal[i] = f4(n * d.h, 0);
 }
 // ref: kernels/AdhesionKernel.py:20-29
@@ -218,18 +225,18 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel(Dev d) {
   const float3 ni = xyz(d.normal[i]);
   const float rhoi = d.rho[i];
   float3 acc = f3(0, 0, 0);
-  walk(d, i, pi,
-       [&](int j, float3, float r2, float m) {
-         float kij = 2.0f * d.rho_L0 / (rhoi + d.rho[j]);
-         if (r2 <= d.h2) acc = acc + (ni - xyz(d.normal[j])) * (-d.tension * kij * m);
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { float4 n = d.normal[j]; n.w = d.rho[j]; return n; },
+       [&](int, float3, float r2, float4 nj) {
+         float kij = 2.0f * d.rho_L0 / (rhoi + nj.w);
+         if (r2 <= d.h2) acc = acc + (ni - xyz(nj)) * (-d.tension * kij);
        },
-       [&](int j, float3 r, float r2, float m) {
+       [&](int j, float3 r, float r2) {
          float3 pj = xyz(d.spos[j]);
          float3 c = pj - f3(0.0f, 0.5f, 0.0f);
          float dis = sqrtf(dot3(c, c));
          if (r2 > d.eps && dis < 0.26f) {  // scene hack of the reference, dfsph.py:300-302
            float rl = sqrtf(r2);
-           acc = acc + r * (m * -d.tension_b * d.rho_S0 * d.VS0 * adhesion_W(d, rl) / rl);
+           acc = acc + r * (-d.tension_b * d.rho_S0 * d.VS0 * adhesion_W(d, rl) / rl);
          }
        });
   float4 a = d.d_vel[i];
@@ -246,15 +253,15 @@ __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const 
   float3 ret = f3(0, 0, 0);
   const float cl = d.dim_coff * d.visc * d.mass;
   const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
-  walk(d, i, pi,
-       [&](int j, float3 r, float r2, float m) {
-         float s = cl / d.rho[j] * dot3(xi - xyz(x[j]), r) / (r2 + e);
-         ret = ret + r * (m * s * cubic_gradW_scale(d, r2));
-       },
-       [&](int, float3 r, float r2, float m) {
-         float s = cs * dot3(xi, r) / (r2 + e);
-         ret = ret + r * (m * s * cubic_gradW_scale(d, r2));
-       });
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = x[j]; xj.w = d.rho[j]; return xj; },
+          [&](int, float3 r, float r2, float4 xj) {
+            float s = cl / xj.w * dot3(xi - xyz(xj), r) / (r2 + e);
+            ret = ret + r * (s * cubic_gradW_scale(d, r2));
+          },
+          [&](int, float3 r, float r2) {
+            float s = cs * dot3(xi, r) / (r2 + e);
+            ret = ret + r * (s * cubic_gradW_scale(d, r2));
+          });
   return xi - ret * (dt / rhoi);
 }
 // ref: dfsph.py:199-200
@@ -277,9 +284,9 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
     m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
     m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
   };
-  walk(d, i, pi,
-       [&](int j, float3 r, float r2, float m) { accum(r, m * cl / d.rho[j] / (r2 + e) * cubic_gradW_scale(d, r2)); },
-       [&](int, float3 r, float r2, float m) { accum(r, m * cs / (r2 + e) * cubic_gradW_scale(d, r2)); });
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.rho[j]; },
+          [&](int, float3 r, float r2, float rhoj) { accum(r, cl / rhoj / (r2 + e) * cubic_gradW_scale(d, r2)); },
+          [&](int, float3 r, float r2) { accum(r, cs / (r2 + e) * cubic_gradW_scale(d, r2)); });
   const float f = dt / rhoi;
   float a = 1.0f - m00 * f, b = -m01 * f, c = -m02 * f, dd = 1.0f - m11 * f, ee = -m12 * f, ff = 1.0f - m22 * f;
   // inverse of the symmetric matrix [[a b c][b dd ee][c ee ff]] by adjugate / determinant
@@ -308,6 +315,52 @@ __global__ void __launch_bounds__(BLOCK) k_visc_residual(Dev d, float dt) {
   }
   block_accumulate(&d.acc[ACC_DZERO], part);
 }
+// fused dfsph.py:202-223: one neighbour walk builds the preconditioner block AND A(v_guess) (both read rho_j,
+// the second also v_guess_j); used by the fused host path, the split kernels above stay for the per-phase API
+__global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
+  LOAD_I
+  float part = 0.f;
+  if (own) {
+    const float rhoi = d.rho[i];
+    const float e = 0.01f * d.h2;
+    const float cl = d.dim_coff * d.visc * d.mass;
+    const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
+    const float3 xi = xyz(d.vel_guess[i]);
+    float m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+    float3 ret = f3(0, 0, 0);
+    auto accum = [&](float3 r, float s) {
+      m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
+      m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
+    };
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = d.vel_guess[j]; xj.w = d.rho[j]; return xj; },
+            [&](int, float3 r, float r2, float4 xj) {
+              const float g = cubic_gradW_scale(d, r2) / (r2 + e);
+              const float c = cl / xj.w * g;
+              accum(r, c);
+              ret = ret + r * (c * dot3(xi - xyz(xj), r));
+            },
+            [&](int, float3 r, float r2) {
+              const float c = cs * cubic_gradW_scale(d, r2) / (r2 + e);
+              accum(r, c);
+              ret = ret + r * (c * dot3(xi, r));
+            });
+    const float f = dt / rhoi;
+    float a = 1.0f - m00 * f, b = -m01 * f, c = -m02 * f, dd = 1.0f - m11 * f, ee = -m12 * f, ff = 1.0f - m22 * f;
+    float A = dd * ff - ee * ee, B = -(b * ff - ee * c), C = b * ee - dd * c;
+    float id = 1.0f / (a * A + b * B + c * C);
+    float i11 = (a * ff - c * c) * id, i12 = -(a * ee - c * b) * id, i22 = (a * dd - b * b) * id;
+    const float4 r0 = make_float4(A * id, B * id, C * id, 0), r1 = make_float4(B * id, i11, i12, 0), r2 = make_float4(C * id, i12, i22, 0);
+    d.minv0[i] = r0; d.minv1[i] = r1; d.minv2[i] = r2;
+    const float3 res = xyz(d.vel[i]) - (xi - ret * f);
+    const float3 dir = f3(r0.x * res.x + r0.y * res.y + r0.z * res.z, r1.x * res.x + r1.y * res.y + r1.z * res.z,
+                          r2.x * res.x + r2.y * res.y + r2.z * res.z);
+    d.cg_r[i] = f4(res, 0);
+    d.cg_dir[i] = f4(dir, 0);
+    part = dot3(res, dir);
+  }
+  block_accumulate(&d.acc[ACC_DZERO], part);
+}
+
 // ref: dfsph.py:227-230: Ad = A(dir); dAd = eps + sum dir.Ad
 __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
   LOAD_I
@@ -364,16 +417,17 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
   const float c1 = -1.0f / dt * d.vort_init * d.visc_omega * d.mass;
   const float c2 = d.vort_coff / rhoi * d.mass;
   const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
-  walk(d, i, pi,
-       [&](int j, float3 r, float r2, float m) {
-         float3 dw = wi - xyz(d.omega[j]);
-         float g = m * cubic_gradW_scale(d, r2);
-         dom = dom + dw * (m * c1 / d.rho[j] * cubic_W(d, r2));
+  struct WV { float4 w, v; };
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { WV p; p.w = d.omega[j]; p.w.w = d.rho[j]; p.v = d.vel[j]; return p; },
+       [&](int, float3 r, float r2, WV pj) {
+         float3 dw = wi - xyz(pj.w);
+         float g = cubic_gradW_scale(d, r2);
+         dom = dom + dw * (c1 / pj.w.w * cubic_W(d, r2));
          dv = dv + cross3(dw, r) * (c2 * g);
-         dom = dom + cross3(vi - xyz(d.vel[j]), r) * (c3 * g);
+         dom = dom + cross3(vi - xyz(pj.v), r) * (c3 * g);
        },
-       [&](int, float3 r, float r2, float m) {
-         float g = m * cubic_gradW_scale(d, r2);
+       [&](int, float3 r, float r2) {
+         float g = cubic_gradW_scale(d, r2);
          dv = dv + cross3(wi, r) * (d.vort_coff / rhoi * d.rho_L0 * d.VS0 * g);
          dom = dom + cross3(vi, r) * (d.vort_coff / rhoi * d.vort_init * d.rho_L0 * d.VL0 * g);
        });
@@ -445,8 +499,8 @@ __global__ void __launch_bounds__(BLOCK) k_ss_density(Dev d) {
   LOAD_I
   if (!own) return;
   float sl = 0.f, ss = 0.f;
-  walk(d, i, pi, [&](int, float3, float r2, float m) { sl += m * cubic_W(d, r2); },
-       [&](int, float3, float r2, float m) { ss += m * cubic_W(d, r2); });
+  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
+          [&](int, float3, float r2) { ss += cubic_W(d, r2); });
   d.rho[i] = (d.ss_VL0 * (d.mk_h3 + sl) + d.ss_VS0 * ss) * d.ss_rho0;
 }
 __global__ void k_ss_pressure(Dev d) {
@@ -465,16 +519,17 @@ __global__ void __launch_bounds__(BLOCK) k_ss_force(Dev d) {
   const float e = 0.01f * d.h2;
   const float pi2 = prsi / (rhoi * rhoi);
   float3 a = f3(d.gx, d.gy, d.gz);
-  walk(d, i, pi,
-       [&](int j, float3 r, float r2, float m) {
-         float g = m * cubic_gradW_scale(d, r2);
-         float rhoj = d.rho[j];
-         float visc = d.ss_dim * d.ss_visc * d.ss_mass / rhoj * dot3(vi - xyz(d.vel[j]), r) / (r2 + e);
-         float prs = -d.ss_rho0 * d.ss_VL0 * (pi2 + d.pressure[j] / (rhoj * rhoj));
+  struct VP { float4 v; float p; };
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { VP q; q.v = d.vel[j]; q.v.w = d.rho[j]; q.p = d.pressure[j]; return q; },
+       [&](int, float3 r, float r2, VP q) {
+         float g = cubic_gradW_scale(d, r2);
+         float rhoj = q.v.w;
+         float visc = d.ss_dim * d.ss_visc * d.ss_mass / rhoj * dot3(vi - xyz(q.v), r) / (r2 + e);
+         float prs = -d.ss_rho0 * d.ss_VL0 * (pi2 + q.p / (rhoj * rhoj));
          a = a + r * ((visc + prs) * g);
        },
-       [&](int, float3 r, float r2, float m) {
-         float g = m * cubic_gradW_scale(d, r2);
+       [&](int, float3 r, float r2) {
+         float g = cubic_gradW_scale(d, r2);
          float visc = d.ss_dim * d.ss_visc_b * d.ss_VS0 * (rhoi / d.ss_rho0) * dot3(vi, r) / (r2 + e);
          float prs = -d.ss_rho0 * d.ss_VS0 * (pi2 + prsi / (d.ss_rho0 * d.ss_rho0));
          a = a + r * ((visc + prs) * g);

@@ -204,18 +204,51 @@ __global__ void __launch_bounds__(ALIAS_TB) k_alias_fill(Dev d, const int *cell_
 // ---- raw list length (HashGrid.neighborCount) --------------------------------------------
 // faithful: count_i = sum over the in-box walked cells c of gridCount[hash(c)]  -  (visits of the own bucket)
 // (ref: HashGrid.py:79-106).  cellval[c] = gridCount[hash(c)], then a separable 5x5x5 box sum.
-__global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d.ncell) return;
+// Only cells whose (x,y) column lies within 2 columns of a column holding liquid can be walked by a liquid
+// particle, so the box filter runs on that sub-box (bb = {xmin, ymin, xmax, ymax} of the non-empty columns).
+__global__ void k_column_bbox(Dev d, int *bb) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int x = t / d.ny, y = t % d.ny;
+  bool ne = false;
+  if (t < d.nx * d.ny) { int base = t * d.nz; ne = d.cs_l[base + d.nz] > d.cs_l[base]; }
+  int xmin = ne ? x : 0x7fffffff, ymin = ne ? y : 0x7fffffff, xmax = ne ? x : -1, ymax = ne ? y : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    xmin = min(xmin, __shfl_down(xmin, o, WAVE)); ymin = min(ymin, __shfl_down(ymin, o, WAVE));
+    xmax = max(xmax, __shfl_down(xmax, o, WAVE)); ymax = max(ymax, __shfl_down(ymax, o, WAVE));
+  }
+  if ((threadIdx.x & (WAVE - 1)) == 0 && xmax >= 0) {
+    atomicMin(&bb[0], xmin); atomicMin(&bb[1], ymin); atomicMax(&bb[2], xmax); atomicMax(&bb[3], ymax);
+  }
+}
+// thread index -> cell of the sub-box (margin columns around bb), or -1
+__device__ __forceinline__ int subbox_cell(const Dev &d, const int *bb, int margin, int t) {
+  const int x0 = max(bb[0] - margin, 0), y0 = max(bb[1] - margin, 0);
+  const int x1 = min(bb[2] + margin, d.nx - 1), y1 = min(bb[3] + margin, d.ny - 1);
+  if (x1 < x0 || y1 < y0) return -1;
+  const int sy = y1 - y0 + 1;
+  const int z = t % d.nz, q = t / d.nz;
+  const int x = x0 + q / sy, y = y0 + q % sy;
+  if (x > x1) return -1;
+  return (x * d.ny + y) * d.nz + z;
+}
+__global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags, const int *bb) {
+  int c = subbox_cell(d, bb, 4, blockIdx.x * blockDim.x + threadIdx.x);
+  if (c < 0) return;
   int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
   int v = bcount[ref_hash(cx + d.x0, cy, cz, d.table_size)];
   if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);  // ref: HashGrid.py:72-74 cannot be reproduced
   cellval[c] = v;
 }
-__global__ void k_boxsum(const int *in, int *out, int n, int len, int stride) {
+// bucket occupancy over ALL buckets (the cap applies to every bucket, not only walked ones)
+__global__ void k_bucket_cap(Dev d, const int *bcount, int *flags) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < d.table_size && bcount[b] > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
+}
+__global__ void k_boxsum(Dev d, const int *in, int *out, int len, int stride, const int *bb, int margin) {
   // 5-tap sum along one axis; len = cells along the axis, stride = element stride of the axis
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+  int c = subbox_cell(d, bb, margin, blockIdx.x * blockDim.x + threadIdx.x);
+  if (c < 0) return;
   int a = (c / stride) % len;
   int s = 0;
 #pragma unroll
@@ -268,22 +301,25 @@ __global__ void k_ncount_clean(Dev d) {
 
 // Compact per-step neighbour lists: the in-support entries of the reference's neighbour row, with the
 // bucket-multiset multiplicity expanded into repeated entries (ref: HashGrid.py:88-106).
-__global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d) {
+__global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   const int i = sorted_index();
   if (i >= d.nl) return;
   const float4 pi = d.pos[i];
   const size_t st = (size_t)d.nbr_stride;
   int cl = 0, cs = 0;
   const int cap = d.nbr_cap;
-  walk_cells(d, i, pi,
+  walk_cells(d, i, pi, liquid_too != 0,
              [&](int j, float3, float, float m) {
-               for (int rep = (int)m; rep > 0; rep--) { if (cl < cap) d.nbr_l[cl * st + i] = j; cl++; }
+               for (int rep = (int)m; rep > 0; rep--) { if (cl < cap) d.nbr_l[NBR_AT(cl, st, i)] = j; cl++; }
              },
              [&](int j, float3, float, float m) {
-               for (int rep = (int)m; rep > 0; rep--) { if (cs < cap) d.nbr_s[cs * st + i] = j; cs++; }
+               for (int rep = (int)m; rep > 0; rep--) { if (cs < cap) d.nbr_s[NBR_AT(cs, st, i)] = j; cs++; }
              });
   if (cl > cap || cs > cap) { atomicOr(&d.flags[FLAG_ERR], ERRBIT_LISTCAP); cl = min(cl, cap); cs = min(cs, cap); }
-  d.ncl[i] = cl;
+  // pad the last 16-byte block with a valid index (the loop loads whole blocks)
+  for (int k = cl; (k & 3) && k < cap; k++) d.nbr_l[NBR_AT(k, st, i)] = 0;
+  for (int k = cs; (k & 3) && k < cap; k++) d.nbr_s[NBR_AT(k, st, i)] = 0;
+  if (liquid_too) d.ncl[i] = cl;
   d.ncs[i] = cs;
 }
 

@@ -14,6 +14,7 @@
 #include "device.h"
 #include "grid.h"
 #include "dfsph_kernels.h"
+#include "tile.h"
 
 struct wcsph_ctx {
   wcsph_params p;
@@ -28,6 +29,9 @@ struct wcsph_ctx {
   // grid scratch
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
   int *bcount = nullptr, *bcount_s = nullptr, *cellval = nullptr, *celltmp = nullptr;
+  int *tile_p = nullptr;
+  int tile_blocks1 = 1024, tile_blocks2 = 512;  // persistent grids: 4 / 2 workgroups per CU (LDS bound)
+  bool use_tiles = false;  // LDS-tiled iteration passes (tile.h); experimental, WCSPH_TILES=1
   int n_alias = 0, scan_blocks = 0;
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats
@@ -126,6 +130,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   memset(&d, 0, sizeof d);
   d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
   ctx->capacity = p->n_liquid;
+  { const char *e = getenv("WCSPH_TILES"); ctx->use_tiles = e && e[0] == '1'; }
   d.faithful = (p->neighbor_mode == WCSPH_MODE_FAITHFUL);
   d.table_size = p->hash_table_size > 0 ? p->hash_table_size : (p->n_liquid + p->n_solid);
   if (d.table_size < 1) d.table_size = 1;
@@ -158,11 +163,12 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.cg_r, nl); DALLOC(d.cg_dir, nl); DALLOC(d.cg_Ad, nl); DALLOC(d.cg_s, nl);
   DALLOC(d.minv0, nl); DALLOC(d.minv1, nl); DALLOC(d.minv2, nl);
   DALLOC(d.rho, nl); DALLOC(d.adv_rho, nl); DALLOC(d.pressure, nl); DALLOC(d.vel_max, nl); DALLOC(d.alpha, nl); DALLOC(d.kbuf, nl);
-  DALLOC(d.ncount, nl); DALLOC(d.ncl, nl); DALLOC(d.ncs, nl);
+  DALLOC(d.ncount, nl); DALLOC(d.ncl, nl); DALLOC(d.ncs, nl); DALLOC(d.pk, nl);
   d.nbr_stride = (int)((nl + 63) / 64 * 64);
   d.nbr_cap = p->max_neighbour < 128 ? p->max_neighbour : 128;
   if (d.nbr_cap < 1) d.nbr_cap = 1;
   DALLOC(d.nbr_l, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.nbr_s, (size_t)d.nbr_stride * d.nbr_cap);
+  DALLOC(d.nbr16, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.cnt16, nl);
   DALLOC(d.spos, (size_t)d.ns);
   DALLOC(d.acc, 8); DALLOC(d.flags, 4);
   size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
@@ -233,6 +239,14 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   ctx->scan_blocks = (nscan + SCAN_TILE - 1) / SCAN_TILE;
   DALLOC(ctx->cnt, nscan); DALLOC(d.cs_l, nscan); DALLOC(d.cs_s, nscan); DALLOC(ctx->bsum, ctx->scan_blocks + 1);
   DALLOC(d.cell_info, d.ncell);
+  d.ntx = (d.nx + TILE_X - 1) / TILE_X; d.nty = (d.ny + TILE_Y - 1) / TILE_Y; d.ntz = (d.nz + TILE_Z - 1) / TILE_Z;
+  d.ntile = d.ntx * d.nty * d.ntz;
+  DALLOC(d.tile_list, d.ntile); DALLOC(d.tile_qoff, d.ntile); DALLOC(d.tile_meta, 8); DALLOC(ctx->tile_p, d.ntile);
+  {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    ctx->tile_blocks1 = ((cus * 2 + 7) / 8) * 8; ctx->tile_blocks2 = ((cus + 7) / 8) * 8;  // 55 / 110 KB LDS per workgroup
+  }
   if (d.faithful) {
     DALLOC(ctx->bcount, d.table_size); DALLOC(ctx->bcount_s, d.table_size);
     DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->celltmp, d.ncell);
@@ -325,15 +339,29 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   }
   // raw neighbour-list length (HashGrid.neighborCount)
   if (d.faithful) {
-    hipLaunchKernelGGL(k_cellval, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags);
-    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, (const int *)ctx->cellval, ctx->celltmp, d.ncell, d.nz, 1);
-    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, (const int *)ctx->celltmp, ctx->cellval, d.ncell, d.ny, d.nz);
-    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, (const int *)ctx->cellval, ctx->celltmp, d.ncell, d.nx, d.ny * d.nz);
+    int *bb = d.tile_meta + 4;  // {xmin, ymin, xmax, ymax} of the liquid-bearing cell columns
+    HIPCHK(hipMemsetAsync(bb, 0x7f, 2 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(bb + 2, 0xff, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(k_column_bbox, dim3(nblk(d.nx * d.ny)), dim3(BLOCK), 0, s, d, bb);
+    hipLaunchKernelGGL(k_bucket_cap, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, d.flags);
+    // separable 5x5x5 box sum of gridCount[hash(cell)]: the z pass needs +-2 columns in x AND y around the liquid
+    // columns (margin 4 covers both later passes), the y pass +-2 in x, the x pass the liquid columns themselves
+    hipLaunchKernelGGL(k_cellval, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags, (const int *)bb);
+    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nz, 1, (const int *)bb, 4);
+    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp, ctx->cellval, d.ny, d.nz, (const int *)bb, 2);
+    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nx, d.ny * d.nz, (const int *)bb, 0);
     if (d.nl > 0) hipLaunchKernelGGL(k_ncount_faithful, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp);
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
   }
-  if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d);
+  if (d.nl > 0) {
+    hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
+    if (ctx->use_tiles) {
+      hipLaunchKernelGGL(k_tile_count, dim3(nblk(d.ntile)), dim3(BLOCK), 0, s, d, ctx->tile_p);
+      hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, d, (const int *)ctx->tile_p);
+      hipLaunchKernelGGL(kt_build_lists, dim3(ctx->tile_blocks1), dim3(TBLOCK), 0, s, d);
+    }
+  }
   LAUNCHCHK();
   ctx->grid_valid = true;
   return WCSPH_OK;
@@ -515,6 +543,32 @@ int wcsph_set_iters(wcsph_ctx *ctx, int32_t vs, int32_t dv, int32_t pr) {
     LAUNCHCHK();                                                                                  \
   } while (0)
 
+#define TPASS1(kern, ...)                                                                         \
+  do {                                                                                            \
+    if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(ctx->tile_blocks1), dim3(TBLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
+    LAUNCHCHK();                                                                                  \
+  } while (0)
+#define TPASS2(kern, ...)                                                                         \
+  do {                                                                                            \
+    if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(ctx->tile_blocks2), dim3(TBLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
+    LAUNCHCHK();                                                                                  \
+  } while (0)
+
+#define HOT_DRHO_DIV(mode, dtv)                                                                   \
+  do { if (ctx->use_tiles) TPASS2((kt_drho<mode, 1>), dtv); else PASS(k_drho_div<mode>, dtv); } while (0)
+#define HOT_DRHO_PRESS(mode, dtv)                                                                 \
+  do { if (ctx->use_tiles) TPASS2((kt_drho<mode, 0>), dtv); else PASS(k_drho_press<mode>, dtv); } while (0)
+/* pack != 0: rebuild the (pos, k) gather records first (k from another array, or ghosts refreshed by a halo
+ * exchange since k_make_k wrote them) */
+#define HOT_VEL(cond, kbp, dtv, pack)                                                             \
+  do {                                                                                            \
+    if (ctx->use_tiles) TPASS1(kt_vel_from_k<cond>, (const float *)(kbp), dtv);                   \
+    else {                                                                                        \
+      if (pack) ELEM(k_pack_k, (const float *)(kbp));                                             \
+      PASS(k_vel_from_k<cond>, (const float4 *)ctx->d.pk, dtv);                                   \
+    }                                                                                             \
+  } while (0)
+
 int wcsph_dfsph_reset_param(wcsph_ctx *ctx) {
   NEED_SETUP();
   ELEM(k_reset);
@@ -526,27 +580,27 @@ int wcsph_dfsph_compute_coff(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_coff); return
 
 int wcsph_dfsph_warmstart_divergence(wcsph_ctx *ctx) {
   NEED_GRID();
-  PASS(k_drho_div<DRHO_WARM>, ctx->dt);
-  PASS(k_vel_from_k<1>, (const float *)ctx->d.kappa_v, ctx->dt);
+  HOT_DRHO_DIV(DRHO_WARM, ctx->dt);
+  HOT_VEL(1, ctx->d.kappa_v, ctx->dt, 1);
   return WCSPH_OK;
 }
-int wcsph_dfsph_begin_divergence(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_drho_div<DRHO_BEGIN>, ctx->dt); return WCSPH_OK; }
+int wcsph_dfsph_begin_divergence(wcsph_ctx *ctx) { NEED_GRID(); HOT_DRHO_DIV(DRHO_BEGIN, ctx->dt); return WCSPH_OK; }
 
 // launches one iteration; the error sum lands in h_acc[ACC_ERR] after pull_scalars()
 static int divergence_iter_async(wcsph_ctx *ctx) {
   ELEM(k_make_k, ctx->d.kappa_v, 0.0f);
-  PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, ctx->dt);
+  HOT_VEL(0, ctx->d.kbuf, ctx->dt, 0);
   int rc = zero_acc(ctx, ACC_ERR);
   if (rc) return rc;
-  PASS(k_drho_div<DRHO_ITER>, ctx->dt);
+  HOT_DRHO_DIV(DRHO_ITER, ctx->dt);
   return 0;
 }
 static int pressure_iter_async(wcsph_ctx *ctx) {
   ELEM(k_make_k, ctx->d.kappa, 1.0f);
-  PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, ctx->dt);
+  HOT_VEL(0, ctx->d.kbuf, ctx->dt, 0);
   int rc = zero_acc(ctx, ACC_ERR);
   if (rc) return rc;
-  PASS(k_drho_press<DRHO_ITER>, ctx->dt);
+  HOT_DRHO_PRESS(DRHO_ITER, ctx->dt);
   return 0;
 }
 int wcsph_dfsph_divergence_iter(wcsph_ctx *ctx) {
@@ -566,7 +620,7 @@ int wcsph_dfsph_warmstart_pressure(wcsph_ctx *ctx) {
   PASS(k_warm_press_vel, ctx->dt);
   return WCSPH_OK;
 }
-int wcsph_dfsph_begin_pressure(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_drho_press<DRHO_BEGIN>, ctx->dt); return WCSPH_OK; }
+int wcsph_dfsph_begin_pressure(wcsph_ctx *ctx) { NEED_GRID(); HOT_DRHO_PRESS(DRHO_BEGIN, ctx->dt); return WCSPH_OK; }
 int wcsph_dfsph_pressure_iter(wcsph_ctx *ctx) {
   NEED_GRID();
   int rc = pressure_iter_async(ctx);
@@ -592,10 +646,9 @@ int wcsph_dfsph_tension(wcsph_ctx *ctx) {
 int wcsph_dfsph_visc_init(wcsph_ctx *ctx) {
   NEED_GRID();
   ELEM(k_visc_guess);
-  PASS(k_visc_minv, ctx->dt);
   int rc = zero_acc(ctx, ACC_DZERO);
   if (rc) return rc;
-  PASS(k_visc_residual, ctx->dt);
+  PASS(k_visc_minv_residual, ctx->dt);  // dfsph.py:202-223 in one neighbour walk
   rc = pull_scalars(ctx);
   if (rc) return rc;
   ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
@@ -847,18 +900,18 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
   const float dt = ctx->dt;
   switch (ph) {
     case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); break;
-    case WCSPH_PH_DRHO_DIV_WARM: PASS(k_drho_div<DRHO_WARM>, dt); break;
-    case WCSPH_PH_VEL_WARM: PASS(k_vel_from_k<1>, (const float *)ctx->d.kappa_v, dt); break;
-    case WCSPH_PH_DRHO_DIV_BEGIN: PASS(k_drho_div<DRHO_BEGIN>, dt); break;
+    case WCSPH_PH_DRHO_DIV_WARM: HOT_DRHO_DIV(DRHO_WARM, dt); break;
+    case WCSPH_PH_VEL_WARM: HOT_VEL(1, ctx->d.kappa_v, dt, 1); break;
+    case WCSPH_PH_DRHO_DIV_BEGIN: HOT_DRHO_DIV(DRHO_BEGIN, dt); break;
     case WCSPH_PH_MAKE_K_DIV: ELEM(k_make_k, ctx->d.kappa_v, 0.0f); break;
-    case WCSPH_PH_VEL_ITER: PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, dt); break;
-    case WCSPH_PH_DRHO_DIV_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; PASS(k_drho_div<DRHO_ITER>, dt); break;
+    case WCSPH_PH_VEL_ITER: HOT_VEL(0, ctx->d.kbuf, dt, ctx->d.n_owned < ctx->d.nl); break;
+    case WCSPH_PH_DRHO_DIV_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_DIV(DRHO_ITER, dt); break;
     case WCSPH_PH_END_DIV: ELEM(k_end_div, dt); break;
     case WCSPH_PH_WARM_PRESS_SCALE: ELEM(k_warm_press_scale, dt); break;
     case WCSPH_PH_WARM_PRESS_VEL: PASS(k_warm_press_vel, dt); break;
-    case WCSPH_PH_DRHO_PRESS_BEGIN: PASS(k_drho_press<DRHO_BEGIN>, dt); break;
+    case WCSPH_PH_DRHO_PRESS_BEGIN: HOT_DRHO_PRESS(DRHO_BEGIN, dt); break;
     case WCSPH_PH_MAKE_K_PRESS: ELEM(k_make_k, ctx->d.kappa, 1.0f); break;
-    case WCSPH_PH_DRHO_PRESS_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; PASS(k_drho_press<DRHO_ITER>, dt); break;
+    case WCSPH_PH_DRHO_PRESS_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_PRESS(DRHO_ITER, dt); break;
     case WCSPH_PH_END_PRESS: ELEM(k_end_press, dt); break;
     case WCSPH_PH_CLEAR: ELEM(k_clear_nonpressure); break;
     case WCSPH_PH_TENSION_NORMAL: PASS(k_tension_normal); break;
@@ -890,8 +943,8 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
   auto one = [&]() -> int {
     if (nm == "pressure_iter") return pressure_iter_async(ctx);
     if (nm == "divergence_iter") return divergence_iter_async(ctx);
-    if (nm == "pressure_vel_loop") { PASS(k_vel_from_k<0>, (const float *)ctx->d.kbuf, ctx->dt); return 0; }
-    if (nm == "pressure_drho_loop") { PASS(k_drho_press<DRHO_ITER>, ctx->dt); return 0; }
+    if (nm == "pressure_vel_loop") { HOT_VEL(0, ctx->d.kbuf, ctx->dt, 0); return 0; }
+    if (nm == "pressure_drho_loop") { HOT_DRHO_PRESS(DRHO_ITER, ctx->dt); return 0; }
     if (nm == "density") { PASS(k_density); return 0; }
     if (nm == "density_coff") { PASS(k_density_coff); return 0; }
     if (nm == "grid_update") return wcsph_grid_update(ctx);
