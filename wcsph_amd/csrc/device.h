@@ -228,27 +228,22 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   const int cl = d.ncl[i];
   const int4 *L = reinterpret_cast<const int4 *>(d.nbr_l) + i;
   for (int k = 0; k < cl; k += U) {
-    int j[U];
-    {
-      const int4 e0 = L[(size_t)(k >> 2) * st];
-      j[0] = e0.x; j[1] = e0.y; j[2] = e0.z; j[3] = e0.w;
-      if (U == 8) {
-        const int4 e1 = (k + 4 < cl) ? L[(size_t)((k >> 2) + 1) * st] : e0;  // tail: re-use valid indices
-        j[4] = e1.x; j[5] = e1.y; j[6] = e1.z; j[7] = e1.w;
-      }
+    const int4 e0 = L[(size_t)(k >> 2) * st];
+    int4 e1 = e0;
+    if (U == 8 && k + 4 < cl) e1 = L[(size_t)((k >> 2) + 1) * st];  // tail: e1 = e0 re-uses valid indices
+    // scalars, not an indexed array: keeps the indices in VGPRs (an int j[U] lands in scratch here)
+    const int j0 = e0.x, j1 = e0.y, j2 = e0.z, j3 = e0.w, j4 = e1.x, j5 = e1.y, j6 = e1.z, j7 = e1.w;
+    const float4 p0 = P[j0], p1 = P[j1], p2 = P[j2], p3 = P[j3];
+    const auto b0 = gl(j0, p0); const auto b1 = gl(j1, p1); const auto b2 = gl(j2, p2); const auto b3 = gl(j3, p3);
+    if (U == 8) {
+      const float4 p4 = P[j4], p5 = P[j5], p6 = P[j6], p7 = P[j7];
+      const auto b4 = gl(j4, p4); const auto b5 = gl(j5, p5); const auto b6 = gl(j6, p6); const auto b7 = gl(j7, p7);
+#define WALK_ONE(u, jj, pp, bb) if (k + u < cl) { const float3 r = xi - xyz(pp); fl(jj, r, dot3(r, r), bb); }
+      WALK_ONE(0, j0, p0, b0) WALK_ONE(1, j1, p1, b1) WALK_ONE(2, j2, p2, b2) WALK_ONE(3, j3, p3, b3)
+      WALK_ONE(4, j4, p4, b4) WALK_ONE(5, j5, p5, b5) WALK_ONE(6, j6, p6, b6) WALK_ONE(7, j7, p7, b7)
+    } else {
+      WALK_ONE(0, j0, p0, b0) WALK_ONE(1, j1, p1, b1) WALK_ONE(2, j2, p2, b2) WALK_ONE(3, j3, p3, b3)
     }
-    float4 p[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) p[u] = P[j[u]];
-    decltype(gl(0, p[0])) b[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) b[u] = gl(j[u], p[u]);
-#pragma unroll
-    for (int u = 0; u < U; u++)
-      if (k + u < cl) {
-        const float3 r = xi - xyz(p[u]);
-        fl(j[u], r, dot3(r, r), b[u]);
-      }
   }
   const int cs = d.ncs[i];
   const int4 *S = reinterpret_cast<const int4 *>(d.nbr_s) + i;

@@ -237,13 +237,11 @@ class SlabSim:
         if self.world == 1:
             return
         B = self.B
-        bl, br = B.gather_rows(field, self.send_l), B.gather_rows(field, self.send_r)
-        w = bl.shape[1]
-        gl = torch.empty((self.ghost_l.numel(), w), dtype=torch.float32, device=self.device)
-        gr = torch.empty((self.ghost_r.numel(), w), dtype=torch.float32, device=self.device)
-        self._sendrecv(bl, br, gl, gr)
-        B.scatter_rows(field, self.ghost_l, gl)
-        B.scatter_rows(field, self.ghost_r, gr)
+        nl, ngl = self.send_l.numel(), self.ghost_l.numel()
+        out = B.gather_rows(field, self.send_all)            # one pack kernel for both neighbours
+        inc = torch.empty((self.ghost_all.numel(), out.shape[1]), dtype=torch.float32, device=self.device)
+        self._sendrecv(out[:nl], out[nl:], inc[:ngl], inc[ngl:])
+        B.scatter_rows(field, self.ghost_all, inc)            # one unpack kernel
 
     def _allreduce(self, v, op):
         if self.world == 1:
@@ -281,6 +279,8 @@ class SlabSim:
             empty = torch.zeros(0, dtype=i32, device=self.device)
             self.send_l = self.send_r = self.ghost_l = self.ghost_r = empty
             allrows = rows
+        self.send_all = torch.cat([self.send_l, self.send_r])
+        self.ghost_all = torch.cat([self.ghost_l, self.ghost_r])
         self.rows = rows
         self.n_owned = rows.shape[0]
         self.B.load_state(self.n_owned, allrows)
