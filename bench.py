@@ -137,7 +137,7 @@ def main():
                    "neighbor_mode": args.mode, "n_liquid": nl, "n_solid": ns,
                    "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)},
                    "dt_end": float(dfsph.deltaT[0]), "setup_s": round(t_setup, 2)},
-        "roofline": {"bound": "hbm", "kernel": "pressure_iter (k_make_k + k_vel_from_k + k_drho_press, ref dfsph.py:518-547)",
+        "roofline": {"bound": "hbm", "kernel": "pressure_iter as the fused solver launches it: k_vel_from_k (kappa += k) + k_drho_press<ITER> (k epilogue), ref dfsph.py:518-547",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "avg_launch_us": round(ms.value * 1e3, 1),
                      "algorithmic_bytes_per_launch": int(alg_bytes), "other_kernels": extra},

@@ -63,7 +63,10 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
 enum { DRHO_PLAIN = 0, DRHO_WARM = 1, DRHO_BEGIN = 2, DRHO_ITER = 3 };
 
 // ref: dfsph.py:374-392 update_drho_divergence, inlined at :418 (WARM), :443 (BEGIN), :475 (ITER)
-template <int MODE>
+// FUSEK (fused solver loops only): the epilogue also emits next iteration's (pos, k_i) gather record,
+// k_i = b_i * alpha_i (dfsph.py:455-456 / 523-525), so that no separate k_make_k launch is needed;
+// kappa += k_i then happens in the prologue of the k_vel_from_k launch that consumes it.
+template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) k_drho_div(Dev d, float dt) {
   LOAD_I
   float a = 0.f;
@@ -76,13 +79,15 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div(Dev d, float dt) {
     a = fmaxf(a, 0.0f);
     if (d.ncount[i] < 20) a = 0.0f;  // raw list length, Q2
     d.adv_rho[i] = a;
-    if (MODE == DRHO_BEGIN) { d.alpha[i] = d.alpha[i] / dt; d.kappa_v[i] = 0.0f; }
+    float al = d.alpha[i];
+    if (MODE == DRHO_BEGIN) { al = al / dt; d.alpha[i] = al; d.kappa_v[i] = 0.0f; }
+    if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * al);
   }
   if (MODE == DRHO_ITER) block_accumulate(&d.acc[ACC_ERR], a);  // ref: dfsph.py:476 avg_density_err += adv_rho
 }
 
 // ref: dfsph.py:394-412 update_drho_pressure, inlined at :513 (BEGIN), :545 (ITER)
-template <int MODE>
+template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) k_drho_press(Dev d, float dt) {
   LOAD_I
   float e = 0.f;
@@ -95,7 +100,9 @@ __global__ void __launch_bounds__(BLOCK) k_drho_press(Dev d, float dt) {
     float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
     d.adv_rho[i] = a;
     e = a - 1.0f;
-    if (MODE == DRHO_BEGIN) { d.alpha[i] = d.alpha[i] / dt / dt; d.kappa[i] = 0.0f; }
+    float al = d.alpha[i];
+    if (MODE == DRHO_BEGIN) { al = al / dt / dt; d.alpha[i] = al; d.kappa[i] = 0.0f; }
+    if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, e * al);
   }
   if (MODE == DRHO_ITER) block_accumulate(&d.acc[ACC_ERR], e);  // ref: dfsph.py:546
 }
@@ -123,12 +130,14 @@ __global__ void k_pack_k(Dev d, const float *kb) {
 // neighbour loop of divergence_iter / pressure_iter / warmstart_divergence_vel
 // (ref: dfsph.py:460-471, 529-541, 420-439): v_i += dt * sum (k_i + k_j) V gradW with the eps gates.
 // COND 0: always; COND 1: only where adv_rho_i > 0 (divergence warm start, :421)
+// kap != nullptr (fused solver loops): kappa_i += k_i here instead of in k_make_k (dfsph.py:458 / 527)
 template <int COND>
-__global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, float dt) {
+__global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, float dt, float *kap = nullptr) {
   LOAD_I
   if (!own) return;
   if (COND == 1 && !(d.adv_rho[i] > 0.0f)) return;
   const float ki = pk[i].w;
+  if (kap) kap[i] += ki;
   float3 acc = f3(0, 0, 0);
   const bool ks = fabsf(ki) > d.eps;
   walk<8>(d, i, pi, pk, [](int, float4 p) { return p.w; },

@@ -603,6 +603,30 @@ static int pressure_iter_async(wcsph_ctx *ctx) {
   HOT_DRHO_PRESS(DRHO_ITER, ctx->dt);
   return 0;
 }
+// fused-loop variants: k_i comes from the previous drho launch's epilogue (FUSEK), kappa += k_i in the vel launch
+static int divergence_iter_fused(wcsph_ctx *ctx) {
+  if (ctx->use_tiles || ctx->d.n_owned < ctx->d.nl) return divergence_iter_async(ctx);
+  PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v);
+  int rc = zero_acc(ctx, ACC_ERR);
+  if (rc) return rc;
+  PASS((k_drho_div<DRHO_ITER, true>), ctx->dt);
+  return 0;
+}
+static int pressure_iter_fused(wcsph_ctx *ctx) {
+  if (ctx->use_tiles || ctx->d.n_owned < ctx->d.nl) return pressure_iter_async(ctx);
+  PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);
+  int rc = zero_acc(ctx, ACC_ERR);
+  if (rc) return rc;
+  PASS((k_drho_press<DRHO_ITER, true>), ctx->dt);
+  return 0;
+}
+static int fused_iter_sync(wcsph_ctx *ctx) {
+  int rc = pull_scalars(ctx);
+  if (rc) return rc;
+  ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+  return 0;
+}
+
 int wcsph_dfsph_divergence_iter(wcsph_ctx *ctx) {
   NEED_GRID();
   int rc = divergence_iter_async(ctx);
@@ -743,10 +767,13 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
   ctx->dv_iter = 0;
   if ((rc = wcsph_dfsph_warmstart_divergence(ctx))) return rc;
   double err = -0.1;
-  if ((rc = wcsph_dfsph_begin_divergence(ctx))) return rc;
+  const bool fusek = !ctx->use_tiles && ctx->d.n_owned == ctx->d.nl;
+  if (fusek) PASS((k_drho_div<DRHO_BEGIN, true>), ctx->dt);
+  else if ((rc = wcsph_dfsph_begin_divergence(ctx))) return rc;
   const float dt = ctx->dt;
   while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
-    if ((rc = wcsph_dfsph_divergence_iter(ctx))) return rc;
+    if ((rc = divergence_iter_fused(ctx))) return rc;
+    if ((rc = fused_iter_sync(ctx))) return rc;
     err = 0.001 * (double)ctx->d.n_owned / (double)dt;
     ctx->dv_iter++;
   }
@@ -759,9 +786,12 @@ int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
   if ((rc = wcsph_dfsph_warmstart_pressure(ctx))) return rc;
   ctx->pr_iter = 0;
   double err = 0.0;
-  if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
+  const bool fusek = !ctx->use_tiles && ctx->d.n_owned == ctx->d.nl;
+  if (fusek) PASS((k_drho_press<DRHO_BEGIN, true>), ctx->dt);
+  else if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
   while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
-    if ((rc = wcsph_dfsph_pressure_iter(ctx))) return rc;
+    if ((rc = pressure_iter_fused(ctx))) return rc;
+    if ((rc = fused_iter_sync(ctx))) return rc;
     err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
     ctx->pr_iter++;
   }
@@ -941,8 +971,9 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
   std::string nm(name);
   int rc = 0;
   auto one = [&]() -> int {
-    if (nm == "pressure_iter") return pressure_iter_async(ctx);
-    if (nm == "divergence_iter") return divergence_iter_async(ctx);
+    if (nm == "pressure_iter") return pressure_iter_fused(ctx);      // what wcsph_dfsph_solve_pressure launches per iteration
+    if (nm == "divergence_iter") return divergence_iter_fused(ctx);
+    if (nm == "pressure_iter_unfused") return pressure_iter_async(ctx);  // k_make_k + vel + drho (per-kernel API)
     if (nm == "pressure_vel_loop") { HOT_VEL(0, ctx->d.kbuf, ctx->dt, 0); return 0; }
     if (nm == "pressure_drho_loop") { HOT_DRHO_PRESS(DRHO_ITER, ctx->dt); return 0; }
     if (nm == "density") { PASS(k_density); return 0; }
@@ -951,6 +982,8 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
     return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");
   };
+  if (nm == "pressure_iter" && (rc = pressure_iter_async(ctx))) return rc;      // primes the (pos, k) records
+  if (nm == "divergence_iter" && (rc = divergence_iter_async(ctx))) return rc;
   if ((rc = one())) return rc;  // warm-up
   HIPCHK(hipEventRecord(e0, ctx->stream));
   for (int r = 0; r < reps && !rc; r++) rc = one();
