@@ -52,7 +52,7 @@ typedef struct wcsph_params {
   int32_t max_neighbour;     /* 2048 (ParticleData.py:27) */
   int32_t hash_table_size;   /* 0 => n_liquid + n_solid (HashGrid.py:114); slabs pass the global count */
   int32_t tension_fixed;     /* 0 literal Q8/Q9 loop is NOT reproducible; only 1 (fixed normals) is implemented */
-  int32_t reserved0;
+  int32_t list_cap;          /* entries per particle of the compact lists; 0 => 128.  pcisph needs the reference's 2048 */
   double particle_radius;    /* what the script passes to ParticleData(): radius (dfsph) or diameter (sesph, Q11) */
   double cfl_radius;         /* dfsph.py:27 particleRadius used by optimize_time_step */
   double user_max_t, user_min_t; /* dfsph.py:39-40 */
@@ -64,7 +64,10 @@ typedef struct wcsph_params {
   float eps;
   /* sesph.py private constants (sesph.py:23-62) */
   float ss_searchR, ss_mk, ss_ml, ss_VL0, ss_VS0, ss_mass, ss_rho0, ss_stiff, ss_dim, ss_visc, ss_visc_b;
-  float list_radius;         /* support radius of the compact per-step neighbour lists; 0 => HashGrid.searchR */
+  float list_radius;         /* radius of the compact per-step neighbour lists; 0 => HashGrid.searchR; < 0 => unbounded:
+                              * every particle of the walked cells, i.e. the reference's raw list (HashGrid.py:88-106) */
+  /* pcisph.py:68-70,299 and iisph.py:80-83 private constants */
+  float pci_coff, pc_visc, pc_visc_b, ii_visc, ii_visc_b, ii_omega;
 } wcsph_params;
 
 /* field ids for wcsph_field_to_host / wcsph_field_from_host (ref: ParticleData.py:33-76, dfsph.py:46-48) */
@@ -78,6 +81,9 @@ enum wcsph_field {
   WCSPH_F_CG_MINV,     /* [n_liquid][3][3] f32 */
   WCSPH_F_NEIGHBOR_COUNT, /* [n_liquid] i32  (HashGrid.neighborCount) */
   WCSPH_F_KBUF,        /* [n_liquid] f32 scratch: k_i = b_i * alpha_i of the running iteration (dfsph.py:456,525) */
+  WCSPH_F_D_VEL_PRE, WCSPH_F_POS_STAR, WCSPH_F_VEL_STAR,   /* pcisph.py:52-54  [n_liquid][3] */
+  WCSPH_F_D_II, WCSPH_F_DIJ_PJ,                            /* iisph.py:58-59   [n_liquid][3] */
+  WCSPH_F_A_II, WCSPH_F_PRESSURE_PRE,                      /* iisph.py:57,60   [n_liquid] */
   WCSPH_F__COUNT
 };
 
@@ -85,6 +91,7 @@ enum wcsph_field {
 enum wcsph_scalar {
   WCSPH_S_DELTA_T = 0, WCSPH_S_AVG_DENSITY_ERR, WCSPH_S_CG_DELTA, WCSPH_S_CG_DELTA_OLD, WCSPH_S_CG_DELTA_ZERO,
   WCSPH_S_VISCOSITY, WCSPH_S_VISCOSITY_B, WCSPH_S_TENSION, WCSPH_S_TENSION_B, WCSPH_S_VEL_MAX0,
+  WCSPH_S_RHO_ERR,     /* pcisph.py:58 rho_err */
   WCSPH_S__COUNT
 };
 
@@ -151,6 +158,30 @@ int wcsph_sesph_pressure(wcsph_ctx *ctx);      /* ref: sesph.py:158-166 */
 int wcsph_sesph_force(wcsph_ctx *ctx);         /* ref: sesph.py:168-188 */
 int wcsph_sesph_integrate(wcsph_ctx *ctx);     /* ref: sesph.py:191-196 */
 int wcsph_sesph_step(wcsph_ctx *ctx);          /* ref: sesph.py:217-225 */
+
+/* ---- pcisph.py kernels ---------------------------------------------------- */
+int wcsph_pcisph_reset_param(wcsph_ctx *ctx);               /* ref: pcisph.py:193-197 */
+int wcsph_pcisph_compute_nonpressure_force(wcsph_ctx *ctx); /* ref: pcisph.py:199-218 */
+int wcsph_pcisph_init_iter_info(wcsph_ctx *ctx);            /* ref: pcisph.py:220-226 */
+int wcsph_pcisph_update_iter_info(wcsph_ctx *ctx);          /* ref: pcisph.py:228-235 */
+int wcsph_pcisph_predict_density(wcsph_ctx *ctx);           /* ref: pcisph.py:237-278 */
+int wcsph_pcisph_update_pos(wcsph_ctx *ctx);                /* ref: pcisph.py:281-285 */
+int wcsph_pcisph_solve_pressure(wcsph_ctx *ctx);            /* ref: pcisph.py:147-157 (sovel_pressure) */
+int wcsph_pcisph_step(wcsph_ctx *ctx);                      /* ref: pcisph.py:303-312 */
+
+/* ---- iisph.py kernels ------------------------------------------------------ */
+int wcsph_iisph_reset_param(wcsph_ctx *ctx);                /* ref: iisph.py:178-182 */
+int wcsph_iisph_compute_density(wcsph_ctx *ctx);            /* ref: iisph.py:254-268 */
+int wcsph_iisph_visc_init(wcsph_ctx *ctx);                  /* ref: iisph.py:200-229 */
+int wcsph_iisph_visc_iter(wcsph_ctx *ctx);                  /* ref: iisph.py:231-252 */
+int wcsph_iisph_combine_nonpressure(wcsph_ctx *ctx);        /* ref: iisph.py:270-274 */
+int wcsph_iisph_compute_nonpressure_force(wcsph_ctx *ctx);  /* ref: iisph.py:114-127 */
+int wcsph_iisph_compute_advection(wcsph_ctx *ctx);          /* ref: iisph.py:276-316 */
+int wcsph_iisph_update_iter_info(wcsph_ctx *ctx);           /* ref: iisph.py:318-334 */
+int wcsph_iisph_update_pressure_force(wcsph_ctx *ctx);      /* ref: iisph.py:336-370 */
+int wcsph_iisph_solve_pressure(wcsph_ctx *ctx);             /* ref: iisph.py:130-139 */
+int wcsph_iisph_update_pos(wcsph_ctx *ctx);                 /* ref: iisph.py:372-396 */
+int wcsph_iisph_step(wcsph_ctx *ctx);                       /* ref: iisph.py:419-428 */
 
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Times `reps` back-to-back launches of one named kernel group with hipEvents on the context's

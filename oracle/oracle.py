@@ -15,11 +15,12 @@ _LIB = os.path.join(_HERE, "_build", "libwcsph_oracle.so")
 
 _SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
             "tension_coff", "tension_coff_b", "VL0", "VS0", "liqiudMass", "searchR", "gridR", "invGridR", "rho_L0",
-            "viscosity_err", "vorticity_coff", "viscosity_omega", "vorticity_init"]
+            "viscosity_err", "vorticity_coff", "viscosity_omega", "vorticity_init", "rho_err", "pci_coff"]
 _INTS = ["vs_iter", "dv_iter", "pr_iter", "overflow_grid", "overflow_neighbor", "table_size", "bs0", "bs1", "bs2",
          "tension_fixed", "mode", "n_reduce"]
-_VEC3 = ["vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s"]
-_SCAL = ["rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "kbuf"]
+_VEC3 = ["vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s",
+         "d_vel_pre", "pos_star", "vel_star", "d_ii", "dij_pj"]
+_SCAL = ["rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "kbuf", "a_ii", "pressure_pre"]
 _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff", "update_drho_divergence",
           "update_drho_pressure", "warmstart_divergence_vel", "begin_divergence_iter", "divergence_iter",
           "end_divergence_iter", "warmstart_pressure", "begin_pressure_iter", "pressure_iter", "end_pressure_iter",
@@ -32,7 +33,14 @@ _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff",
           "warmstart_divergence_drho", "warmstart_divergence_velloop", "make_k_div", "make_k_press", "vel_iter",
           "drho_div_iter", "drho_press_iter", "warmstart_pressure_scale", "warmstart_pressure_vel", "tension_normal",
           "tension_accel", "visc_guess", "visc_minv", "visc_residual", "visc_Ad", "visc_update", "visc_dir",
-          "vorticity_accumulate", "vorticity_integrate"]
+          "vorticity_accumulate", "vorticity_integrate",
+          # pcisph.py / iisph.py
+          "pcisph_reset_param", "pcisph_compute_nonpressure_force", "pcisph_init_iter_info", "pcisph_update_iter_info",
+          "pcisph_predict_density", "pcisph_solve_pressure", "pcisph_update_pos", "pcisph_step",
+          "iisph_reset_param", "iisph_compute_density", "iisph_init_viscosity_para", "iisph_compute_viscosity_force",
+          "iisph_combine_nonpressure", "iisph_compute_nonpressure_force", "iisph_compute_advection",
+          "iisph_update_iter_info", "iisph_update_pressure_force", "iisph_solve_pressure", "iisph_update_pos",
+          "iisph_step"]
 
 
 def build_oracle(force=False):
@@ -66,6 +74,10 @@ def _load():
         lib.orc_adh_W.restype = C.c_float
         lib.orc_gradW.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_sesph_init.argtypes = [C.c_void_p, C.c_double]
+        lib.orc_pcisph_init.argtypes = [C.c_void_p, C.c_double]
+        lib.orc_iisph_init.argtypes = [C.c_void_p, C.c_double]
+        lib.orc_pci_coff.argtypes = [C.c_double]
+        lib.orc_pci_coff.restype = C.c_double
         lib.orc_get_scalar.argtypes = [C.c_void_p, C.c_int]
         lib.orc_get_scalar.restype = C.c_float
         lib.orc_set_scalar.argtypes = [C.c_void_p, C.c_int, C.c_float]
@@ -192,6 +204,12 @@ class Oracle:
 
     def sesph_init(self, particleRadius=0.025):
         self.lib.orc_sesph_init(self.h, float(particleRadius))
+
+    def pcisph_init(self, particleRadius=0.025):
+        self.lib.orc_pcisph_init(self.h, float(particleRadius))
+
+    def iisph_init(self, particleRadius=0.025):
+        self.lib.orc_iisph_init(self.h, float(particleRadius))
 
     def close(self):
         if self.__dict__.get("h"):

@@ -80,6 +80,11 @@ typedef struct orc_ctx {
   float ck_h, ck_h3, ck_mk, ck_ml;
   /* cohesion / adhesion (ref: kernels/CohesionKernel.py:12-15, AdhesionKernel.py:12-14) */
   float coh_mk, coh_mc, adh_mk;
+  /* ---- pcisph.py / iisph.py private fields (ref: pcisph.py:50-64, iisph.py:56-66) ---- */
+  v3 *d_vel_pre, *pos_star, *vel_star, *d_ii, *dij_pj;
+  float *a_ii, *pressure_pre;
+  float rho_err, pci_coff;
+  float ii_visc, ii_visc_b, ii_omega, pc_visc, pc_visc_b;
   /* ---- sesph.py private state (ref: sesph.py:23-62) ---- */
   float ss_searchR, ss_mk, ss_ml, ss_VL0, ss_VS0, ss_mass, ss_rho0, ss_stiff, ss_dim, ss_visc, ss_visc_b;
 } orc_ctx;
@@ -120,6 +125,7 @@ orc_ctx *orc_create(int n_liquid, int n_solid, double particleR, int maxInGrid, 
   c->cg_Minv = (float *)calloc(nl * 9, sizeof(float));
   AL3(cg_r); AL3(cg_dir); AL3(cg_Ad); AL3(cg_s);
   AL1(alpha_coff); AL1(kappa); AL1(kappa_v); AL1(kbuf);
+  AL3(d_vel_pre); AL3(pos_star); AL3(vel_star); AL3(d_ii); AL3(dij_pj); AL1(a_ii); AL1(pressure_pre);
   c->n_reduce = n_liquid;
   c->neighborCount = (int *)calloc(nl, sizeof(int));
   c->neighbor = (int *)malloc(nl * (size_t)maxNeighbour * sizeof(int));
@@ -132,7 +138,7 @@ void orc_destroy(orc_ctx *c) {
   free(c->pos); free(c->vel); free(c->vel_guess); free(c->d_vel); free(c->omega); free(c->d_omega);
   free(c->normal); free(c->rho); free(c->adv_rho); free(c->pressure); free(c->vel_max); free(c->cg_Minv);
   free(c->cg_r); free(c->cg_dir); free(c->cg_Ad); free(c->cg_s); free(c->alpha_coff); free(c->kappa);
-  free(c->kappa_v); free(c->kbuf); free(c->neighborCount); free(c->neighbor); free(c->gridCount); free(c->grid);
+  free(c->kappa_v); free(c->kbuf); free(c->d_vel_pre); free(c->pos_star); free(c->vel_star); free(c->d_ii); free(c->dij_pj); free(c->a_ii); free(c->pressure_pre); free(c->neighborCount); free(c->neighbor); free(c->gridCount); free(c->grid);
   free(c);
 }
 
@@ -839,6 +845,359 @@ void orc_sesph_step(orc_ctx *c) {
   orc_sesph_integrate(c);
 }
 
+
+/* ------------------------------------------------------------------------------------ */
+/* pcisph.py (ref: pcisph.py:30-64 constants, 87-115 GetPciCoff, 147-285 kernels).  Uses the sesph-style
+ * private kernel constants (ss_*: pi = 3.1415926, VS0 = 2 VL0) set by orc_sesph_init().                 */
+
+/* ref: pcisph.py:75-115 -- host-side, float64 NumPy in the reference */
+double orc_pci_coff(double particleRadius) {
+  const double gridR = particleRadius * 2.0, sr = gridR * 2.0, pi = 3.1415926, h3 = sr * sr * sr, m_l = 48.0 / (pi * h3);
+  const double diam = 2.0 * particleRadius;
+  double sg[3] = {0, 0, 0}, sg2 = 0.0;
+  const double V00 = particleRadius * particleRadius * particleRadius * 0.8 * 8.0;
+  double xj[3] = {-sr, -sr, -sr};
+  while (xj[0] <= sr) {
+    while (xj[1] <= sr) {
+      while (xj[2] <= sr) {
+        double r[3] = {-xj[0], -xj[1], -xj[2]};
+        double dist = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        if (dist < sr) {
+          double g[3] = {0, 0, 0}, q = dist / sr;
+          if (dist > 1.0e-5 && q <= 1.0) {
+            double f = (q <= 0.5) ? m_l * q * (3.0 * q - 2.0) : -m_l * (1.0 - q) * (1.0 - q);
+            for (int a = 0; a < 3; a++) g[a] = f * r[a] / (dist * sr);
+          }
+          for (int a = 0; a < 3; a++) sg[a] += g[a];
+          double dg = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+          sg2 += dg * dg;
+        }
+        xj[2] += diam;
+      }
+      xj[1] += diam; xj[2] = -sr;
+    }
+    xj[0] += diam; xj[1] = -sr; xj[2] = -sr;
+  }
+  const double beta = 2.0 * V00 * V00;
+  const double ds = sqrt(sg[0] * sg[0] + sg[1] * sg[1] + sg[2] * sg[2]);
+  return 1.0 / (beta * (ds * ds + sg2));
+}
+void orc_pcisph_init(orc_ctx *c, double particleRadius) {
+  orc_sesph_init(c, particleRadius);
+  c->pci_coff = (float)orc_pci_coff(particleRadius);
+  c->pc_visc = 0.05f; c->pc_visc_b = 0.0f;   /* pcisph.py:68-70 */
+}
+/* ref: pcisph.py:193-197 */
+void orc_pcisph_reset_param(orc_ctx *c) {
+  for (int i = 0; i < NL; i++) c->vel[i] = V(0, 0, 0);
+  c->deltaT = 0.001f;
+}
+/* ref: pcisph.py:199-218.  The reference reads rho[j] inside the loop that is still writing rho (a data race:
+ * any mix of last step's, partial and final values).  Restated two-phase: densities first, then the viscous term
+ * with the finished rho_j of THIS step.  rho[i] in the solid term is the running partial sum of
+ * the reference; restated with the finished rho_i (the term is multiplied by viscosity_b = 0). */
+void orc_pcisph_compute_nonpressure_force(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float rho = c->ss_VL0 * ss_W_norm(c, 0.0f) * c->ss_rho0;
+    NB_BEGIN(i)
+      float w = ss_W_norm(c, sqrtf(nsq(r)));
+      rho += ((j < NL) ? c->ss_VL0 : c->ss_VS0) * w * c->ss_rho0;
+    NB_END
+    c->rho[i] = rho;
+  }
+  const float e = 0.01f * c->ss_searchR * c->ss_searchR;
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 a = c->gravity;
+    NB_BEGIN(i)
+      v3 g = ss_gradW(c, r);
+      if (j < NL) a = add(a, mul(g, c->ss_dim * c->pc_visc * c->ss_mass / c->rho[j] * dot(sub(c->vel[i], c->vel[j]), r) / (nsq(r) + e)));
+      else        a = add(a, mul(g, c->ss_dim * c->pc_visc_b * c->ss_VS0 * (c->rho[i] / c->ss_rho0) * dot(c->vel[i], r) / (nsq(r) + e)));
+    NB_END
+    c->d_vel[i] = a;
+  }
+}
+/* ref: pcisph.py:220-226 */
+void orc_pcisph_init_iter_info(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->vel_star[i] = c->vel[i]; c->pos_star[i] = c->pos[i]; c->pressure[i] = 0.0f; c->d_vel_pre[i] = V(0, 0, 0);
+  }
+}
+/* ref: pcisph.py:228-235 (rho_err[i] = 0 on a shape-(1) field: only element 0 exists, Q12) */
+void orc_pcisph_update_iter_info(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->vel_star[i] = add(c->vel[i], mul(add(c->d_vel[i], c->d_vel_pre[i]), c->deltaT));
+    c->pos_star[i] = add(c->pos[i], mul(c->vel_star[i], c->deltaT));
+    c->pressure[i] = 0.0f;
+  }
+  c->rho_err = 0.0f;
+}
+/* ref: pcisph.py:237-278.  The density prediction uses the CURRENT positions (Q13), the pressure force
+ * mixes pos[i] with pos_star[j] -- both kept literally. */
+void orc_pcisph_predict_density(orc_ctx *c) {
+  double err = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : err)
+  for (int i = 0; i < NL; i++) {
+    float a = c->ss_VL0 * ss_W_norm(c, 0.0f);
+    NB_BEGIN(i)
+      float w = ss_W_norm(c, sqrtf(nsq(r)));
+      a += ((j < NL) ? c->ss_VL0 : c->ss_VS0) * w;
+    NB_END
+    a = fmaxf(a, 1.0f);
+    c->adv_rho[i] = a;
+    c->pressure[i] += c->pci_coff * (a - 1.0f) / (c->deltaT * c->deltaT);
+    if (i < c->n_reduce) err += (double)(a - 1.0f);
+  }
+  c->rho_err = (float)((double)c->rho_err + err);
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 a = V(0, 0, 0);
+    int cur = c->neighborCount[i];
+    const int *nb = c->neighbor + (long)i * c->maxNeighbour;
+    for (int k = 0; k < cur; k++) {
+      int j = nb[k];
+      v3 pj = (j < NL) ? c->pos_star[j] : c->pos[j];
+      v3 g = ss_gradW(c, sub(c->pos[i], pj));
+      float dpi = c->pressure[i];
+      if (j < NL) a = add(a, mul(g, -c->ss_VL0 * (dpi + c->pressure[j])));
+      else        a = add(a, mul(g, -c->ss_VS0 * dpi));
+    }
+    c->d_vel_pre[i] = a;
+  }
+}
+/* ref: pcisph.py:147-157 */
+void orc_pcisph_solve_pressure(orc_ctx *c) {
+  c->pr_iter = 0;
+  double err = 0.0;
+  orc_pcisph_init_iter_info(c);
+  while ((err > 0.01 || c->pr_iter < 3) && c->pr_iter < 50) {
+    orc_pcisph_update_iter_info(c);
+    orc_pcisph_predict_density(c);
+    err = (double)c->rho_err / (double)c->n_reduce;
+    c->pr_iter++;
+  }
+}
+/* ref: pcisph.py:281-285 */
+void orc_pcisph_update_pos(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->vel[i] = add(c->vel[i], mul(add(c->d_vel[i], c->d_vel_pre[i]), c->deltaT));
+    c->pos[i] = add(c->pos[i], mul(c->vel[i], c->deltaT));
+  }
+}
+/* ref: pcisph.py:303-312 main-loop body */
+void orc_pcisph_step(orc_ctx *c) {
+  orc_update_grid(c);
+  orc_pcisph_compute_nonpressure_force(c);
+  orc_pcisph_solve_pressure(c);
+  orc_pcisph_update_pos(c);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* iisph.py (ref: iisph.py:24-96 constants, 114-139 host loops, 184-396 kernels); private kernel constants as
+ * sesph (pi = 3.1415926) but VS0 = VL0 (iisph.py:37).                                                    */
+void orc_iisph_init(orc_ctx *c, double particleRadius) {
+  orc_sesph_init(c, particleRadius);
+  c->ss_VS0 = c->ss_VL0;                         /* iisph.py:37 */
+  c->ii_visc = 2.0f; c->ii_visc_b = 3.0f; c->ii_omega = 0.5f;   /* iisph.py:80-83 */
+}
+/* ref: iisph.py:178-182 */
+void orc_iisph_reset_param(orc_ctx *c) {
+  for (int i = 0; i < NL; i++) { c->vel[i] = V(0, 0, 0); c->pressure[i] = 0.0f; }
+  c->deltaT = 0.001f;
+}
+/* ref: iisph.py:254-268 */
+void orc_iisph_compute_density(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float rho = c->ss_VL0 * ss_W_norm(c, 0.0f) * c->ss_rho0;
+    NB_BEGIN(i)
+      float w = ss_W_norm(c, sqrtf(nsq(r)));
+      rho += ((j < NL) ? c->ss_VL0 : c->ss_VS0) * w * c->ss_rho0;
+    NB_END
+    c->rho[i] = rho;
+  }
+}
+/* ref: iisph.py:184-198 */
+static inline v3 ii_viscosity_Ax(const orc_ctx *c, const v3 *x, int i) {
+  v3 ret = V(0, 0, 0);
+  const float e = 0.01f * c->ss_searchR * c->ss_searchR;
+  NB_BEGIN(i)
+    if (j < NL) {
+      float s = c->ss_dim * c->ii_visc * c->ss_mass / c->rho[j] * dot(sub(x[i], x[j]), r) / (nsq(r) + e);
+      ret = add(ret, mul(ss_gradW(c, r), s / c->rho[i] * c->deltaT));
+    } else {
+      float s = c->ss_dim * c->ii_visc_b * c->ss_rho0 / c->rho[i] * c->ss_VS0 * dot(x[i], r) / (nsq(r) + e);
+      ret = add(ret, mul(ss_gradW(c, r), s / c->rho[i] * c->deltaT));
+    }
+  NB_END
+  return sub(x[i], ret);
+}
+/* ref: iisph.py:200-229 */
+void orc_iisph_init_viscosity_para(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) c->vel_guess[i] = add(c->vel_guess[i], c->vel[i]);
+  const float e = 0.01f * c->ss_searchR * c->ss_searchR;
+  PFOR for (int i = 0; i < NL; i++) {
+    float m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    NB_BEGIN(i)
+      v3 g = ss_gradW(c, r);
+      float s;
+      if (j < NL) s = c->ss_dim * c->ii_visc * c->ss_mass / c->rho[j] / (nsq(r) + e);
+      else        s = c->ss_dim * c->ii_visc_b * c->ss_rho0 / c->rho[i] * c->ss_VS0 / (nsq(r) + e);
+      m[0] += s * g.x * r.x; m[1] += s * g.x * r.y; m[2] += s * g.x * r.z;
+      m[3] += s * g.y * r.x; m[4] += s * g.y * r.y; m[5] += s * g.y * r.z;
+      m[6] += s * g.z * r.x; m[7] += s * g.z * r.y; m[8] += s * g.z * r.z;
+    NB_END
+    float f = c->deltaT / c->rho[i], t[9];
+    for (int a = 0; a < 9; a++) t[a] = ((a % 4 == 0) ? 1.0f : 0.0f) - m[a] * f;
+    inv3(t, c->cg_Minv + (long)i * 9);
+  }
+  double dz = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : dz)
+  for (int i = 0; i < NL; i++) {
+    c->cg_r[i] = sub(c->vel[i], ii_viscosity_Ax(c, c->vel_guess, i));
+    c->cg_dir[i] = matvec(c->cg_Minv + (long)i * 9, c->cg_r[i]);
+    dz += (double)dot(c->cg_r[i], c->cg_dir[i]);
+  }
+  c->cg_delta_zero = (float)dz;
+  c->cg_delta = c->cg_delta_zero;
+}
+/* ref: iisph.py:231-252 */
+void orc_iisph_compute_viscosity_force(orc_ctx *c) {
+  double dAd = (double)c->eps;
+#pragma omp parallel for schedule(static) reduction(+ : dAd)
+  for (int i = 0; i < NL; i++) {
+    c->cg_Ad[i] = ii_viscosity_Ax(c, c->cg_dir, i);
+    dAd += (double)dot(c->cg_dir[i], c->cg_Ad[i]);
+  }
+  float alpha = c->cg_delta / (float)dAd;
+  c->cg_delta_old = c->cg_delta;
+  double dl = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : dl)
+  for (int i = 0; i < NL; i++) {
+    c->vel_guess[i] = add(c->vel_guess[i], mul(c->cg_dir[i], alpha));
+    c->cg_r[i] = sub(c->cg_r[i], mul(c->cg_Ad[i], alpha));
+    c->cg_s[i] = matvec(c->cg_Minv + (long)i * 9, c->cg_r[i]);
+    dl += (double)dot(c->cg_r[i], c->cg_s[i]);
+  }
+  c->cg_delta = (float)dl;
+  float beta = c->cg_delta / c->cg_delta_old;
+  PFOR for (int i = 0; i < NL; i++) c->cg_dir[i] = add(c->cg_s[i], mul(c->cg_dir[i], beta));
+}
+/* ref: iisph.py:270-274 */
+void orc_iisph_combine_nonpressure(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    c->d_vel[i] = add(c->gravity, mul(sub(c->vel_guess[i], c->vel[i]), 1.0f / c->deltaT));
+    c->vel_guess[i] = sub(c->vel_guess[i], c->vel[i]);
+  }
+}
+/* ref: iisph.py:114-127 */
+void orc_iisph_compute_nonpressure_force(orc_ctx *c) {
+  orc_iisph_init_viscosity_para(c);
+  c->vs_iter = 0;
+  while (c->vs_iter < 100) {
+    orc_iisph_compute_viscosity_force(c);
+    c->vs_iter++;
+    if ((double)c->cg_delta <= (double)c->viscosity_err * (double)c->cg_delta_zero || (double)c->cg_delta_zero < (double)c->eps) break;
+  }
+  orc_iisph_combine_nonpressure(c);
+}
+/* ref: iisph.py:276-316 */
+void orc_iisph_compute_advection(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 dii = V(0, 0, 0);
+    c->vel[i] = add(c->vel[i], mul(c->d_vel[i], c->deltaT));
+    float inv_den = c->ss_rho0 / c->rho[i];
+    NB_BEGIN(i)
+      dii = add(dii, mul(ss_gradW(c, r), -c->ss_VL0 * inv_den * inv_den));
+    NB_END
+    c->d_ii[i] = dii;
+  }
+  PFOR for (int i = 0; i < NL; i++) {
+    float aii = 0.0f, density = c->rho[i] / c->ss_rho0, adv = density;
+    c->pressure_pre[i] = 0.5f * c->pressure[i];
+    NB_BEGIN(i)
+      v3 g = ss_gradW(c, r);
+      if (j < NL) adv += c->deltaT * c->ss_VL0 * dot(sub(c->vel[i], c->vel[j]), g);
+      else        adv += c->deltaT * c->ss_VS0 * dot(c->vel[i], g);
+      v3 d_ji = mul(g, c->ss_VL0 / (density * density));
+      aii += c->ss_VL0 * dot(sub(c->d_ii[i], d_ji), g);
+    NB_END
+    c->a_ii[i] = aii; c->adv_rho[i] = adv;
+  }
+}
+/* ref: iisph.py:318-334 */
+void orc_iisph_update_iter_info(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 s = V(0, 0, 0);
+    NB_BEGIN(i)
+      if (j < NL) {
+        float dj = c->rho[j] / c->ss_rho0;
+        s = add(s, mul(ss_gradW(c, r), -c->ss_VL0 / (dj * dj) * c->pressure_pre[j]));
+      }
+    NB_END
+    c->dij_pj[i] = s;
+  }
+  c->avg_density_err = 0.0f;
+}
+/* ref: iisph.py:336-370 (pressure_pre is never refreshed inside the solver loop: every iteration is the same) */
+void orc_iisph_update_pressure_force(orc_ctx *c) {
+  double err = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : err)
+  for (int i = 0; i < NL; i++) {
+    float sum = 0.0f;
+    NB_BEGIN(i)
+      v3 g = ss_gradW(c, r);
+      if (j < NL) {
+        float density = c->rho[i] / c->ss_rho0;
+        v3 dji = mul(g, c->ss_VL0 / (density * density));
+        v3 d_ji_pi = mul(dji, c->pressure_pre[i]);
+        v3 t = sub(sub(c->dij_pj[i], mul(c->d_ii[j], c->pressure_pre[j])), sub(c->dij_pj[j], d_ji_pi));
+        sum += c->ss_VL0 * dot(t, g);
+      } else sum += c->ss_VS0 * dot(c->dij_pj[i], g);
+    NB_END
+    float b = 1.0f - c->adv_rho[i], h2 = c->deltaT * c->deltaT, denom = c->a_ii[i] * h2, p;
+    if (fabsf(denom) > c->eps) p = fmaxf((1.0f - c->ii_omega) * c->pressure_pre[i] + c->ii_omega / denom * (b - h2 * sum), 0.0f);
+    else p = 0.0f;
+    c->pressure[i] = p;
+    if (p != 0.0f && i < c->n_reduce) err += (double)((c->a_ii[i] * p + sum) * h2 - b);
+  }
+  c->avg_density_err = (float)err;
+}
+/* ref: iisph.py:130-139 */
+void orc_iisph_solve_pressure(orc_ctx *c) {
+  c->pr_iter = 0;
+  double err = 0.0;
+  while ((err > 0.001 || c->pr_iter < 2) && c->pr_iter < 100) {
+    orc_iisph_update_iter_info(c);
+    orc_iisph_update_pressure_force(c);
+    err = (double)c->avg_density_err / (double)c->n_reduce;
+    c->pr_iter++;
+  }
+}
+/* ref: iisph.py:372-396 */
+void orc_iisph_update_pos(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 a = V(0, 0, 0);
+    float di = c->rho[i] / c->ss_rho0, dpi = c->pressure[i] / (di * di);
+    NB_BEGIN(i)
+      v3 g = ss_gradW(c, r);
+      if (j < NL) { float dj = c->rho[j] / c->ss_rho0; a = add(a, mul(g, -c->ss_VL0 * (dpi + c->pressure[j] / (dj * dj)))); }
+      else a = add(a, mul(g, -c->ss_VS0 * dpi));
+    NB_END
+    c->d_vel[i] = a;
+  }
+  PFOR for (int i = 0; i < NL; i++) {
+    c->vel[i] = add(c->vel[i], mul(c->d_vel[i], c->deltaT));
+    c->pos[i] = add(c->pos[i], mul(c->vel[i], c->deltaT));
+  }
+}
+/* ref: iisph.py:419-428 main-loop body */
+void orc_iisph_step(orc_ctx *c) {
+  orc_update_grid(c);
+  orc_iisph_compute_density(c);
+  orc_iisph_compute_nonpressure_force(c);
+  orc_iisph_compute_advection(c);
+  orc_iisph_solve_pressure(c);
+  orc_iisph_update_pos(c);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* accessors for the ctypes wrapper (oracle/oracle.py)                                    */
 #define PTR(name, type) type *orc_ptr_##name(orc_ctx *c) { return (type *)c->name; }
@@ -846,11 +1205,12 @@ PTR(pos, float) PTR(vel, float) PTR(vel_guess, float) PTR(d_vel, float) PTR(omeg
 PTR(normal, float) PTR(rho, float) PTR(adv_rho, float) PTR(pressure, float) PTR(vel_max, float)
 PTR(cg_Minv, float) PTR(cg_r, float) PTR(cg_dir, float) PTR(cg_Ad, float) PTR(cg_s, float)
 PTR(alpha_coff, float) PTR(kappa, float) PTR(kappa_v, float) PTR(kbuf, float)
+PTR(d_vel_pre, float) PTR(pos_star, float) PTR(vel_star, float) PTR(d_ii, float) PTR(dij_pj, float) PTR(a_ii, float) PTR(pressure_pre, float)
 PTR(gridCount, int) PTR(grid, int) PTR(neighborCount, int) PTR(neighbor, int)
 
 enum { S_deltaT = 0, S_avg_density_err, S_cg_delta, S_cg_delta_old, S_cg_delta_zero, S_viscosity, S_viscosity_b,
        S_tension_coff, S_tension_coff_b, S_VL0, S_VS0, S_liqiudMass, S_searchR, S_gridR, S_invGridR, S_rho_L0,
-       S_viscosity_err, S_vorticity_coff, S_viscosity_omega, S_vorticity_init };
+       S_viscosity_err, S_vorticity_coff, S_viscosity_omega, S_vorticity_init, S_rho_err, S_pci_coff };
 static float *sptr(orc_ctx *c, int id) {
   switch (id) {
     case S_deltaT: return &c->deltaT; case S_avg_density_err: return &c->avg_density_err;
@@ -861,7 +1221,7 @@ static float *sptr(orc_ctx *c, int id) {
     case S_liqiudMass: return &c->liqiudMass; case S_searchR: return &c->searchR; case S_gridR: return &c->gridR;
     case S_invGridR: return &c->invGridR; case S_rho_L0: return &c->rho_L0; case S_viscosity_err: return &c->viscosity_err;
     case S_vorticity_coff: return &c->vorticity_coff; case S_viscosity_omega: return &c->viscosity_omega;
-    case S_vorticity_init: return &c->vorticity_init;
+    case S_vorticity_init: return &c->vorticity_init; case S_rho_err: return &c->rho_err; case S_pci_coff: return &c->pci_coff;
   }
   return NULL;
 }

@@ -93,6 +93,11 @@ class ParticleData:
         self.sesph_particle_radius = 0.025
         self.hash_table_size = 0  # 0 => count (HashGrid.py:114)
         self.list_radius = 0.0    # 0 => HashGrid.searchR; sesph.py sets its own (smaller) kernel support
+        self.list_cap = 0         # 0 => 128 entries per particle
+        self.ss_VS0_factor = 2.0  # sesph.py:37 / pcisph.py:38 VS0 = 2 VL0 ; iisph.py:37 VS0 = VL0
+        self.pci_coff = 0.0       # pcisph.py:299 GetPciCoff()
+        self.pc_visc, self.pc_visc_b = 0.05, 0.0              # pcisph.py:68-70
+        self.ii_visc, self.ii_visc_b, self.ii_omega = 2.0, 3.0, 0.5   # iisph.py:80-83
         self._ctx = None
 
     # ---- point accumulation (ref: ParticleData.py:100-138) -------------------------------------
@@ -160,6 +165,7 @@ class ParticleData:
         p.max_in_grid, p.max_neighbour = self.hash_grid.maxInGrid, self.hash_grid.maxNeighbour
         p.hash_table_size = int(self.hash_table_size)
         p.tension_fixed = 1
+        p.list_cap = int(self.list_cap)
         p.particle_radius, p.cfl_radius = float(self.particleR), float(self.cfl_radius)
         p.user_max_t, p.user_min_t = float(self.user_max_t), float(self.user_min_t)
         p.rho_L0, p.rho_S0, p.VL0, p.VS0, p.liqiudMass = self.rho_L0, self.rho_S0, self.VL0, self.VS0, self.liqiudMass
@@ -176,9 +182,11 @@ class ParticleData:
         h3 = sr * sr * sr
         VL0 = r * r * r * 0.8 * 8.0
         p.ss_searchR, p.ss_mk, p.ss_ml = sr, 8.0 / (pi * h3), 48.0 / (pi * h3)
-        p.ss_VL0, p.ss_VS0, p.ss_mass, p.ss_rho0 = VL0, VL0 * 2.0, VL0 * 1000.0, 1000.0
+        p.ss_VL0, p.ss_VS0, p.ss_mass, p.ss_rho0 = VL0, VL0 * self.ss_VS0_factor, VL0 * 1000.0, 1000.0
         p.ss_stiff, p.ss_dim, p.ss_visc, p.ss_visc_b = 50000.0, 10.0, 0.1, 0.0
         p.list_radius = float(self.list_radius)
+        p.pci_coff, p.pc_visc, p.pc_visc_b = float(self.pci_coff), self.pc_visc, self.pc_visc_b
+        p.ii_visc, p.ii_visc_b, p.ii_omega = self.ii_visc, self.ii_visc_b, self.ii_omega
         return p
 
     def setup_data_gpu(self):

@@ -17,7 +17,7 @@ class Params(C.Structure):
     _fields_ = [
         ("n_liquid", C.c_int32), ("n_solid", C.c_int32), ("neighbor_mode", C.c_int32), ("max_in_grid", C.c_int32),
         ("max_neighbour", C.c_int32), ("hash_table_size", C.c_int32), ("tension_fixed", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("list_cap", C.c_int32),
         ("particle_radius", C.c_double), ("cfl_radius", C.c_double), ("user_max_t", C.c_double),
         ("user_min_t", C.c_double),
         ("rho_L0", C.c_float), ("rho_S0", C.c_float), ("VL0", C.c_float), ("VS0", C.c_float),
@@ -29,16 +29,19 @@ class Params(C.Structure):
         ("ss_searchR", C.c_float), ("ss_mk", C.c_float), ("ss_ml", C.c_float), ("ss_VL0", C.c_float),
         ("ss_VS0", C.c_float), ("ss_mass", C.c_float), ("ss_rho0", C.c_float), ("ss_stiff", C.c_float),
         ("ss_dim", C.c_float), ("ss_visc", C.c_float), ("ss_visc_b", C.c_float), ("list_radius", C.c_float),
+        ("pci_coff", C.c_float), ("pc_visc", C.c_float), ("pc_visc_b", C.c_float), ("ii_visc", C.c_float),
+        ("ii_visc_b", C.c_float), ("ii_omega", C.c_float),
     ]
 
 
 # enum wcsph_field
 FIELDS = ["pos", "vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s",
-          "rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "cg_Minv", "neighborCount", "kbuf"]
+          "rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "cg_Minv", "neighborCount", "kbuf",
+          "d_vel_pre", "pos_star", "vel_star", "d_ii", "dij_pj", "a_ii", "pressure_pre"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 # enum wcsph_scalar
 SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
-           "tension_coff", "tension_coff_b", "vel_max0"]
+           "tension_coff", "tension_coff_b", "vel_max0", "rho_err"]
 SCALAR_ID = {n: i for i, n in enumerate(SCALARS)}
 
 # every entry point include/wcsph.h declares that takes only the context
@@ -54,6 +57,13 @@ CTX_ONLY = [
     "wcsph_dfsph_solve_pressure", "wcsph_dfsph_step",
     "wcsph_sesph_reset_param", "wcsph_sesph_density", "wcsph_sesph_pressure", "wcsph_sesph_force",
     "wcsph_sesph_integrate", "wcsph_sesph_step",
+    "wcsph_pcisph_reset_param", "wcsph_pcisph_compute_nonpressure_force", "wcsph_pcisph_init_iter_info",
+    "wcsph_pcisph_update_iter_info", "wcsph_pcisph_predict_density", "wcsph_pcisph_update_pos",
+    "wcsph_pcisph_solve_pressure", "wcsph_pcisph_step",
+    "wcsph_iisph_reset_param", "wcsph_iisph_compute_density", "wcsph_iisph_visc_init", "wcsph_iisph_visc_iter",
+    "wcsph_iisph_combine_nonpressure", "wcsph_iisph_compute_nonpressure_force", "wcsph_iisph_compute_advection",
+    "wcsph_iisph_update_iter_info", "wcsph_iisph_update_pressure_force", "wcsph_iisph_solve_pressure",
+    "wcsph_iisph_update_pos", "wcsph_iisph_step",
 ]
 OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_count", "wcsph_setup",
          "wcsph_get_block_size", "wcsph_field_to_host", "wcsph_field_from_host", "wcsph_get_scalar",

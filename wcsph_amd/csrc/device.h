@@ -44,6 +44,9 @@ struct Dev {
   float4 *minv0, *minv1, *minv2;          // rows of cg_Minv
   float *rho, *adv_rho, *pressure, *vel_max, *alpha, *kbuf;
   float4 *pk;                             // per-pass packed gather record (pos.xyz, payload)
+  // pcisph.py / iisph.py private fields
+  float4 *d_vel_pre, *pos_star, *vel_star, *d_ii, *dij_pj;
+  float *a_ii, *pressure_pre;
   int *ncount;                            // HashGrid.neighborCount (raw list length)
   // compact per-step neighbour lists (k-major: entry k of particle i at [k * nbr_stride + i])
   int *nbr_l, *nbr_s;                     // sorted liquid index / sorted solid index

@@ -42,10 +42,10 @@ __device__ __forceinline__ int lin_of(const Dev &d, int w) {
 // phase 3: move every persistent liquid field to its cell-sorted position
 struct SortBuffers {
   const float4 *pos, *vel, *vel_guess, *omega;
-  const float *kappa, *kappa_v;
+  const float *kappa, *kappa_v, *pressure;   // pressure: iisph.py:298 carries it into the next step
   const int *oid;
   float4 *pos_o, *vel_o, *vel_guess_o, *omega_o;
-  float *kappa_o, *kappa_v_o;
+  float *kappa_o, *kappa_v_o, *pressure_o;
   int *oid_o, *where;
 };
 __global__ void k_scatter_liquid(Dev d, SortBuffers b, const int *cs, const int *pw, const int *slot) {
@@ -61,6 +61,7 @@ __global__ void k_scatter_liquid(Dev d, SortBuffers b, const int *cs, const int 
   b.omega_o[dst] = b.omega[i];
   b.kappa_o[dst] = b.kappa[i];
   b.kappa_v_o[dst] = b.kappa_v[i];
+  b.pressure_o[dst] = b.pressure[i];
   int o = b.oid[i];
   b.oid_o[dst] = o;
   b.where[o] = dst;

@@ -15,6 +15,7 @@
 #include "grid.h"
 #include "dfsph_kernels.h"
 #include "tile.h"
+#include "solver_extra.h"
 
 struct wcsph_ctx {
   wcsph_params p;
@@ -24,7 +25,7 @@ struct wcsph_ctx {
   bool is_setup = false, grid_valid = false;
   // double buffers of the persistent fields (the *_b set is the scatter target)
   float4 *pos_b = nullptr, *vel_b = nullptr, *vel_guess_b = nullptr, *omega_b = nullptr;
-  float *kappa_b = nullptr, *kappa_v_b = nullptr;
+  float *kappa_b = nullptr, *kappa_v_b = nullptr, *pressure_b = nullptr;
   int *oid_b = nullptr;
   // grid scratch
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
@@ -40,6 +41,7 @@ struct wcsph_ctx {
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
   float dt = 0.0f;
+  float rho_err = 0.0f;
   float avg_density_err = 0.0f, cg_delta = 0.0f, cg_delta_old = 0.0f, cg_delta_zero = 0.0f, vel_max0 = 0.0f;
   int vs_iter = 0, dv_iter = 0, pr_iter = 0;
   int bs[3] = {0, 0, 0};
@@ -92,7 +94,7 @@ static int check_flags(wcsph_ctx *ctx) {
   int f = ctx->h_flags[FLAG_ERR];
   if (f & ERRBIT_BUCKET) return ctx->fail(WCSPH_EBUCKET, "more than maxInGrid particles in one hash bucket (ref: HashGrid.py:72-74)");
   if (f & ERRBIT_NEIGH) return ctx->fail(WCSPH_ENEIGH, "more than maxNeighbour neighbour-list entries (ref: HashGrid.py:100-103)");
-  if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "more than 128 in-support neighbours of one kind for a particle (compact list capacity)");
+  if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "compact neighbour list capacity (wcsph_params.list_cap, default 128 entries of one kind) exceeded");
   return 0;
 }
 // copy reduction slots + flags to the host and wait
@@ -143,7 +145,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   d.ml_h3 = (float)(48.0 / M_PI) * (float)(1.0 / (h * h * h));
   d.mk_h3 = (float)(8.0 / M_PI) * (float)(1.0 / (h * h * h));
   d.adh_mk = (float)(0.007 / pow(h, 3.25));
-  { float lr = p->list_radius > 0.0f ? p->list_radius : d.h; d.list_r2 = lr * lr * 1.00001f; }
+  { float lr = p->list_radius > 0.0f ? p->list_radius : d.h; d.list_r2 = p->list_radius < 0.0f ? 1e30f : lr * lr * 1.00001f; }
   d.VL0 = p->VL0; d.VS0 = p->VS0; d.rho_L0 = p->rho_L0; d.rho_S0 = p->rho_S0; d.mass = p->liqiudMass; d.eps = p->eps;
   d.gx = p->gravity[0]; d.gy = p->gravity[1]; d.gz = p->gravity[2];
   d.dim_coff = p->dim_coff; d.visc = p->viscosity; d.visc_b = p->viscosity_b;
@@ -157,18 +159,22 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   const size_t nl = (size_t)d.nl;
   DALLOC(d.pos, nl); DALLOC(d.vel, nl); DALLOC(d.vel_guess, nl); DALLOC(d.omega, nl);
   DALLOC(ctx->pos_b, nl); DALLOC(ctx->vel_b, nl); DALLOC(ctx->vel_guess_b, nl); DALLOC(ctx->omega_b, nl);
-  DALLOC(d.kappa, nl); DALLOC(d.kappa_v, nl); DALLOC(ctx->kappa_b, nl); DALLOC(ctx->kappa_v_b, nl);
+  DALLOC(d.kappa, nl); DALLOC(d.kappa_v, nl); DALLOC(ctx->kappa_b, nl); DALLOC(ctx->kappa_v_b, nl); DALLOC(ctx->pressure_b, nl);
   DALLOC(d.oid, nl); DALLOC(ctx->oid_b, nl); DALLOC(d.where, nl);
   DALLOC(d.d_vel, nl); DALLOC(d.d_omega, nl); DALLOC(d.normal, nl);
   DALLOC(d.cg_r, nl); DALLOC(d.cg_dir, nl); DALLOC(d.cg_Ad, nl); DALLOC(d.cg_s, nl);
   DALLOC(d.minv0, nl); DALLOC(d.minv1, nl); DALLOC(d.minv2, nl);
   DALLOC(d.rho, nl); DALLOC(d.adv_rho, nl); DALLOC(d.pressure, nl); DALLOC(d.vel_max, nl); DALLOC(d.alpha, nl); DALLOC(d.kbuf, nl);
   DALLOC(d.ncount, nl); DALLOC(d.ncl, nl); DALLOC(d.ncs, nl); DALLOC(d.pk, nl);
+  DALLOC(d.d_vel_pre, nl); DALLOC(d.pos_star, nl); DALLOC(d.vel_star, nl); DALLOC(d.d_ii, nl); DALLOC(d.dij_pj, nl);
+  DALLOC(d.a_ii, nl); DALLOC(d.pressure_pre, nl);
   d.nbr_stride = (int)((nl + 63) / 64 * 64);
-  d.nbr_cap = p->max_neighbour < 128 ? p->max_neighbour : 128;
+  d.nbr_cap = p->list_cap > 0 ? p->list_cap : 128;
+  if (d.nbr_cap > p->max_neighbour) d.nbr_cap = p->max_neighbour;
+  d.nbr_cap = (d.nbr_cap + 7) & ~7;
   if (d.nbr_cap < 1) d.nbr_cap = 1;
   DALLOC(d.nbr_l, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.nbr_s, (size_t)d.nbr_stride * d.nbr_cap);
-  DALLOC(d.nbr16, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.cnt16, nl);
+  if (ctx->use_tiles) { DALLOC(d.nbr16, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.cnt16, nl); }
   DALLOC(d.spos, (size_t)d.ns);
   DALLOC(d.acc, 8); DALLOC(d.flags, 4);
   size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
@@ -329,13 +335,13 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l);
   if (rc) return rc;
   if (d.nl > 0) {
-    SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.oid,
-                     ctx->pos_b, ctx->vel_b, ctx->vel_guess_b, ctx->omega_b, ctx->kappa_b, ctx->kappa_v_b, ctx->oid_b, d.where};
+    SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.pressure, d.oid,
+                     ctx->pos_b, ctx->vel_b, ctx->vel_guess_b, ctx->omega_b, ctx->kappa_b, ctx->kappa_v_b, ctx->pressure_b, ctx->oid_b, d.where};
     hipLaunchKernelGGL(k_scatter_liquid, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, b, (const int *)d.cs_l, (const int *)ctx->pw,
                        (const int *)ctx->slot);
     std::swap(d.pos, ctx->pos_b); std::swap(d.vel, ctx->vel_b); std::swap(d.vel_guess, ctx->vel_guess_b);
     std::swap(d.omega, ctx->omega_b); std::swap(d.kappa, ctx->kappa_b); std::swap(d.kappa_v, ctx->kappa_v_b);
-    std::swap(d.oid, ctx->oid_b);
+    std::swap(d.oid, ctx->oid_b); std::swap(d.pressure, ctx->pressure_b);
   }
   // raw neighbour-list length (HashGrid.neighborCount)
   if (d.faithful) {
@@ -393,6 +399,13 @@ static FieldDesc field_desc(wcsph_ctx *ctx, int f) {
     case WCSPH_F_CG_MINV: return {9, nullptr};
     case WCSPH_F_NEIGHBOR_COUNT: return {-1, d.ncount};
     case WCSPH_F_KBUF: return {1, d.kbuf};
+    case WCSPH_F_D_VEL_PRE: return {3, d.d_vel_pre};
+    case WCSPH_F_POS_STAR: return {3, d.pos_star};
+    case WCSPH_F_VEL_STAR: return {3, d.vel_star};
+    case WCSPH_F_D_II: return {3, d.d_ii};
+    case WCSPH_F_DIJ_PJ: return {3, d.dij_pj};
+    case WCSPH_F_A_II: return {1, d.a_ii};
+    case WCSPH_F_PRESSURE_PRE: return {1, d.pressure_pre};
   }
   return {0, nullptr};
 }
@@ -498,6 +511,7 @@ int wcsph_get_scalar(wcsph_ctx *ctx, int id, float *v) {
     case WCSPH_S_TENSION: *v = ctx->d.tension; break;
     case WCSPH_S_TENSION_B: *v = ctx->d.tension_b; break;
     case WCSPH_S_VEL_MAX0: *v = ctx->vel_max0; break;
+    case WCSPH_S_RHO_ERR: *v = ctx->rho_err; break;
     default: return ctx->fail(WCSPH_EARG, "unknown scalar id");
   }
   return WCSPH_OK;
@@ -837,6 +851,155 @@ int wcsph_sesph_step(wcsph_ctx *ctx) {
   if ((rc = wcsph_sesph_pressure(ctx))) return rc;
   if ((rc = wcsph_sesph_force(ctx))) return rc;
   return wcsph_sesph_integrate(ctx);
+}
+
+// ---- pcisph.py ----------------------------------------------------------------------------------
+int wcsph_pcisph_reset_param(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_pc_reset); ctx->dt = 0.001f; return WCSPH_OK; }
+int wcsph_pcisph_compute_nonpressure_force(wcsph_ctx *ctx) {
+  NEED_GRID();
+  SPASS(k_ss_density);   // rho_i = (VL0 (W0 + sum) + VS0 sum_s) rho_0, pcisph.py:203,212,215
+  SPASS(k_pc_force, ctx->p.pc_visc, ctx->p.pc_visc_b);
+  return WCSPH_OK;
+}
+int wcsph_pcisph_init_iter_info(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_pc_init_iter); return WCSPH_OK; }
+int wcsph_pcisph_update_iter_info(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  ELEM(k_pc_update_iter, ctx->dt);
+  ctx->rho_err = 0.0f;
+  return WCSPH_OK;
+}
+int wcsph_pcisph_predict_density(wcsph_ctx *ctx) {
+  NEED_GRID();
+  int rc = zero_acc(ctx, ACC_ERR);
+  if (rc) return rc;
+  SPASS(k_pc_predict, ctx->dt, ctx->p.pci_coff);
+  SPASS(k_pc_pressure_force);
+  if ((rc = pull_scalars(ctx))) return rc;
+  ctx->rho_err = (float)((double)ctx->rho_err + ctx->h_acc[ACC_ERR]);
+  return WCSPH_OK;
+}
+int wcsph_pcisph_update_pos(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_pc_update_pos, ctx->dt); return WCSPH_OK; }
+int wcsph_pcisph_solve_pressure(wcsph_ctx *ctx) {  // ref: pcisph.py:147-157
+  NEED_GRID();
+  int rc;
+  ctx->pr_iter = 0;
+  double err = 0.0;
+  if ((rc = wcsph_pcisph_init_iter_info(ctx))) return rc;
+  while ((err > 0.01 || ctx->pr_iter < 3) && ctx->pr_iter < 50) {
+    if ((rc = wcsph_pcisph_update_iter_info(ctx))) return rc;
+    if ((rc = wcsph_pcisph_predict_density(ctx))) return rc;
+    err = (double)ctx->rho_err / (double)ctx->d.n_owned;
+    ctx->pr_iter++;
+  }
+  return WCSPH_OK;
+}
+int wcsph_pcisph_step(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  int rc;
+  if ((rc = wcsph_grid_update(ctx))) return rc;
+  if ((rc = wcsph_pcisph_compute_nonpressure_force(ctx))) return rc;
+  if ((rc = wcsph_pcisph_solve_pressure(ctx))) return rc;
+  return wcsph_pcisph_update_pos(ctx);
+}
+
+// ---- iisph.py -------------------------------------------------------------------------------------
+static Dev iisph_view(const wcsph_ctx *ctx) {   // sesph kernel constants + the script's own viscosity setup
+  Dev s = sesph_view(ctx);
+  s.visc = ctx->p.ii_visc; s.visc_b = ctx->p.ii_visc_b; s.mass = ctx->p.ss_mass; s.rho_S0 = ctx->p.ss_rho0;
+  s.VS0 = ctx->p.ss_VS0; s.dim_coff = ctx->p.ss_dim;
+  return s;
+}
+#define IPASS(kern, ...)                                                                          \
+  do {                                                                                            \
+    Dev iv_ = iisph_view(ctx);                                                                    \
+    if (iv_.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk8(iv_.nl)), dim3(BLOCK), 0, ctx->stream, iv_, ##__VA_ARGS__); \
+    LAUNCHCHK();                                                                                  \
+  } while (0)
+int wcsph_iisph_reset_param(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_reset); ctx->dt = 0.001f; return WCSPH_OK; }
+int wcsph_iisph_compute_density(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_density); return WCSPH_OK; }
+int wcsph_iisph_visc_init(wcsph_ctx *ctx) {
+  NEED_GRID();
+  ELEM(k_visc_guess);
+  int rc = zero_acc(ctx, ACC_DZERO);
+  if (rc) return rc;
+  IPASS(k_visc_minv_residual, ctx->dt);
+  if ((rc = pull_scalars(ctx))) return rc;
+  ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
+  ctx->cg_delta = ctx->cg_delta_zero;
+  return WCSPH_OK;
+}
+int wcsph_iisph_visc_iter(wcsph_ctx *ctx) {
+  NEED_GRID();
+  int rc = zero_acc(ctx, ACC_DAD);
+  if (rc) return rc;
+  IPASS(k_visc_Ad, ctx->dt);
+  if ((rc = zero_acc(ctx, ACC_DNEW))) return rc;
+  ELEM(k_visc_update, ctx->cg_delta);
+  ELEM(k_visc_dir, ctx->cg_delta);
+  if ((rc = pull_scalars(ctx))) return rc;
+  ctx->cg_delta_old = ctx->cg_delta;
+  ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+  return WCSPH_OK;
+}
+int wcsph_iisph_combine_nonpressure(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ii_combine, ctx->dt); return WCSPH_OK; }
+int wcsph_iisph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: iisph.py:114-127
+  NEED_GRID();
+  int rc;
+  if ((rc = wcsph_iisph_visc_init(ctx))) return rc;
+  ctx->vs_iter = 0;
+  while (ctx->vs_iter < 100) {
+    if ((rc = wcsph_iisph_visc_iter(ctx))) return rc;
+    ctx->vs_iter++;
+    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero ||
+        (double)ctx->cg_delta_zero < (double)ctx->p.eps)
+      break;
+  }
+  return wcsph_iisph_combine_nonpressure(ctx);
+}
+int wcsph_iisph_compute_advection(wcsph_ctx *ctx) {
+  NEED_GRID();
+  SPASS(k_ii_dii, ctx->dt);
+  SPASS(k_ii_aii, ctx->dt);
+  return WCSPH_OK;
+}
+int wcsph_iisph_update_iter_info(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ii_dijpj); ctx->avg_density_err = 0.0f; return WCSPH_OK; }
+int wcsph_iisph_update_pressure_force(wcsph_ctx *ctx) {
+  NEED_GRID();
+  int rc = zero_acc(ctx, ACC_ERR);
+  if (rc) return rc;
+  SPASS(k_ii_pressure, ctx->dt, ctx->p.ii_omega);
+  if ((rc = pull_scalars(ctx))) return rc;
+  ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+  return WCSPH_OK;
+}
+int wcsph_iisph_solve_pressure(wcsph_ctx *ctx) {  // ref: iisph.py:130-139
+  NEED_GRID();
+  int rc;
+  ctx->pr_iter = 0;
+  double err = 0.0;
+  while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
+    if ((rc = wcsph_iisph_update_iter_info(ctx))) return rc;
+    if ((rc = wcsph_iisph_update_pressure_force(ctx))) return rc;
+    err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
+    ctx->pr_iter++;
+  }
+  return WCSPH_OK;
+}
+int wcsph_iisph_update_pos(wcsph_ctx *ctx) {
+  NEED_GRID();
+  SPASS(k_ii_pressure_accel);
+  ELEM(k_ss_integrate, ctx->dt);
+  return WCSPH_OK;
+}
+int wcsph_iisph_step(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  int rc;
+  if ((rc = wcsph_grid_update(ctx))) return rc;
+  if ((rc = wcsph_iisph_compute_density(ctx))) return rc;
+  if ((rc = wcsph_iisph_compute_nonpressure_force(ctx))) return rc;
+  if ((rc = wcsph_iisph_compute_advection(ctx))) return rc;
+  if ((rc = wcsph_iisph_solve_pressure(ctx))) return rc;
+  return wcsph_iisph_update_pos(ctx);
 }
 
 // ---- explicit neighbour list (debug / API parity) ----------------------------------------------
