@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3", help="C2 | C3 | default | an integer particleDim")
     ap.add_argument("--mode", default="faithful", choices=["faithful", "clean"])
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-n", type=int, default=46)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
