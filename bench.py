@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-n", type=int, default=46)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-clean", action="store_true", help="skip the clean-mode companion run")
     ap.add_argument("--kernel-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -142,10 +143,24 @@ def main():
                      "traffic": traffic, "avg_launch_us": round(ms.value * 1e3, 1),
                      "algorithmic_bytes_per_launch": int(alg_bytes), "other_kernels": extra},
     }
+    pd.close()
+    if args.mode == "faithful" and not args.no_clean:
+        # the N > 1 slab runs use clean neighbour semantics: same workload, same step count, for a
+        # like-for-like reading of the multi-GPU numbers
+        dfsph2, pd2, _ = build_sim(n, "clean")
+        for _ in range(args.warmup):
+            dfsph2.step()
+        pd2.sync(); tsync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dfsph2.step()
+        pd2.sync(); tsync()
+        el2 = time.perf_counter() - t0
+        out["config"]["clean_mode"] = {"value": round(nl * args.steps / el2 / 1e6, 3), "ms_per_step": round(el2 / args.steps * 1e3, 3)}
+        pd2.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
     print(json.dumps(out))
-    pd.close()
 
 
 if __name__ == "__main__":

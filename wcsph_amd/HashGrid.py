@@ -118,7 +118,7 @@ class HashGrid:
             return ((v + 2 ** 31) % 2 ** 32) - 2 ** 31
         p1, p2, p3 = wrap(73856093 * a[..., 0]), wrap(19349663 * a[..., 1]), wrap(83492791 * a[..., 2])
         x = (p1.astype(np.int32) ^ p2.astype(np.int32) ^ p3.astype(np.int32)).astype(np.int64)
-        n = self.particle_data.count
+        n = self.particle_data.hash_table_size or self.particle_data.count
         return np.mod(x, n)  # numpy mod is already the non-negative residue
 
     def check_in_box(self, index):
@@ -132,4 +132,5 @@ class HashGrid:
         pos = self.particle_data.pos.to_numpy()
         cells = self._cells(pos)
         inb = self.check_in_box(cells).astype(bool)
-        return np.bincount(self.get_cell_hash(cells[inb]), minlength=self.particle_data.count).astype(np.int32)
+        n = self.particle_data.hash_table_size or self.particle_data.count
+        return np.bincount(self.get_cell_hash(cells[inb]), minlength=n).astype(np.int32)

@@ -732,8 +732,7 @@ int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx) {
 int wcsph_dfsph_update_vel(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_update_vel, ctx->dt); return WCSPH_OK; }
 int wcsph_dfsph_update_pos(wcsph_ctx *ctx) {
   NEED_SETUP();
-  ELEM(k_update_pos, ctx->dt);
-  ctx->grid_valid = ctx->grid_valid;  // cells go stale, but the reference also keeps using the step's lists
+  ELEM(k_update_pos, ctx->dt);  // cells and lists go stale; like the reference's they stay in use until update_grid()
   return WCSPH_OK;
 }
 
