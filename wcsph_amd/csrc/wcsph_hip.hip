@@ -719,6 +719,9 @@ int wcsph_dfsph_vorticity(wcsph_ctx *ctx) {
 
 int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx) {
   NEED_SETUP();
+  // ref: dfsph.py:108-111 `while size < particleLiquidNum`: with a single liquid particle the reference launches
+  // nothing, vel_max[0] keeps its initial 0 and the time step is never adapted
+  if (ctx->d.faithful && ctx->d.nl <= 1) { ctx->vel_max0 = 0.0f; return WCSPH_OK; }
   HIPCHK(hipMemsetAsync(ctx->d.flags + FLAG_VMAX, 0, sizeof(int), ctx->stream));
   ELEM(k_cfl, ctx->dt);
   hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(1), 0, ctx->stream, ctx->d);
