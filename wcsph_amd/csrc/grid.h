@@ -23,16 +23,62 @@ __device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin) {
   return in ? (cx | (cy << 10) | (cz << 20)) : -1;
 }
 
-// phase 1 of the counting sort (ref: HashGrid.py:67-76 "insert pos"): cell of every particle, slot in cell
-__global__ void k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount) {
+// phase 1 of the counting sort (ref: HashGrid.py:67-76 "insert pos"): cell of every particle, slot in cell.
+// bbox != nullptr: also this block's bounding box of the occupied cells -> bbox[6 * blockIdx.x ..] (no atomics: the
+// particles are x-sorted, so a shared max would be raised by nearly every block); k_bbox_final reduces them.
+__global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pos[i];
-  int lin;
-  int w = cell_packed(d, xyz(p), &lin);
-  pw[i] = w;
-  slot[i] = atomicAdd(&cnt[lin], 1);
-  if (bcount && w >= 0) atomicAdd(&bcount[ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+  if (i < n) {
+    float4 p = pos[i];
+    int lin;
+    int w = cell_packed(d, xyz(p), &lin);
+    pw[i] = w;
+    slot[i] = atomicAdd(&cnt[lin], 1);
+    if (w >= 0) {
+      if (bcount) atomicAdd(&bcount[ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+      lo[0] = hi[0] = w & 1023; lo[1] = hi[1] = (w >> 10) & 1023; lo[2] = hi[2] = w >> 20;
+    }
+  }
+  if (!bbox) return;
+  __shared__ int slo[3][BLOCK / WAVE], shi[3][BLOCK / WAVE];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_down(lo[a], o, WAVE)); hi[a] = max(hi[a], __shfl_down(hi[a], o, WAVE)); }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { slo[a][threadIdx.x / WAVE] = lo[a]; shi[a][threadIdx.x / WAVE] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    int l = slo[a][0], h = shi[a][0];
+#pragma unroll
+    for (int k = 1; k < BLOCK / WAVE; k++) { l = min(l, slo[a][k]); h = max(h, shi[a][k]); }
+    bbox[6 * blockIdx.x + a] = l;
+    bbox[6 * blockIdx.x + 3 + a] = h;
+  }
+}
+// one block: reduce the per-block boxes of k_cell_assign into out[6] = {xmin,ymin,zmin,xmax,ymax,zmax} (max < 0: empty)
+__global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out) {
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+  for (int b = threadIdx.x; b < nparts; b += BLOCK)
+#pragma unroll
+    for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], part[6 * b + a]); hi[a] = max(hi[a], part[6 * b + 3 + a]); }
+  __shared__ int slo[3][BLOCK / WAVE], shi[3][BLOCK / WAVE];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_down(lo[a], o, WAVE)); hi[a] = max(hi[a], __shfl_down(hi[a], o, WAVE)); }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { slo[a][threadIdx.x / WAVE] = lo[a]; shi[a][threadIdx.x / WAVE] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    int l = slo[a][0], h = shi[a][0];
+#pragma unroll
+    for (int k = 1; k < BLOCK / WAVE; k++) { l = min(l, slo[a][k]); h = max(h, shi[a][k]); }
+    out[a] = l; out[3 + a] = h;
+  }
 }
 
 __device__ __forceinline__ int lin_of(const Dev &d, int w) {
@@ -99,7 +145,19 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
   *total = tot;
   return off + inc - v;
 }
-__global__ void k_scan_reduce(const int *in, int n, int *bsum) {
+// Scan blocks wholly outside the cell columns [xmin-2, xmax+2] of the occupied box hold only zeros: their block sum
+// is written as 0 without reading, their outputs are left alone (nothing reads cells that far from every particle).
+// The last block (out-of-box bin, grand total) is always processed.  bbox == nullptr: everything.
+__device__ __forceinline__ bool scan_block_active(const int *bbox, int n, int col_cells) {
+  if (!bbox || (int)blockIdx.x == (n - 1) / SCAN_TILE) return true;
+  const int xmin = bbox[0], xmax = bbox[3];
+  if (xmax < 0) return false;
+  const long lo = (long)max(xmin - 2, 0) * col_cells, hi = (long)(xmax + 3) * col_cells + 1;
+  const long b0 = (long)blockIdx.x * SCAN_TILE, b1 = b0 + SCAN_TILE;
+  return b1 > lo && b0 <= hi;
+}
+__global__ void k_scan_reduce(const int *in, int n, int *bsum, const int *bbox, int col_cells) {
+  if (!scan_block_active(bbox, n, col_cells)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int s = 0;
 #pragma unroll
@@ -124,7 +182,8 @@ __global__ void k_scan_bsums(int *bsum, int nb) {  // one block
     __syncthreads();
   }
 }
-__global__ void k_scan_final(const int *in, int n, const int *bsum, int *out) {
+__global__ void k_scan_final(const int *in, int n, const int *bsum, int *out, const int *bbox, int col_cells) {
+  if (!scan_block_active(bbox, n, col_cells)) return;
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int v[SCAN_PER_THREAD], s = 0;
 #pragma unroll
@@ -205,59 +264,47 @@ __global__ void __launch_bounds__(ALIAS_TB) k_alias_fill(Dev d, const int *cell_
 // ---- raw list length (HashGrid.neighborCount) --------------------------------------------
 // faithful: count_i = sum over the in-box walked cells c of gridCount[hash(c)]  -  (visits of the own bucket)
 // (ref: HashGrid.py:79-106).  cellval[c] = gridCount[hash(c)], then a separable 5x5x5 box sum.
-// Only cells whose (x,y) column lies within 2 columns of a column holding liquid can be walked by a liquid
-// particle, so the box filter runs on that sub-box (bb = {xmin, ymin, xmax, ymax} of the non-empty columns).
-__global__ void k_column_bbox(Dev d, int *bb) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int x = t / d.ny, y = t % d.ny;
-  bool ne = false;
-  if (t < d.nx * d.ny) { int base = t * d.nz; ne = d.cs_l[base + d.nz] > d.cs_l[base]; }
-  int xmin = ne ? x : 0x7fffffff, ymin = ne ? y : 0x7fffffff, xmax = ne ? x : -1, ymax = ne ? y : -1;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    xmin = min(xmin, __shfl_down(xmin, o, WAVE)); ymin = min(ymin, __shfl_down(ymin, o, WAVE));
-    xmax = max(xmax, __shfl_down(xmax, o, WAVE)); ymax = max(ymax, __shfl_down(ymax, o, WAVE));
-  }
-  if ((threadIdx.x & (WAVE - 1)) == 0 && xmax >= 0) {
-    atomicMin(&bb[0], xmin); atomicMin(&bb[1], ymin); atomicMax(&bb[2], xmax); atomicMax(&bb[3], ymax);
-  }
-}
-// thread index -> cell of the sub-box (margin columns around bb), or -1
-__device__ __forceinline__ int subbox_cell(const Dev &d, const int *bb, int margin, int t) {
-  const int x0 = max(bb[0] - margin, 0), y0 = max(bb[1] - margin, 0);
-  const int x1 = min(bb[2] + margin, d.nx - 1), y1 = min(bb[3] + margin, d.ny - 1);
-  if (x1 < x0 || y1 < y0) return -1;
-  const int sy = y1 - y0 + 1;
-  const int z = t % d.nz, q = t / d.nz;
+// Only cells within the walk radius of an occupied cell can be walked by a liquid particle, so the box filter
+// runs on the occupied box bb = {xmin,ymin,zmin,xmax,ymax,zmax} (k_cell_assign) grown by a per-pass margin.
+// thread index -> cell of that sub-box, or -1
+__device__ __forceinline__ int subbox_cell(const Dev &d, const int *bb, int mx, int my, int mz, int t) {
+  if (bb[3] < 0) return -1;
+  const int x0 = max(bb[0] - mx, 0), y0 = max(bb[1] - my, 0), z0 = max(bb[2] - mz, 0);
+  const int x1 = min(bb[3] + mx, d.nx - 1), y1 = min(bb[4] + my, d.ny - 1), z1 = min(bb[5] + mz, d.nz - 1);
+  const int sz = z1 - z0 + 1, sy = y1 - y0 + 1;
+  const int z = z0 + t % sz, q = t / sz;
   const int x = x0 + q / sy, y = y0 + q % sy;
   if (x > x1) return -1;
   return (x * d.ny + y) * d.nz + z;
 }
+// (fixed-size grids + grid-stride loops: the sub-box volume lives on the device)
 __global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags, const int *bb) {
-  int c = subbox_cell(d, bb, 4, blockIdx.x * blockDim.x + threadIdx.x);
-  if (c < 0) return;
-  int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
-  int v = bcount[ref_hash(cx + d.x0, cy, cz, d.table_size)];
-  if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);  // ref: HashGrid.py:72-74 cannot be reproduced
-  cellval[c] = v;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x;; t += gridDim.x * blockDim.x) {
+    int c = subbox_cell(d, bb, 2, 2, 2, t);
+    if (c < 0) return;
+    int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
+    cellval[c] = bcount[ref_hash(cx + d.x0, cy, cz, d.table_size)];
+  }
 }
 // bucket occupancy over ALL buckets (the cap applies to every bucket, not only walked ones)
 __global__ void k_bucket_cap(Dev d, const int *bcount, int *flags) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < d.table_size && bcount[b] > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
 }
-__global__ void k_boxsum(Dev d, const int *in, int *out, int len, int stride, const int *bb, int margin) {
+__global__ void k_boxsum(Dev d, const int *in, int *out, int len, int stride, const int *bb, int mx, int my) {
   // 5-tap sum along one axis; len = cells along the axis, stride = element stride of the axis
-  int c = subbox_cell(d, bb, margin, blockIdx.x * blockDim.x + threadIdx.x);
-  if (c < 0) return;
-  int a = (c / stride) % len;
-  int s = 0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x;; t += gridDim.x * blockDim.x) {
+    int c = subbox_cell(d, bb, mx, my, 0, t);
+    if (c < 0) return;
+    int a = (c / stride) % len;
+    int s = 0;
 #pragma unroll
-  for (int k = -2; k <= 2; k++) {
-    int q = a + k;
-    if (q >= 0 && q < len) s += in[c + k * stride];
+    for (int k = -2; k <= 2; k++) {
+      int q = a + k;
+      if (q >= 0 && q < len) s += in[c + k * stride];
+    }
+    out[c] = s;
   }
-  out[c] = s;
 }
 __global__ void k_ncount_faithful(Dev d, const int *boxsum) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -53,6 +53,8 @@ __global__ void k_tile_count(Dev d, int *tile_p) {
   int tz = t % d.ntz, ty = (t / d.ntz) % d.nty, tx = t / (d.ntz * d.nty);
   int z0 = tz * TILE_Z, z1 = min(z0 + TILE_Z, d.nz);
   int p = 0;
+  // the cell table is only scanned around the occupied columns (grid.h scan_block_active): tiles elsewhere are empty
+  if (d.bbox[3] < 0 || tx * TILE_X > d.bbox[3] + 1 || tx * TILE_X + TILE_X - 1 < d.bbox[0] - 1) { tile_p[t] = 0; return; }
   for (int ox = 0; ox < TILE_X; ox++) {
     int x = tx * TILE_X + ox;
     if (x >= d.nx) break;

@@ -30,7 +30,7 @@ struct wcsph_ctx {
   // grid scratch
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
   int *bcount = nullptr, *bcount_s = nullptr, *cellval = nullptr, *celltmp = nullptr;
-  int *tile_p = nullptr;
+  int *tile_p = nullptr, *bbox_part = nullptr;
   int tile_blocks1 = 1024, tile_blocks2 = 512;  // persistent grids: 4 / 2 workgroups per CU (LDS bound)
   bool use_tiles = false;  // LDS-tiled iteration passes (tile.h); experimental, WCSPH_TILES=1
   int n_alias = 0, scan_blocks = 0;
@@ -211,11 +211,12 @@ int wcsph_sync(wcsph_ctx *ctx) {
   return pull_scalars(ctx);
 }
 
-static int run_scan(wcsph_ctx *ctx, const int *in, int n, int *out) {
+static int run_scan(wcsph_ctx *ctx, const int *in, int n, int *out, const int *bbox) {
   int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum);
+  const int col = ctx->d.ny * ctx->d.nz;
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, bbox, col);
   hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->bsum, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out, bbox, col);
   LAUNCHCHK();
   return 0;
 }
@@ -247,7 +248,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   DALLOC(d.cell_info, d.ncell);
   d.ntx = (d.nx + TILE_X - 1) / TILE_X; d.nty = (d.ny + TILE_Y - 1) / TILE_Y; d.ntz = (d.nz + TILE_Z - 1) / TILE_Z;
   d.ntile = d.ntx * d.nty * d.ntz;
-  DALLOC(d.tile_list, d.ntile); DALLOC(d.tile_qoff, d.ntile); DALLOC(d.tile_meta, 8); DALLOC(ctx->tile_p, d.ntile);
+  DALLOC(d.tile_list, d.ntile); DALLOC(d.tile_qoff, d.ntile); DALLOC(d.tile_meta, 8); DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1)); DALLOC(ctx->tile_p, d.ntile);
   {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -281,9 +282,9 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
     HIPCHK(hipMemcpyAsync(spos_in, tmp.data(), (size_t)d.ns * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->cnt, 0, (size_t)nscan * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.ns)), dim3(BLOCK), 0, ctx->stream, d, (const float4 *)spos_in, d.ns, ctx->cnt,
-                       ctx->pw, ctx->slot, d.faithful ? ctx->bcount_s : (int *)nullptr);
+                       ctx->pw, ctx->slot, d.faithful ? ctx->bcount_s : (int *)nullptr, (int *)nullptr);
     LAUNCHCHK();
-    int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_s);
+    int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_s, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(k_scatter_solid, dim3(nblk(d.ns)), dim3(BLOCK), 0, ctx->stream, d, (const float4 *)spos_in, d.spos, d.cs_s,
                        ctx->pw, ctx->slot);
@@ -331,8 +332,9 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   if (d.faithful) HIPCHK(hipMemcpyAsync(ctx->bcount, ctx->bcount_s, (size_t)d.table_size * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
-                       d.faithful ? ctx->bcount : (int *)nullptr);
-  int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l);
+                       d.faithful ? ctx->bcount : (int *)nullptr, ctx->bbox_part);
+  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
+  int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox);
   if (rc) return rc;
   if (d.nl > 0) {
     SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.pressure, d.oid,
@@ -345,17 +347,14 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   }
   // raw neighbour-list length (HashGrid.neighborCount)
   if (d.faithful) {
-    int *bb = d.tile_meta + 4;  // {xmin, ymin, xmax, ymax} of the liquid-bearing cell columns
-    HIPCHK(hipMemsetAsync(bb, 0x7f, 2 * sizeof(int), s));
-    HIPCHK(hipMemsetAsync(bb + 2, 0xff, 2 * sizeof(int), s));
-    hipLaunchKernelGGL(k_column_bbox, dim3(nblk(d.nx * d.ny)), dim3(BLOCK), 0, s, d, bb);
+    const int *bb = d.bbox;
     hipLaunchKernelGGL(k_bucket_cap, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, d.flags);
-    // separable 5x5x5 box sum of gridCount[hash(cell)]: the z pass needs +-2 columns in x AND y around the liquid
-    // columns (margin 4 covers both later passes), the y pass +-2 in x, the x pass the liquid columns themselves
-    hipLaunchKernelGGL(k_cellval, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags, (const int *)bb);
-    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nz, 1, (const int *)bb, 4);
-    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp, ctx->cellval, d.ny, d.nz, (const int *)bb, 2);
-    hipLaunchKernelGGL(k_boxsum, dim3(nblk(d.ncell)), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nx, d.ny * d.nz, (const int *)bb, 0);
+    // separable 5x5x5 box sum of gridCount[hash(cell)] on the occupied box: values on box +-2 in every axis, the z pass
+    // on box +-2 in x and y, the y pass on box +-2 in x, the x pass on the box itself
+    hipLaunchKernelGGL(k_cellval, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags, bb);
+    hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nz, 1, bb, 2, 2);
+    hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp, ctx->cellval, d.ny, d.nz, bb, 2, 0);
+    hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nx, d.ny * d.nz, bb, 0, 0);
     if (d.nl > 0) hipLaunchKernelGGL(k_ncount_faithful, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp);
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
