@@ -158,6 +158,20 @@ def main():
         el2 = time.perf_counter() - t0
         out["config"]["clean_mode"] = {"value": round(nl * args.steps / el2 / 1e6, 3), "ms_per_step": round(el2 / args.steps * 1e3, 3)}
         pd2.close()
+    if args.config == "C3" and not args.no_clean:
+        # BASELINE.json configs[1] (C2, ~100 k particles) for reference: too small to fill 256 CUs, launch-bound
+        d3, p3, _ = build_sim(scene.CONFIGS["C2"], args.mode)
+        for _ in range(args.warmup):
+            d3.step()
+        p3.sync(); tsync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d3.step()
+        p3.sync(); tsync()
+        el3 = time.perf_counter() - t0
+        out["config"]["C2_100k"] = {"value": round(p3.liquid_count * args.steps / el3 / 1e6, 3), "ms_per_step": round(el3 / args.steps * 1e3, 3),
+                                    "n_liquid": p3.liquid_count}
+        p3.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
     print(json.dumps(out))

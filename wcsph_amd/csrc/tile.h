@@ -12,7 +12,7 @@
 #include "device.h"
 
 #define TILE_X 8
-#define TILE_Y 8
+#define TILE_Y 4
 #define TILE_Z 12
 #define T_HALO 2
 #define T_RX (TILE_X + 2 * T_HALO)
@@ -20,9 +20,9 @@
 #define T_NROW (T_RX * T_RY)          /* 144 staged rows */
 #define T_RZ (TILE_Z + 2 * T_HALO)    /* cells per staged row */
 #define T_OWN (TILE_X * TILE_Y)       /* 64 rows whose particles this tile updates */
-#define T_CAP 3456                    /* staged liquid particles per tile (1.5 per staged cell; rest density is 1.25) */
-#define TBLOCK 1024                   /* threads per tile workgroup: ~960 own particles at rest density */
-static_assert(T_NROW <= TBLOCK && T_OWN == 64, "row tables are built by one pass of the block");
+#define T_CAP 2304                    /* staged liquid particles per tile (1.5 per staged cell; rest density is 1.25) */
+#define TBLOCK 512                    /* threads per tile workgroup: ~480 own particles at rest density */
+static_assert(T_NROW <= TBLOCK && (T_OWN & (T_OWN - 1)) == 0, "row tables are built by one pass of the block");
 
 struct TileTables {
   int row_lo[T_NROW];        // first sorted particle of the staged row
@@ -58,6 +58,7 @@ __global__ void k_tile_count(Dev d, int *tile_p) {
   for (int ox = 0; ox < TILE_X; ox++) {
     int x = tx * TILE_X + ox;
     if (x >= d.nx) break;
+    if (x < d.bbox[0] - 2 || x > d.bbox[3] + 2) continue;
     for (int oy = 0; oy < TILE_Y; oy++) {
       int y = ty * TILE_Y + oy;
       if (y >= d.ny) break;
@@ -117,7 +118,8 @@ __device__ __forceinline__ void tile_tables(const Dev &d, TileTables &tt, int sl
   const int rx = tid / T_RY, ry = tid % T_RY;
   const int x = tx0 - T_HALO + rx, y = ty0 - T_HALO + ry;
   const int ox = rx - T_HALO, oy = ry - T_HALO;
-  const bool isrow = tid < T_NROW && (unsigned)x < (unsigned)d.nx && (unsigned)y < (unsigned)d.ny;
+  // columns further than 2 from every occupied column are empty AND not covered by the cell-table scan (grid.h)
+  const bool isrow = tid < T_NROW && (unsigned)x < (unsigned)d.nx && (unsigned)y < (unsigned)d.ny && x >= d.bbox[0] - 2 && x <= d.bbox[3] + 2;
   const bool isown = isrow && (unsigned)ox < TILE_X && (unsigned)oy < TILE_Y;
   int lo = 0, hi = 0, olo = 0, ohi = 0;
   if (isrow) {
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(TBLOCK) kt_build_lists(Dev d) {
         const int r = e / (T_RZ + 1), zc = e % (T_RZ + 1);
         const int x = tt.tx0 - T_HALO + r / T_RY, y = tt.ty0 - T_HALO + r % T_RY;
         int v = tt.row_off[r];
-        if ((unsigned)x < (unsigned)d.nx && (unsigned)y < (unsigned)d.ny) {
+        if ((unsigned)x < (unsigned)d.nx && (unsigned)y < (unsigned)d.ny && x >= d.bbox[0] - 2 && x <= d.bbox[3] + 2) {
           const int z = min(max(tt.tz0 - T_HALO + zc, 0), d.nz);
           v += d.cs_l[(x * d.ny + y) * d.nz + z] - tt.row_lo[r];
           v = min(max(v, tt.row_off[r]), tt.row_off[r + 1]);

@@ -252,7 +252,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    ctx->tile_blocks1 = ((cus * 2 + 7) / 8) * 8; ctx->tile_blocks2 = ((cus + 7) / 8) * 8;  // 55 / 110 KB LDS per workgroup
+    ctx->tile_blocks1 = ((cus * 4 + 7) / 8) * 8; ctx->tile_blocks2 = ((cus * 2 + 7) / 8) * 8;  // 37 / 74 KB LDS per workgroup
   }
   if (d.faithful) {
     DALLOC(ctx->bcount, d.table_size); DALLOC(ctx->bcount_s, d.table_size);
