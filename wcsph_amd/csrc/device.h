@@ -56,6 +56,7 @@ struct Dev {
   // LDS tiles (tile.h): active-tile list of the step, tile-local 16-bit neighbour lists
   int ntx, nty, ntz, ntile;
   int *tile_list, *tile_qoff, *tile_meta; // [ntile] tile ids / first list slot; meta[0] = active tiles
+  int tile_ablate;                        // experiments: 1 = stage only, 2 = compute only (WCSPH_TILE_ABLATE)
   int *bbox;                              // [6] {xmin,ymin,zmin,xmax,ymax,zmax} of the in-box liquid cells of this step
   uint16_t *nbr16, *cnt16;                // [nbr_cap][nbr_stride] staged indices, [nl] entries
   // solids, cell-sorted once

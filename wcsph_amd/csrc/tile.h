@@ -1,5 +1,6 @@
 // tile.h -- LDS-staged neighbour passes.
 //
+// EXPERIMENTAL (off by default, WCSPH_TILES=1; DESIGN.md 4 has the measurements: it does not beat the list path).
 // A workgroup owns one TILE of TILE_X x TILE_Y x TILE_Z hash cells.  It stages the tile plus a 2-cell
 // halo (the 5x5x5 walk radius, ref: HashGrid.py:82-85) into LDS as float4 records with coalesced loads:
 // in the z-fastest cell order every (x,y) row of the staged box is ONE contiguous particle range, so the
@@ -153,6 +154,7 @@ __device__ __forceinline__ bool tile_stage(const Dev &d, const TileTables &tt, f
     return false;
   }
   const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+  if (d.tile_ablate == 2) { __syncthreads(); return true; }   // experiment: compute phase only
 #pragma unroll
   for (int r = g; r < T_NROW; r += TBLOCK / 16) {   // 64 row groups of 16 lanes: 144 rows in 3 sweeps
     const int lo = tt.row_lo[r], off = tt.row_off[r], len = tt.row_off[r + 1] - off;
@@ -307,13 +309,13 @@ __global__ void __launch_bounds__(TBLOCK) kt_build_lists(Dev d) {
 // ---- the solver-iteration passes on tiles ----------------------------------------------------------------------------
 // ref: dfsph.py:460-471 / 529-541 / 420-439 (see k_vel_from_k): A.w carries k_j
 template <int COND>
-__global__ void __launch_bounds__(TBLOCK) kt_vel_from_k(Dev d, const float *kb, float dt) {
+__global__ void __launch_bounds__(TBLOCK, 4) kt_vel_from_k(Dev d, const float *kb, float dt) {
   __shared__ TileTables tt;
   __shared__ float4 sA[T_CAP];
   TILE_LOOP_BEGIN
     tile_tables(d, tt, slot_);
     if (tile_stage<1>(d, tt, sA, nullptr, nullptr, kb, nullptr, nullptr, nullptr)) {
-      const int P = tt.own_off[T_OWN];
+      const int P = d.tile_ablate == 1 ? 0 : tt.own_off[T_OWN];   // experiment: staging phase only
       for (int p = threadIdx.x; p < P; p += TBLOCK) {
         const TileParticle tp = tile_particle(tt, p);
         if (d.oid[tp.i] >= d.n_owned) continue;
@@ -341,7 +343,7 @@ __global__ void __launch_bounds__(TBLOCK) kt_vel_from_k(Dev d, const float *kb, 
 
 // ref: dfsph.py:394-412 (see k_drho_press) and :374-392 (k_drho_div): B = vel
 template <int MODE, int DIV>
-__global__ void __launch_bounds__(TBLOCK) kt_drho(Dev d, float dt) {
+__global__ void __launch_bounds__(TBLOCK, 4) kt_drho(Dev d, float dt) {
   __shared__ TileTables tt;
   __shared__ float4 sA[T_CAP];
   __shared__ float4 sB[T_CAP];
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(TBLOCK) kt_drho(Dev d, float dt) {
   TILE_LOOP_BEGIN
     tile_tables(d, tt, slot_);
     if (tile_stage<2>(d, tt, sA, sB, nullptr, nullptr, d.vel, nullptr, nullptr)) {
-      const int P = tt.own_off[T_OWN];
+      const int P = d.tile_ablate == 1 ? 0 : tt.own_off[T_OWN];
       for (int p = threadIdx.x; p < P; p += TBLOCK) {
         const TileParticle tp = tile_particle(tt, p);
         const int i = tp.i;

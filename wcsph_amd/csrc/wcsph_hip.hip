@@ -32,6 +32,7 @@ struct wcsph_ctx {
   int *bcount = nullptr, *bcount_s = nullptr, *cellval = nullptr, *celltmp = nullptr;
   int *tile_p = nullptr, *bbox_part = nullptr;
   int tile_blocks1 = 1024, tile_blocks2 = 512;  // persistent grids: 4 / 2 workgroups per CU (LDS bound)
+  int tile_ablate_env = 0;
   bool use_tiles = false;  // LDS-tiled iteration passes (tile.h); experimental, WCSPH_TILES=1
   int n_alias = 0, scan_blocks = 0;
   // staging for original-order transfers
@@ -133,6 +134,8 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
   ctx->capacity = p->n_liquid;
   { const char *e = getenv("WCSPH_TILES"); ctx->use_tiles = e && e[0] == '1'; }
+  { const char *e = getenv("WCSPH_TILE_ABLATE"); ctx->tile_ablate_env = e ? atoi(e) : 0; }
+  ctx->d.tile_ablate = ctx->tile_ablate_env;
   d.faithful = (p->neighbor_mode == WCSPH_MODE_FAITHFUL);
   d.table_size = p->hash_table_size > 0 ? p->hash_table_size : (p->n_liquid + p->n_solid);
   if (d.table_size < 1) d.table_size = 1;
