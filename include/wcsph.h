@@ -84,6 +84,9 @@ enum wcsph_field {
   WCSPH_F_D_VEL_PRE, WCSPH_F_POS_STAR, WCSPH_F_VEL_STAR,   /* pcisph.py:52-54  [n_liquid][3] */
   WCSPH_F_D_II, WCSPH_F_DIJ_PJ,                            /* iisph.py:58-59   [n_liquid][3] */
   WCSPH_F_A_II, WCSPH_F_PRESSURE_PRE,                      /* iisph.py:57,60   [n_liquid] */
+  WCSPH_F_COLOR,       /* ParticleData.py:37   [n_liquid]        (after wcsph_surface_color_map) */
+  WCSPH_F_COLOR_GRAD, WCSPH_F_POS_AVR,                     /* ParticleData.py:38,40 [n_liquid][3] */
+  WCSPH_F_G,           /* ParticleData.py:41   [n_liquid][3][3]  (after wcsph_surface_anisotropic_kernel) */
   WCSPH_F__COUNT
 };
 
@@ -182,6 +185,10 @@ int wcsph_iisph_update_pressure_force(wcsph_ctx *ctx);      /* ref: iisph.py:336
 int wcsph_iisph_solve_pressure(wcsph_ctx *ctx);             /* ref: iisph.py:130-139 */
 int wcsph_iisph_update_pos(wcsph_ctx *ctx);                 /* ref: iisph.py:372-396 */
 int wcsph_iisph_step(wcsph_ctx *ctx);                       /* ref: iisph.py:419-428 */
+
+/* ---- ParticleData surface-reconstruction kernels ------------------------- */
+int wcsph_surface_color_map(wcsph_ctx *ctx);                          /* ref: ParticleData.py:187-215 compute_color_map */
+int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR); /* ref: ParticleData.py:220-289 cal_anistropic_kernel */
 
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Times `reps` back-to-back launches of one named kernel group with hipEvents on the context's

@@ -19,8 +19,8 @@ _SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_z
 _INTS = ["vs_iter", "dv_iter", "pr_iter", "overflow_grid", "overflow_neighbor", "table_size", "bs0", "bs1", "bs2",
          "tension_fixed", "mode", "n_reduce"]
 _VEC3 = ["vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s",
-         "d_vel_pre", "pos_star", "vel_star", "d_ii", "dij_pj"]
-_SCAL = ["rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "kbuf", "a_ii", "pressure_pre"]
+         "d_vel_pre", "pos_star", "vel_star", "d_ii", "dij_pj", "color_grad", "pos_avr"]
+_SCAL = ["rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "kbuf", "a_ii", "pressure_pre", "color"]
 _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff", "update_drho_divergence",
           "update_drho_pressure", "warmstart_divergence_vel", "begin_divergence_iter", "divergence_iter",
           "end_divergence_iter", "warmstart_pressure", "begin_pressure_iter", "pressure_iter", "end_pressure_iter",
@@ -40,7 +40,8 @@ _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff",
           "iisph_reset_param", "iisph_compute_density", "iisph_init_viscosity_para", "iisph_compute_viscosity_force",
           "iisph_combine_nonpressure", "iisph_compute_nonpressure_force", "iisph_compute_advection",
           "iisph_update_iter_info", "iisph_update_pressure_force", "iisph_solve_pressure", "iisph_update_pos",
-          "iisph_step"]
+          "iisph_step",
+          "compute_color_map", "cal_anistropic_kernel"]
 
 
 def build_oracle(force=False):
@@ -91,7 +92,7 @@ def _load():
         for s in _STEPS:
             getattr(lib, "orc_" + s).argtypes = [C.c_void_p]
             getattr(lib, "orc_" + s).restype = None
-        for f in _VEC3 + _SCAL + ["pos", "cg_Minv"]:
+        for f in _VEC3 + _SCAL + ["pos", "cg_Minv", "G"]:
             getattr(lib, "orc_ptr_" + f).argtypes = [C.c_void_p]
             getattr(lib, "orc_ptr_" + f).restype = C.POINTER(C.c_float)
         for f in ["gridCount", "grid", "neighborCount", "neighbor"]:
@@ -137,6 +138,7 @@ class Oracle:
         for f in _SCAL:
             d[f] = self._view(f, (nl,))
         d["cg_Minv"] = self._view("cg_Minv", (nl, 3, 3))
+        d["G"] = self._view("G", (nl, 3, 3))
         d["neighborCount"] = self._view("neighborCount", (nl,), np.int32)
         d["neighbor"] = self._view("neighbor", (nl, maxNeighbour), np.int32)
         ts = self.table_size

@@ -80,6 +80,9 @@ typedef struct orc_ctx {
   float ck_h, ck_h3, ck_mk, ck_ml;
   /* cohesion / adhesion (ref: kernels/CohesionKernel.py:12-15, AdhesionKernel.py:12-14) */
   float coh_mk, coh_mc, adh_mk;
+  /* ---- surface reconstruction fields (ref: ParticleData.py:37-42) ---- */
+  float *color; v3 *color_grad, *pos_avr; float *G; /* [liquid*9] */
+  float mc_searchR;
   /* ---- pcisph.py / iisph.py private fields (ref: pcisph.py:50-64, iisph.py:56-66) ---- */
   v3 *d_vel_pre, *pos_star, *vel_star, *d_ii, *dij_pj;
   float *a_ii, *pressure_pre;
@@ -125,6 +128,8 @@ orc_ctx *orc_create(int n_liquid, int n_solid, double particleR, int maxInGrid, 
   c->cg_Minv = (float *)calloc(nl * 9, sizeof(float));
   AL3(cg_r); AL3(cg_dir); AL3(cg_Ad); AL3(cg_s);
   AL1(alpha_coff); AL1(kappa); AL1(kappa_v); AL1(kbuf);
+  AL1(color); AL3(color_grad); AL3(pos_avr); c->G = (float *)calloc(nl * 9, sizeof(float));
+  c->mc_searchR = (float)((double)particleR * 0.9 * 4.0);   /* MCGrid(particleR, ...) MarchingCubeGrid.py:22-25 */
   AL3(d_vel_pre); AL3(pos_star); AL3(vel_star); AL3(d_ii); AL3(dij_pj); AL1(a_ii); AL1(pressure_pre);
   c->n_reduce = n_liquid;
   c->neighborCount = (int *)calloc(nl, sizeof(int));
@@ -138,7 +143,7 @@ void orc_destroy(orc_ctx *c) {
   free(c->pos); free(c->vel); free(c->vel_guess); free(c->d_vel); free(c->omega); free(c->d_omega);
   free(c->normal); free(c->rho); free(c->adv_rho); free(c->pressure); free(c->vel_max); free(c->cg_Minv);
   free(c->cg_r); free(c->cg_dir); free(c->cg_Ad); free(c->cg_s); free(c->alpha_coff); free(c->kappa);
-  free(c->kappa_v); free(c->kbuf); free(c->d_vel_pre); free(c->pos_star); free(c->vel_star); free(c->d_ii); free(c->dij_pj); free(c->a_ii); free(c->pressure_pre); free(c->neighborCount); free(c->neighbor); free(c->gridCount); free(c->grid);
+  free(c->color); free(c->color_grad); free(c->pos_avr); free(c->G); free(c->kappa_v); free(c->kbuf); free(c->d_vel_pre); free(c->pos_star); free(c->vel_star); free(c->d_ii); free(c->dij_pj); free(c->a_ii); free(c->pressure_pre); free(c->neighborCount); free(c->neighbor); free(c->gridCount); free(c->grid);
   free(c);
 }
 
@@ -1198,6 +1203,99 @@ void orc_iisph_step(orc_ctx *c) {
   orc_iisph_update_pos(c);
 }
 
+
+/* ------------------------------------------------------------------------------------ */
+/* ParticleData surface-reconstruction kernels (ref: ParticleData.py:187-298), SURVEY 8(f) rank 3  */
+
+/* ref: ParticleData.py:187-215 */
+void orc_compute_color_map(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float col = c->liqiudMass / c->rho[i] * Cubic_W_norm(c, 0.0f);
+    NB_BEGIN(i)
+      float Wr = Cubic_W(c, r);
+      if (j < NL) col += c->liqiudMass / c->rho[j] * Wr;
+      else        col += c->VS0 * Wr;
+    NB_END
+    c->color[i] = col;
+  }
+  PFOR for (int i = 0; i < NL; i++) {
+    v3 g = V(0, 0, 0);
+    NB_BEGIN(i)
+      if (j < NL) g = add(g, mul(CubicGradW(c, r), c->liqiudMass / c->rho[j] * c->color[j]));
+    NB_END
+    c->color_grad[i] = mul(g, 1.0f / c->color[i]);
+  }
+}
+/* ref: ParticleData.py:291-298 */
+static inline float aniso_weight(const orc_ctx *c, v3 xi, v3 xj) {
+  float dis = sqrtf(nsq(sub(xi, xj))), R2 = c->mc_searchR * 2.0f;
+  return (dis < R2) ? 1.0f - powf(dis / R2, 3.0f) : 0.0f;
+}
+/* eigen-decomposition of a symmetric 3x3 matrix by cyclic Jacobi rotations: a = Q diag(w) Q^T, w descending.
+ * The reference calls ti.svd on the (symmetric positive semi-definite) covariance: U = V = Q, sigma = w for every
+ * direction with w > 0 -- the only ones whose sign convention matters for G = R inv(sigmas) RT^T. */
+static void eig3(const float *a, float *w, float *Q) {
+  double A[3][3] = {{a[0], a[1], a[2]}, {a[1], a[4], a[5]}, {a[2], a[5], a[8]}};
+  double Vv[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 12; sweep++) {
+    double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    if (off < 1e-40) break;
+    for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+      if (fabs(A[p][q]) < 1e-300) continue;
+      double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+      double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+      for (int k = 0; k < 3; k++) { double akp = A[k][p], akq = A[k][q]; A[k][p] = cs * akp - sn * akq; A[k][q] = sn * akp + cs * akq; }
+      for (int k = 0; k < 3; k++) { double apk = A[p][k], aqk = A[q][k]; A[p][k] = cs * apk - sn * aqk; A[q][k] = sn * apk + cs * aqk; }
+      for (int k = 0; k < 3; k++) { double vkp = Vv[k][p], vkq = Vv[k][q]; Vv[k][p] = cs * vkp - sn * vkq; Vv[k][q] = sn * vkp + cs * vkq; }
+    }
+  }
+  int idx[3] = {0, 1, 2};
+  for (int x = 0; x < 2; x++) for (int y = x + 1; y < 3; y++) if (A[idx[y]][idx[y]] > A[idx[x]][idx[x]]) { int t = idx[x]; idx[x] = idx[y]; idx[y] = t; }
+  for (int k = 0; k < 3; k++) { w[k] = (float)A[idx[k]][idx[k]]; for (int r = 0; r < 3; r++) Q[r * 3 + k] = (float)Vv[r][idx[k]]; }
+}
+/* ref: ParticleData.py:220-289 */
+void orc_cal_anistropic_kernel(orc_ctx *c) {
+  PFOR for (int i = 0; i < NL; i++) {
+    float sw = 0.0f; v3 sx = V(0, 0, 0);
+    NB_BEGIN(i)
+      (void)r;
+      if (j < NL) { float w = aniso_weight(c, c->pos[i], c->pos[j]); sw += w; sx = add(sx, mul(c->pos[j], w)); }
+    NB_END
+    c->pos_avr[i] = (sw > 0.0f) ? mul(sx, 1.0f / sw) : c->pos[i];
+  }
+  PFOR for (int i = 0; i < NL; i++) {
+    const float kr = 4.0f, ks = 1400.0f, kn = 0.5f, ne = 25.0f;
+    float *G = c->G + (long)i * 9;
+    for (int a = 0; a < 9; a++) G[a] = (a % 4 == 0) ? kn : 0.0f;
+    int cur = c->neighborCount[i];
+    if ((float)cur > ne) {
+      float sw = 0.0f, m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const int *nb = c->neighbor + (long)i * c->maxNeighbour;
+      for (int k = 0; k < cur; k++) {
+        int j = nb[k];
+        if (j < NL) {
+          float w = aniso_weight(c, c->pos[i], c->pos[j]);
+          v3 r = sub(c->pos[j], c->pos_avr[i]);
+          sw += w;
+          m[0] += w * r.x * r.x; m[1] += w * r.x * r.y; m[2] += w * r.x * r.z;
+          m[4] += w * r.y * r.y; m[5] += w * r.y * r.z; m[8] += w * r.z * r.z;
+        }
+      }
+      m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+      for (int a = 0; a < 9; a++) m[a] /= sw;
+      float w[3], Q[9];
+      eig3(m, w, Q);
+      if (w[0] > 0.0f) {
+        float s0 = ks * w[0], s1 = ks * fmaxf(w[1], w[0] / kr), s2 = ks * fmaxf(w[2], w[0] / kr);
+        float inv[3] = {1.0f / s0, 1.0f / s1, 1.0f / s2};
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++)
+          G[a * 3 + b] = Q[a * 3 + 0] * inv[0] * Q[b * 3 + 0] + Q[a * 3 + 1] * inv[1] * Q[b * 3 + 1] + Q[a * 3 + 2] * inv[2] * Q[b * 3 + 2];
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* accessors for the ctypes wrapper (oracle/oracle.py)                                    */
 #define PTR(name, type) type *orc_ptr_##name(orc_ctx *c) { return (type *)c->name; }
@@ -1205,6 +1303,7 @@ PTR(pos, float) PTR(vel, float) PTR(vel_guess, float) PTR(d_vel, float) PTR(omeg
 PTR(normal, float) PTR(rho, float) PTR(adv_rho, float) PTR(pressure, float) PTR(vel_max, float)
 PTR(cg_Minv, float) PTR(cg_r, float) PTR(cg_dir, float) PTR(cg_Ad, float) PTR(cg_s, float)
 PTR(alpha_coff, float) PTR(kappa, float) PTR(kappa_v, float) PTR(kbuf, float)
+PTR(color, float) PTR(color_grad, float) PTR(pos_avr, float) PTR(G, float)
 PTR(d_vel_pre, float) PTR(pos_star, float) PTR(vel_star, float) PTR(d_ii, float) PTR(dij_pj, float) PTR(a_ii, float) PTR(pressure_pre, float)
 PTR(gridCount, int) PTR(grid, int) PTR(neighborCount, int) PTR(neighbor, int)
 

@@ -53,7 +53,7 @@ def test_enum_ids_match_header():
     names = [n for n in names if n != "_COUNT"]
     want = ["POS", "VEL", "VEL_GUESS", "D_VEL", "OMEGA", "D_OMEGA", "NORMAL", "CG_R", "CG_DIR", "CG_AD", "CG_S", "RHO",
             "ADV_RHO", "PRESSURE", "VEL_MAX", "ALPHA", "KAPPA", "KAPPA_V", "CG_MINV", "NEIGHBOR_COUNT", "KBUF", "D_VEL_PRE",
-            "POS_STAR", "VEL_STAR", "D_II", "DIJ_PJ", "A_II", "PRESSURE_PRE"]
+            "POS_STAR", "VEL_STAR", "D_II", "DIJ_PJ", "A_II", "PRESSURE_PRE", "COLOR", "COLOR_GRAD", "POS_AVR", "G"]
     assert names == want and len(_lib.FIELDS) == len(want)
 
 

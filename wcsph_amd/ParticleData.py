@@ -19,6 +19,15 @@ from .field import Field, ScalarField
 from .kernels.CubicKernel import CubicKernel
 
 
+class _MCGridRadii:
+    """ref: MarchingCubeGrid.py:22-25 (gridR = 0.9 particleR, searchR = 4 gridR); the grid itself is out of scope"""
+
+    def __init__(self, particleR):
+        self.gridR = particleR * 0.9
+        self.invGridR = 1.0 / self.gridR
+        self.searchR = self.gridR * 4.0
+
+
 class ParticleData:
     def __init__(self, particleR, neighbor_mode="faithful", maxInGrid=64, maxNeighbour=2048, cfl_radius=None):
         self.count = 0
@@ -36,9 +45,16 @@ class ParticleData:
         self.neighbor_mode = neighbor_mode
         self.hash_grid = HashGrid(particleR * 2.0, maxInGrid, maxNeighbour, self)
         self.kernel_c = CubicKernel(self.hash_grid.searchR)
+        # the reference builds a full marching-cubes grid here (ParticleData.py:29: MCGrid(particleR, 4, 512, self));
+        # only its radii take part in the per-particle surface kernels below (MarchingCubeGrid.py:22-25)
+        self.mc_grid = _MCGridRadii(particleR)
 
         f = lambda name, nc: Field(self, name, nc)  # noqa: E731
         self.pos = Field(self, "pos", 3, full_count=True)
+        self.color = f("color", 1)            # surface reconstruction fields (ParticleData.py:37-42),
+        self.color_grad = f("color_grad", 3)  # filled by compute_color_map() / cal_anistropic_kernel()
+        self.pos_avr = f("pos_avr", 3)
+        self.G = f("G", 9)
         self.normal = f("normal", 3)
         self.vel_guess = f("vel_guess", 3)
         self.vel = f("vel", 3)
@@ -205,6 +221,17 @@ class ParticleData:
         """ref: ParticleData.py:180-185 -- upload positions, fix the grid box."""
         self.hash_grid.setup_grid_cpu(self.maxboundarynp, self.minboundarynp)
         print("liqiud particle num:", self.liquid_count, "solid particle num:", self.solid_count)
+
+    # ---- surface reconstruction, per-particle part (ref: ParticleData.py:187-298) ------------------------
+    def compute_color_map(self):
+        """ref: ParticleData.py:187-215 (needs rho of the current step and a valid grid)"""
+        ctx = self._need_ctx()
+        _lib.check(ctx, _lib.load().wcsph_surface_color_map(ctx))
+
+    def cal_anistropic_kernel(self):
+        """ref: ParticleData.py:220-289: weighted mean positions and the anisotropy matrices G (Yu & Turk)"""
+        ctx = self._need_ctx()
+        _lib.check(ctx, _lib.load().wcsph_surface_anisotropic_kernel(ctx, float(self.mc_grid.searchR)))
 
     def _need_ctx(self):
         if self._ctx is None:

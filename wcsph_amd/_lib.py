@@ -37,7 +37,8 @@ class Params(C.Structure):
 # enum wcsph_field
 FIELDS = ["pos", "vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_r", "cg_dir", "cg_Ad", "cg_s",
           "rho", "adv_rho", "pressure", "vel_max", "alpha_coff", "kappa", "kappa_v", "cg_Minv", "neighborCount", "kbuf",
-          "d_vel_pre", "pos_star", "vel_star", "d_ii", "dij_pj", "a_ii", "pressure_pre"]
+          "d_vel_pre", "pos_star", "vel_star", "d_ii", "dij_pj", "a_ii", "pressure_pre",
+          "color", "color_grad", "pos_avr", "G"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 # enum wcsph_scalar
 SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
@@ -63,13 +64,14 @@ CTX_ONLY = [
     "wcsph_iisph_reset_param", "wcsph_iisph_compute_density", "wcsph_iisph_visc_init", "wcsph_iisph_visc_iter",
     "wcsph_iisph_combine_nonpressure", "wcsph_iisph_compute_nonpressure_force", "wcsph_iisph_compute_advection",
     "wcsph_iisph_update_iter_info", "wcsph_iisph_update_pressure_force", "wcsph_iisph_solve_pressure",
-    "wcsph_iisph_update_pos", "wcsph_iisph_step",
+    "wcsph_iisph_update_pos", "wcsph_iisph_step", "wcsph_surface_color_map",
 ]
 OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_count", "wcsph_setup",
          "wcsph_get_block_size", "wcsph_field_to_host", "wcsph_field_from_host", "wcsph_get_scalar",
          "wcsph_set_scalar", "wcsph_get_iters", "wcsph_set_iters", "wcsph_neighbors_to_host", "wcsph_time_kernel",
          "wcsph_field_gather_rows", "wcsph_field_scatter_rows", "wcsph_set_owned", "wcsph_set_cell_window",
-         "wcsph_load_state", "wcsph_store_state", "wcsph_get_acc", "wcsph_set_acc", "wcsph_phase"]
+         "wcsph_load_state", "wcsph_store_state", "wcsph_get_acc", "wcsph_set_acc", "wcsph_phase",
+         "wcsph_surface_anisotropic_kernel"]
 ALL_SYMBOLS = CTX_ONLY + OTHER
 
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
@@ -117,6 +119,7 @@ def load():
     lib.wcsph_get_acc.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.wcsph_set_acc.argtypes = [vp, C.c_int, C.c_double]
     lib.wcsph_phase.argtypes = [vp, C.c_int]
+    lib.wcsph_surface_anisotropic_kernel.argtypes = [vp, C.c_float]
     for name in CTX_ONLY:
         getattr(lib, name).argtypes = [vp]
     for name in ALL_SYMBOLS:

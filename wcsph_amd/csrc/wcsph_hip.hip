@@ -16,6 +16,7 @@
 #include "dfsph_kernels.h"
 #include "tile.h"
 #include "solver_extra.h"
+#include "surface.h"
 
 struct wcsph_ctx {
   wcsph_params p;
@@ -43,6 +44,7 @@ struct wcsph_ctx {
   // host-side solver state (ref: dfsph.py:36-41 module globals)
   float dt = 0.0f;
   float rho_err = 0.0f;
+  SurfDev surf = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
   float avg_density_err = 0.0f, cg_delta = 0.0f, cg_delta_old = 0.0f, cg_delta_zero = 0.0f, vel_max0 = 0.0f;
   int vs_iter = 0, dv_iter = 0, pr_iter = 0;
   int bs[3] = {0, 0, 0};
@@ -408,6 +410,10 @@ static FieldDesc field_desc(wcsph_ctx *ctx, int f) {
     case WCSPH_F_DIJ_PJ: return {3, d.dij_pj};
     case WCSPH_F_A_II: return {1, d.a_ii};
     case WCSPH_F_PRESSURE_PRE: return {1, d.pressure_pre};
+    case WCSPH_F_COLOR: return {ctx->surf.color ? 1 : 0, ctx->surf.color};
+    case WCSPH_F_COLOR_GRAD: return {ctx->surf.color ? 3 : 0, ctx->surf.color_grad};
+    case WCSPH_F_POS_AVR: return {ctx->surf.color ? 3 : 0, ctx->surf.pos_avr};
+    case WCSPH_F_G: return {ctx->surf.color ? 10 : 0, nullptr};
   }
   return {0, nullptr};
 }
@@ -417,22 +423,23 @@ int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
   if (!dst) return WCSPH_EARG;
   Dev &d = ctx->d;
   FieldDesc fd = field_desc(ctx, field);
-  if (!fd.kind) return ctx->fail(WCSPH_EARG, "unknown field id");
+  if (!fd.kind) return ctx->fail(WCSPH_EARG, "unknown field id (or a surface field before the surface kernels ran)");
   hipStream_t s = ctx->stream;
   const int nl = d.nl;
   size_t rows = (field == WCSPH_F_POS) ? (size_t)nl + d.ns : (size_t)nl;
-  size_t per = fd.kind == 3 ? 3 : fd.kind == 9 ? 9 : 1;
+  size_t per = fd.kind == 3 ? 3 : (fd.kind == 9 || fd.kind == 10) ? 9 : 1;
   if (bytes != rows * per * 4) return ctx->fail(WCSPH_EARG, "wcsph_field_to_host: wrong byte count");
   if (nl > 0) {
     if (fd.kind == 3) hipLaunchKernelGGL(k_unpermute3, dim3(nblk(nl)), dim3(BLOCK), 0, s, (const float4 *)fd.ptr, (const int *)d.oid, nl, ctx->stage);
     else if (fd.kind == 1 || fd.kind == -1)
       hipLaunchKernelGGL(k_unpermute1, dim3(nblk(nl)), dim3(BLOCK), 0, s, (const float *)fd.ptr, (const int *)d.oid, nl, ctx->stage);
-    else {  // cg_Minv rows -> [n][3][3]
+    else {  // cg_Minv / G rows -> [n][3][3]
       std::vector<float4> r0(nl), r1(nl), r2(nl);
       std::vector<int> oid(nl);
-      HIPCHK(hipMemcpyAsync(r0.data(), d.minv0, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(r1.data(), d.minv1, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(r2.data(), d.minv2, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      const bool isG = fd.kind == 10;
+      HIPCHK(hipMemcpyAsync(r0.data(), isG ? ctx->surf.g0 : d.minv0, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(r1.data(), isG ? ctx->surf.g1 : d.minv1, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(r2.data(), isG ? ctx->surf.g2 : d.minv2, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
       HIPCHK(hipMemcpyAsync(oid.data(), d.oid, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       float *o = (float *)dst;
@@ -457,7 +464,7 @@ int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t byt
   if (!src) return WCSPH_EARG;
   Dev &d = ctx->d;
   FieldDesc fd = field_desc(ctx, field);
-  if (!fd.kind || fd.kind == 9 || fd.kind == -1) return ctx->fail(WCSPH_EARG, "field is not writable from the host");
+  if (!fd.kind || fd.kind == 9 || fd.kind == 10 || fd.kind == -1) return ctx->fail(WCSPH_EARG, "field is not writable from the host");
   hipStream_t s = ctx->stream;
   const int nl = d.nl;
   size_t per = fd.kind == 3 ? 3 : 1;
@@ -1004,6 +1011,43 @@ int wcsph_iisph_step(wcsph_ctx *ctx) {
   if ((rc = wcsph_iisph_compute_advection(ctx))) return rc;
   if ((rc = wcsph_iisph_solve_pressure(ctx))) return rc;
   return wcsph_iisph_update_pos(ctx);
+}
+
+// ---- ParticleData surface reconstruction (post-processing) ------------------------------------------
+static int surf_alloc(wcsph_ctx *ctx) {
+  if (ctx->surf.color) return 0;
+  const size_t n = (size_t)ctx->capacity;
+  DALLOC(ctx->surf.color, n); DALLOC(ctx->surf.color_grad, n); DALLOC(ctx->surf.pos_avr, n);
+  DALLOC(ctx->surf.g0, n); DALLOC(ctx->surf.g1, n); DALLOC(ctx->surf.g2, n);
+  return 0;
+}
+int wcsph_surface_color_map(wcsph_ctx *ctx) {
+  NEED_GRID();
+  int rc = surf_alloc(ctx);
+  if (rc) return rc;
+  Dev v = ctx->d;
+  v.list_r2 = v.h2;   // Cubic kernel support
+  if (v.nl > 0) {
+    hipLaunchKernelGGL(k_surf_color, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
+    hipLaunchKernelGGL(k_surf_color_grad, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
+  }
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR) {
+  NEED_GRID();
+  if (!(mc_searchR > 0.0f)) return ctx->fail(WCSPH_EARG, "mc_searchR must be positive");
+  int rc = surf_alloc(ctx);
+  if (rc) return rc;
+  Dev v = ctx->d;
+  ctx->surf.R2 = mc_searchR * 2.0f;                 // ParticleData.py:295 support of weight_func
+  v.list_r2 = ctx->surf.R2 * ctx->surf.R2;          // entries of the walked cells beyond it weigh exactly zero
+  if (v.nl > 0) {
+    hipLaunchKernelGGL(k_surf_pos_avr, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
+    hipLaunchKernelGGL(k_surf_aniso, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
+  }
+  LAUNCHCHK();
+  return WCSPH_OK;
 }
 
 // ---- explicit neighbour list (debug / API parity) ----------------------------------------------
