@@ -38,7 +38,8 @@ def build_sim(n, mode):
 
 
 def cpu_baseline(n, steps):
-    """Reference-algorithm CPU restatement (oracle/wcsph_ref.c, faithful mode) on the host cores."""
+    """Reference-algorithm CPU restatement (oracle/wcsph_ref.c, faithful mode) on the host cores: all cores, and 1 thread."""
+    import oracle
     from oracle import Oracle
     from wcsph_amd import scene
     liquid, solid = scene.dam_break_dfsph(n)
@@ -46,17 +47,23 @@ def cpu_baseline(n, steps):
     o = Oracle(pos, len(liquid), 0.025, mode="faithful")
     o.reset_param()
     o.dfsph_step()  # first step pays the page faults of the 8 KiB/particle neighbour table
+    cores = oracle.get_max_threads()
     t0 = time.perf_counter()
     for _ in range(steps):
         o.dfsph_step()
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    oracle.set_num_threads(1)
+    t1 = time.perf_counter()
+    o.dfsph_step()
+    dt1 = time.perf_counter() - t1
+    oracle.set_num_threads(cores)
     val = len(liquid) * steps / dt / 1e6
     o.close()
     return {"value": round(val, 4), "unit": "M particle-steps/s", "cores": cores, "kind": "port",
             "sample": "DFSPH dam break %d^3 = %d liquid + %d boundary particles (config C2 size), %d steps after 1 "
                       "warm-up step, faithful neighbour mode, gcc -O2 -fopenmp" % (n, len(liquid), len(solid), steps),
-            "ms_per_step": round(dt / steps * 1e3, 2)}
+            "ms_per_step": round(dt / steps * 1e3, 2),
+            "single_thread": {"value": round(len(liquid) / dt1 / 1e6, 4), "ms_per_step": round(dt1 * 1e3, 1), "steps": 1}}
 
 
 def main():
@@ -158,6 +165,20 @@ def main():
         el2 = time.perf_counter() - t0
         out["config"]["clean_mode"] = {"value": round(nl * args.steps / el2 / 1e6, 3), "ms_per_step": round(el2 / args.steps * 1e3, 3)}
         pd2.close()
+    if not args.no_clean:
+        # equal-work micro-benchmark: fixed dv = 2, pr = 4, vs = 4 iterations per step
+        d4, p4, _ = build_sim(n, args.mode)
+        for _ in range(max(args.warmup // 2, 2)):
+            d4.step_fixed(2, 4, 4)
+        p4.sync(); tsync()
+        t0 = time.perf_counter()
+        nfix = max(args.steps // 2, 5)
+        for _ in range(nfix):
+            d4.step_fixed(2, 4, 4)
+        p4.sync(); tsync()
+        el4 = time.perf_counter() - t0
+        out["config"]["fixed_iters_dv2_pr4_vs4"] = {"value": round(nl * nfix / el4 / 1e6, 3), "ms_per_step": round(el4 / nfix * 1e3, 3), "steps": nfix}
+        p4.close()
     if args.config == "C3" and not args.no_clean:
         # BASELINE.json configs[1] (C2, ~100 k particles) for reference: too small to fill 256 CUs, launch-bound
         d3, p3, _ = build_sim(scene.CONFIGS["C2"], args.mode)

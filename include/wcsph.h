@@ -153,6 +153,9 @@ int wcsph_dfsph_optimize_time_step(wcsph_ctx *ctx);        /* ref: dfsph.py:107-
 int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx);          /* ref: dfsph.py:131-146 */
 int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx);            /* ref: dfsph.py:150-164 */
 int wcsph_dfsph_step(wcsph_ctx *ctx);                      /* ref: dfsph.py:606-617 */
+/* the same step with the three solver loops run for a FIXED number of iterations (equal-work micro-benchmark,
+ * SURVEY 8(d)); 0 for a count keeps that loop's reference stopping rule */
+int wcsph_dfsph_step_fixed(wcsph_ctx *ctx, int32_t dv_iters, int32_t pr_iters, int32_t vs_iters);
 
 /* ---- sesph.py kernels ----------------------------------------------------------------- */
 int wcsph_sesph_reset_param(wcsph_ctx *ctx);   /* ref: sesph.py:130-135 */

@@ -98,8 +98,18 @@ def _load():
         for f in ["gridCount", "grid", "neighborCount", "neighbor"]:
             getattr(lib, "orc_ptr_" + f).argtypes = [C.c_void_p]
             getattr(lib, "orc_ptr_" + f).restype = C.POINTER(C.c_int)
+        lib.orc_set_num_threads.argtypes = [C.c_int]
+        lib.orc_get_max_threads.restype = C.c_int
         _lib = lib
     return _lib
+
+
+def set_num_threads(n):
+    _load().orc_set_num_threads(int(n))
+
+
+def get_max_threads():
+    return int(_load().orc_get_max_threads())
 
 
 class Oracle:

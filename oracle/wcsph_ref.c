@@ -30,6 +30,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef struct { float x, y, z; } v3;
 static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
@@ -1348,3 +1351,19 @@ double orc_get_dAd(orc_ctx *c) { return c->cg_dAd; }
 void orc_set_dAd(orc_ctx *c, double v) { c->cg_dAd = v; }
 double orc_get_dnew(orc_ctx *c) { return c->cg_dnew; }
 void orc_set_dnew(orc_ctx *c, double v) { c->cg_dnew = v; }
+
+/* thread count of the OpenMP loops (bench.py reports an all-cores and a 1-thread figure) */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -47,6 +47,7 @@ struct wcsph_ctx {
   SurfDev surf = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
   float avg_density_err = 0.0f, cg_delta = 0.0f, cg_delta_old = 0.0f, cg_delta_zero = 0.0f, vel_max0 = 0.0f;
   int vs_iter = 0, dv_iter = 0, pr_iter = 0;
+  int fix_dv = 0, fix_pr = 0, fix_vs = 0;  // > 0: run exactly that many iterations (wcsph_dfsph_step_fixed)
   int bs[3] = {0, 0, 0};
   int win_x0 = 0, win_x1 = -1;  // cell-x window (slab decomposition); x1 < 0 => whole box
   int capacity = 0;
@@ -759,6 +760,10 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
   while (ctx->vs_iter < 100) {
     if ((rc = wcsph_dfsph_visc_iter(ctx))) return rc;
     ctx->vs_iter++;
+    if (ctx->fix_vs > 0) {  // fixed count, but never past an exactly-zero residual (beta would be 0/0)
+      if (ctx->vs_iter >= ctx->fix_vs || (double)ctx->cg_delta_zero < (double)ctx->p.eps || ctx->cg_delta == 0.0f) break;
+      continue;
+    }
     if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero ||
         (double)ctx->cg_delta_zero < (double)ctx->p.eps)
       break;
@@ -796,7 +801,7 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
   if (fusek) PASS((k_drho_div<DRHO_BEGIN, true>), ctx->dt);
   else if ((rc = wcsph_dfsph_begin_divergence(ctx))) return rc;
   const float dt = ctx->dt;
-  while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
+  while (ctx->fix_dv > 0 ? ctx->dv_iter < ctx->fix_dv : ((double)ctx->avg_density_err > err && ctx->dv_iter < 10)) {
     if ((rc = divergence_iter_fused(ctx))) return rc;
     if ((rc = fused_iter_sync(ctx))) return rc;
     err = 0.001 * (double)ctx->d.n_owned / (double)dt;
@@ -814,7 +819,7 @@ int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
   const bool fusek = !ctx->use_tiles && ctx->d.n_owned == ctx->d.nl;
   if (fusek) PASS((k_drho_press<DRHO_BEGIN, true>), ctx->dt);
   else if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
-  while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
+  while (ctx->fix_pr > 0 ? ctx->pr_iter < ctx->fix_pr : ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100)) {
     if ((rc = pressure_iter_fused(ctx))) return rc;
     if ((rc = fused_iter_sync(ctx))) return rc;
     err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
@@ -834,6 +839,15 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
   if ((rc = wcsph_dfsph_solve_pressure(ctx))) return rc;
   return wcsph_dfsph_update_pos(ctx);
+}
+
+int wcsph_dfsph_step_fixed(wcsph_ctx *ctx, int32_t dv, int32_t pr, int32_t vs) {
+  NEED_SETUP();
+  if (dv < 0 || pr < 0 || vs < 0) return WCSPH_EARG;
+  ctx->fix_dv = dv; ctx->fix_pr = pr; ctx->fix_vs = vs;
+  int rc = wcsph_dfsph_step(ctx);
+  ctx->fix_dv = ctx->fix_pr = ctx->fix_vs = 0;
+  return rc;
 }
 
 // ---- sesph.py ---------------------------------------------------------------------------------

@@ -229,6 +229,17 @@ def step():
     return dt
 
 
+def step_fixed(dv=2, pr=4, vs=4):
+    """The step with fixed solver iteration counts (equal-work micro-benchmark)."""
+    global current_time
+    ctx = particle_data._need_ctx()
+    _lib.check(ctx, _lib.load().wcsph_dfsph_step_fixed(ctx, dv, pr, vs))
+    _pull_iters()
+    dt = float(deltaT.to_numpy()[0])
+    current_time += dt
+    return dt
+
+
 def step_reference_loop():
     """The reference main-loop body, verbatim (dfsph.py:606-617), through the per-kernel entry points."""
     global current_time
