@@ -47,7 +47,16 @@ def cpu_baseline(n, steps):
     o = Oracle(pos, len(liquid), 0.025, mode="faithful")
     o.reset_param()
     o.dfsph_step()  # first step pays the page faults of the 8 KiB/particle neighbour table
-    cores = oracle.get_max_threads()
+    maxt = oracle.get_max_threads()
+    # the loops of a C2-size scene are short: try a few team sizes, report the best one (and which)
+    sweep = {}
+    for th in sorted({maxt, 64, 32, 16} & set(range(1, maxt + 1)), reverse=True):
+        oracle.set_num_threads(th)
+        t0 = time.perf_counter()
+        o.dfsph_step()
+        sweep[th] = time.perf_counter() - t0
+    cores = min(sweep, key=sweep.get)
+    oracle.set_num_threads(cores)
     t0 = time.perf_counter()
     for _ in range(steps):
         o.dfsph_step()
@@ -56,13 +65,14 @@ def cpu_baseline(n, steps):
     t1 = time.perf_counter()
     o.dfsph_step()
     dt1 = time.perf_counter() - t1
-    oracle.set_num_threads(cores)
+    oracle.set_num_threads(maxt)
     val = len(liquid) * steps / dt / 1e6
     o.close()
     return {"value": round(val, 4), "unit": "M particle-steps/s", "cores": cores, "kind": "port",
             "sample": "DFSPH dam break %d^3 = %d liquid + %d boundary particles (config C2 size), %d steps after 1 "
                       "warm-up step, faithful neighbour mode, gcc -O2 -fopenmp" % (n, len(liquid), len(solid), steps),
-            "ms_per_step": round(dt / steps * 1e3, 2),
+            "ms_per_step": round(dt / steps * 1e3, 2), "host_threads_available": maxt,
+            "thread_sweep_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
             "single_thread": {"value": round(len(liquid) / dt1 / 1e6, 4), "ms_per_step": round(dt1 * 1e3, 1), "steps": 1}}
 
 

@@ -25,6 +25,9 @@ def _built():
     """Both native pieces must exist before any test runs (the HIP library is cross-compiled on CPU boxes)."""
     import __graft_entry__ as g
     g.build()
+    # the checker's OpenMP loops are short: hundreds of threads (GPU-box hosts have 256) only add fork/join cost
+    import oracle
+    oracle.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -1,0 +1,37 @@
+"""Long-horizon behaviour: the reference default scene (20^3 liquid, box shell) run for 80 DFSPH steps on the GPU and
+in the oracle.  SPH trajectories are chaotic, so this compares ensemble statistics, not particles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_default_scene_statistics_track_the_oracle():
+    from oracle import Oracle
+    from wcsph_amd import dfsph
+    pd = dfsph.init_particle(particleDim=20, neighbor_mode="faithful")
+    assert pd.liquid_count == 8000 and abs(pd.solid_count - 25387) < 100      # the reference's default scene size
+    o = Oracle(pd.pos.to_numpy(), 8000, 0.025, mode="faithful")
+    dfsph.reset_param(); o.reset_param()
+    tg = to = 0.0
+    it_g, it_o = [], []
+    for s in range(80):
+        tg += dfsph.step()
+        o.dfsph_step(); to += o.deltaT
+        it_g.append((dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter)); it_o.append((o.vs_iter, o.dv_iter, o.pr_iter))
+        if s == 9:   # still deterministic-ish early on: fields agree tightly
+            assert np.abs(pd.pos.to_numpy() - o.pos).max() < 1e-4
+            assert np.abs(pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-3
+    pg, po = pd.pos.to_numpy()[:8000], o.pos[:8000]
+    vg, vo = pd.vel.to_numpy(), o.vel
+    assert np.isfinite(pg).all() and np.isfinite(vg).all()
+    assert abs(tg - to) < 0.02 * to                                            # same simulated time (dt history)
+    assert abs(pg[:, 1].mean() - po[:, 1].mean()) < 0.01                       # centre of mass height
+    assert abs(np.abs(pg[:, 0]).max() - np.abs(po[:, 0]).max()) < 0.05         # spreading front
+    ke_g, ke_o = (vg ** 2).sum(), (vo ** 2).sum()
+    assert abs(ke_g - ke_o) < 0.1 * ke_o                                       # kinetic energy
+    assert abs(pd.rho.to_numpy().mean() - o.rho.mean()) < 0.01 * o.rho.mean()
+    ig, io = np.array(it_g), np.array(it_o)
+    assert np.abs(ig.mean(0) - io.mean(0)).max() < 0.5                         # solver effort per step
+    assert (pg[:, 1] > -1e-3).all() and (np.abs(pg[:, [0, 2]]) < 1.0 + 1e-3).all()   # nobody left the box
+    pd.close()
