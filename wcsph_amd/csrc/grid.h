@@ -352,6 +352,7 @@ __global__ void k_ncount_clean(Dev d) {
 __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   const int i = sorted_index();
   if (i >= d.nl) return;
+  if (d.oid[i] >= d.n_owned) { if (liquid_too) d.ncl[i] = 0; d.ncs[i] = 0; return; }  // ghosts never run a neighbour loop
   const float4 pi = d.pos[i];
   const size_t st = (size_t)d.nbr_stride;
   int cl = 0, cs = 0;
