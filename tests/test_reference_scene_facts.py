@@ -1,0 +1,60 @@
+"""The reference's own default DFSPH scene: 20^3 liquid block (dfsph.py:59-73) + its shipped boundary point cloud
+model/box_boundry.obj, loaded through the reference-compatible OBJ loader (ParticleData.add_obj).  SURVEY.md Appendix
+A-Q1 / C / D record what an INDEPENDENT NumPy emulation of the reference's HashGrid measured on this scene; the oracle
+must reproduce those numbers.  Needs the reference tree (data file only); skipped where it is absent (GPU box)."""
+import os
+
+import numpy as np
+import pytest
+
+OBJ = "/root/reference/model/box_boundry.obj"
+pytestmark = pytest.mark.skipif(not os.path.exists(OBJ), reason="reference data file not available")
+
+
+@pytest.fixture(scope="module")
+def scene_pos():
+    from wcsph_amd import ParticleData, scene
+    pd = ParticleData(0.025)
+    pd.add_liquid_points(scene.dam_break_liquid(20))
+    pd.add_obj(OBJ)
+    assert (pd.liquid_count, pd.solid_count, pd.count) == (8000, 25387, 33387)
+    np.testing.assert_allclose(pd.minboundarynp, [[-1, 0, -1]], atol=1e-6)
+    np.testing.assert_allclose(pd.maxboundarynp, [[1, 2, 1]], atol=1e-6)
+    return pd._initial_positions()
+
+
+def test_default_scene_list_statistics(scene_pos):
+    from oracle import Oracle
+    o = Oracle(scene_pos, 8000, 0.025, mode="faithful")
+    assert o.blockSize == (41, 41, 41) and o.table_size == 33387
+    o.update_grid()
+    assert o.overflow_grid == 0 and o.overflow_neighbor == 0
+    assert o.gridCount.max() == 13                              # App. C: max bucket occupancy 13 (cap 64 never hit)
+    nc = o.neighborCount
+    assert abs(nc.mean() - 227) < 3 and 290 <= nc.max() <= 320  # App. D: raw list length 227 mean / 301 max (here 312)
+    # in-support entries and duplicates (Q1: 21 % of the liquid particles carry duplicated entries)
+    pos = scene_pos
+    dup = 0
+    insup = []
+    for i in range(0, 8000, 5):
+        lst = o.neighbor[i, :nc[i]]
+        d = np.linalg.norm(pos[lst] - pos[i], axis=1)
+        near = lst[d <= 0.1 * (1 + 1e-6)]
+        insup.append(len(set(near.tolist())))
+        dup += len(near) != len(set(near.tolist()))
+    assert abs(np.mean(insup) - 27) < 1.5 and max(insup) <= 33  # App. D: 27 in support (max 32)
+    assert 0.15 < dup / len(insup) < 0.27                       # Q1: ~21 %
+
+
+def test_default_scene_density_error_of_the_aliasing(scene_pos):
+    """Q1: 8 % of the particles have a density that differs by > 1e-4 (max 18.7 %) from the collision-free list."""
+    from oracle import Oracle
+    of = Oracle(scene_pos, 8000, 0.025, mode="faithful")
+    oc = Oracle(scene_pos, 8000, 0.025, mode="clean")
+    for o in (of, oc):
+        o.update_grid(); o.compute_density()
+    rel = np.abs(of.rho - oc.rho) / oc.rho
+    assert 0.05 < (rel > 1e-4).mean() < 0.11
+    assert 0.15 < rel.max() < 0.22
+    interior = np.argmin(np.linalg.norm(scene_pos[:8000] - scene_pos[:8000].mean(0), axis=1))
+    assert oc.rho[interior] == pytest.approx(799.978, rel=1e-5)   # App. C lattice density
