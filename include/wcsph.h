@@ -193,6 +193,14 @@ int wcsph_iisph_step(wcsph_ctx *ctx);                       /* ref: iisph.py:419
 int wcsph_surface_color_map(wcsph_ctx *ctx);                          /* ref: ParticleData.py:187-215 compute_color_map */
 int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR); /* ref: ParticleData.py:220-289 cal_anistropic_kernel */
 
+/* ---- boundary sampler ------------------------------------------------------- */
+/* ref: boundry.py:100-460 -- Poisson-disk sampling of a triangle mesh (tri_xyz: [n_tri][3 vertices][3]) into
+ * boundary particles no closer than particle_radius (normal-corrected distance, boundry.py:340-370).
+ * Self-contained (no context), synchronous; out_xyz receives at most `cap` points, *n_out the number produced
+ * (if *n_out > cap the output was truncated). */
+int wcsph_sample_surface(const float *tri_xyz, int32_t n_tri, double particle_radius, uint32_t seed, int32_t trials,
+                         float *out_xyz, int32_t cap, int32_t *n_out);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Times `reps` back-to-back launches of one named kernel group with hipEvents on the context's
  * stream; *ms_per_launch is the average.  Names: "pressure_iter", "divergence_iter", "density",

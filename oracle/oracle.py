@@ -46,8 +46,8 @@ _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff",
 
 def build_oracle(force=False):
     """Compile oracle/wcsph_ref.c with gcc (oracle/Makefile). Returns the .so path."""
-    src = os.path.join(_HERE, "wcsph_ref.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("wcsph_ref.c", "poisson_ref.c", "Makefile")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB
 
@@ -99,9 +99,24 @@ def _load():
             getattr(lib, "orc_ptr_" + f).argtypes = [C.c_void_p]
             getattr(lib, "orc_ptr_" + f).restype = C.POINTER(C.c_int)
         lib.orc_set_num_threads.argtypes = [C.c_int]
+        lib.orc_poisson_sample.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_uint32, C.c_int, C.c_void_p, C.c_int]
+        lib.orc_poisson_sample.restype = C.c_int
+        lib.orc_ps_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.orc_ps_distance.restype = C.c_float
         lib.orc_get_max_threads.restype = C.c_int
         _lib = lib
     return _lib
+
+
+def poisson_sample(tri, radius=0.025, seed=20240901, trials=10, cap=None):
+    """CPU restatement of the boundary sampler (oracle/poisson_ref.c); tri: [n_tri,3,3] float32 -> [n,3] float32"""
+    tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+    if cap is None:
+        t = tri.reshape(-1, 3, 3)
+        cap = int(3.0 * 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum() / radius ** 2) + 1024
+    out = np.empty((cap, 3), np.float32)
+    n = _load().orc_poisson_sample(tri.ctypes.data, len(tri), float(radius), int(seed) & 0xffffffff, int(trials), out.ctypes.data, cap)
+    return out[:min(n, cap)].copy()
 
 
 def set_num_threads(n):

@@ -17,6 +17,7 @@
 #include "tile.h"
 #include "solver_extra.h"
 #include "surface.h"
+#include "sampler.h"
 
 struct wcsph_ctx {
   wcsph_params p;
@@ -1185,6 +1186,92 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     default: return ctx->fail(WCSPH_EARG, "unknown phase id");
   }
   return WCSPH_OK;
+}
+
+// ---- boundary sampler --------------------------------------------------------------------------------
+int wcsph_sample_surface(const float *tri_xyz, int32_t n_tri, double R, uint32_t seed, int32_t trials,
+                         float *out_xyz, int32_t cap, int32_t *n_out) {
+  if (!tri_xyz || n_tri < 1 || !(R > 0.0) || trials < 1 || !out_xyz || cap < 0 || !n_out) return WCSPH_EARG;
+  // ref: boundry.py:128-165 -- face areas / normals (float32 arrays), bounding box, candidate count
+  std::vector<float> nrm((size_t)n_tri * 3), area(n_tri);
+  double total = 0.0, maxa = 0.0;
+  float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+  for (int t = 0; t < n_tri; t++) {
+    const float *a = tri_xyz + 9 * (size_t)t, *b = a + 3, *c = a + 6;
+    for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], fminf(a[k], fminf(b[k], c[k]))); mx[k] = fmaxf(mx[k], fmaxf(a[k], fmaxf(b[k], c[k]))); }
+    const double d1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]}, d2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+    const double n[3] = {d1[1] * d2[2] - d1[2] * d2[1], d1[2] * d2[0] - d1[0] * d2[2], d1[0] * d2[1] - d1[1] * d2[0]};
+    const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    area[t] = (float)(len * 0.5);
+    for (int k = 0; k < 3; k++) nrm[3 * (size_t)t + k] = len > 0 ? (float)(n[k] / len) : 0.f;
+    total += (double)area[t];
+    if ((double)area[t] > maxa) maxa = (double)area[t];
+  }
+  if (!(maxa > 0.0)) return WCSPH_EARG;
+  const double pi_ref = 3.1415926;   // boundry.py:54
+  const long ncand_l = (long)(40.0 * (total / (pi_ref * R * R)));
+  if (ncand_l < 1 || ncand_l > 400000000L) return WCSPH_EARG;
+  PsDev s;
+  memset(&s, 0, sizeof s);
+  s.n_tri = n_tri; s.n_cand = (int)ncand_l; s.seed = seed; s.radius = (float)R; s.max_area = (float)maxa;
+  const double grid_r = R / sqrt(3.0);   // boundry.py:21
+  s.inv_grid = (float)(1.0 / grid_r);
+  s.minx = mn[0]; s.miny = mn[1]; s.minz = mn[2];
+  const long dims[3] = {(long)(((double)mx[0] - mn[0]) / grid_r) + 3, (long)(((double)mx[1] - mn[1]) / grid_r) + 3, (long)(((double)mx[2] - mn[2]) / grid_r) + 3};
+  if (dims[0] * dims[1] * dims[2] > 1500000000L) return WCSPH_EARG;
+  s.nx = (int)dims[0]; s.ny = (int)dims[1]; s.nz = (int)dims[2]; s.ncell = s.nx * s.ny * s.nz;
+  std::vector<void *> mem;
+  hipError_t herr = hipSuccess;
+  auto A = [&](size_t bytes) -> void * { void *p = nullptr; if (herr == hipSuccess) herr = hipMalloc(&p, bytes ? bytes : 4); if (p) { mem.push_back(p); (void)hipMemset(p, 0, bytes ? bytes : 4); } return p; };
+  float *d_tri = (float *)A((size_t)n_tri * 36), *d_nrm = (float *)A((size_t)n_tri * 12), *d_area = (float *)A((size_t)n_tri * 4);
+  s.pos = (float *)A((size_t)s.n_cand * 12); s.tri_id = (int *)A((size_t)s.n_cand * 4); s.cell = (int *)A((size_t)s.n_cand * 4);
+  s.cnt = (int *)A(((size_t)s.ncell + 1) * 4); s.start = (int *)A(((size_t)s.ncell + 1) * 4); s.order = (int *)A((size_t)s.n_cand * 4);
+  s.samp_cnt = (int *)A((size_t)s.ncell * 4); s.samp = (int *)A((size_t)s.ncell * PS_MAX_PER_CELL * 4); s.accepted = (int *)A((size_t)s.n_cand * 4);
+  s.occ_start = (int *)A(28 * 4);
+  int rc = WCSPH_OK;
+  auto done = [&](int code) { for (void *p : mem) (void)hipFree(p); return code; };
+  if (herr != hipSuccess) return done(WCSPH_EHIP);
+  s.tri = d_tri; s.nrm = d_nrm; s.area = d_area;
+  (void)hipMemcpy(d_tri, tri_xyz, (size_t)n_tri * 36, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_nrm, nrm.data(), (size_t)n_tri * 12, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_area, area.data(), (size_t)n_tri * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_ps_init, dim3(nblk(s.n_cand)), dim3(BLOCK), 0, 0, s);
+  // cell table on the host (an offline tool: one pass over the dense cell array)
+  std::vector<int> cnt((size_t)s.ncell + 1), start((size_t)s.ncell + 1);
+  if (hipMemcpy(cnt.data(), s.cnt, ((size_t)s.ncell + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return done(WCSPH_EHIP);
+  std::vector<int> occ[27];
+  int run = 0;
+  for (int c = 0; c < s.ncell; c++) {
+    start[c] = run; run += cnt[c];
+    if (cnt[c] > 0) { const int cz = c % s.nz, cy = (c / s.nz) % s.ny, cx = c / (s.nz * s.ny); occ[cx % 3 + 3 * (cy % 3) + 9 * (cz % 3)].push_back(c); }   // boundry.py:265
+  }
+  start[s.ncell] = run;
+  std::vector<int> occ_all, occ_start(28, 0);
+  for (int g = 0; g < 27; g++) { occ_start[g] = (int)occ_all.size(); occ_all.insert(occ_all.end(), occ[g].begin(), occ[g].end()); }
+  occ_start[27] = (int)occ_all.size();
+  s.occ = (int *)A(occ_all.size() * 4);
+  if (herr != hipSuccess) return done(WCSPH_EHIP);
+  (void)hipMemcpy(s.start, start.data(), ((size_t)s.ncell + 1) * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(s.occ, occ_all.data(), occ_all.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(s.occ_start, occ_start.data(), 28 * 4, hipMemcpyHostToDevice);
+  (void)hipMemset(s.cnt, 0, ((size_t)s.ncell + 1) * 4);
+  hipLaunchKernelGGL(k_ps_place, dim3(nblk(s.n_cand)), dim3(BLOCK), 0, 0, s);
+  hipLaunchKernelGGL(k_ps_sort_cells, dim3(nblk(s.ncell)), dim3(BLOCK), 0, 0, s);
+  for (int trial = 0; trial < trials; trial++)          // boundry.py:424-458: trial_total rounds over the 27 phase groups
+    for (int pg = 0; pg < 27; pg++) {
+      const int n = occ_start[pg + 1] - occ_start[pg];
+      if (n > 0) hipLaunchKernelGGL(k_ps_trial, dim3(nblk(n)), dim3(BLOCK), 0, 0, s, pg, trial);
+    }
+  std::vector<int> acc(s.n_cand);
+  std::vector<float> pos((size_t)s.n_cand * 3);
+  if (hipMemcpy(acc.data(), s.accepted, (size_t)s.n_cand * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(pos.data(), s.pos, (size_t)s.n_cand * 12, hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess)
+    return done(WCSPH_EHIP);
+  int n = 0;
+  for (int i = 0; i < s.n_cand; i++)
+    if (acc[i]) { if (n < cap) { out_xyz[3 * n] = pos[3 * (size_t)i]; out_xyz[3 * n + 1] = pos[3 * (size_t)i + 1]; out_xyz[3 * n + 2] = pos[3 * (size_t)i + 2]; } n++; }
+  *n_out = n;
+  return done(rc);
 }
 
 // ---- measurement --------------------------------------------------------------------------------
