@@ -48,9 +48,10 @@ struct Dev {
   float4 *d_vel_pre, *pos_star, *vel_star, *d_ii, *dij_pj;
   float *a_ii, *pressure_pre;
   int *ncount;                            // HashGrid.neighborCount (raw list length)
-  // compact per-step neighbour lists (k-major: entry k of particle i at [k * nbr_stride + i])
-  int *nbr_l, *nbr_s;                     // sorted liquid index / sorted solid index
-  int *ncl, *ncs;                         // entries per particle
+  // compact per-step neighbour lists: 16-bit delta streams, 8 slots per 16-byte block, block b of particle i at
+  // [b * nbr_stride + i] (see "neighbour streams" below)
+  uint4 *nbl, *nbs;                       // liquid / solid streams
+  int2 *nhead;                            // x = liquid slots | solid slots << 16, y = sorted solid index the solid stream starts from
   int nbr_stride, nbr_cap;
   float list_r2;                          // squared support radius the lists are built with
   // LDS tiles (tile.h): active-tile list of the step, tile-local 16-bit neighbour lists
@@ -212,58 +213,130 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
   }
 }
 
-// The neighbour loop of every pass: iterate the compact list the grid update built for this step
-// (the in-support subset of the reference's HashGrid.neighbor row, duplicates included).
+// ---- neighbour streams ---------------------------------------------------------------------------------
+// The compact list of particle i (the in-support subset of the reference's HashGrid.neighbor row, duplicates
+// included) is stored as a stream of int16 DELTAS: slot k holds j_k - j_{k-1}, the liquid stream starting from
+// j_{-1} = i (neighbours are near i in the cell-sorted order), the solid stream from nhead[i].y.  A sorted index
+// needs 4 bytes, its delta 2: the index stream is what a pass reads most of (tools/ablate.py), so this halves the
+// HBM traffic of every neighbour pass.  Deltas that do not fit (the jump to another x-plane of a large grid) are
+// bridged by HOP slots, +-32767, which move the running index but are not entries.  Eight slots form one
+// 16-byte block; block b of particle i sits at [b * nbr_stride + i], so a wave loads 1 KB contiguous per trip.
+#define NB_HOP 32767
+#define NB_IS_ENTRY(dd) ((unsigned)((dd) + (NB_HOP - 1)) <= (unsigned)(2 * NB_HOP - 2))   // |dd| < NB_HOP
+
+// builder side: shift register of eight slots, flushed as whole blocks
+struct NbWriter {
+  uint4 *base;        // &stream[i]
+  size_t stride;
+  int run, slots, cap;
+  unsigned w0, w1, w2, w3;
+  __device__ __forceinline__ void init(uint4 *b, size_t st, int start, int cap_) { base = b; stride = st; run = start; slots = 0; cap = cap_; w0 = w1 = w2 = w3 = 0; }
+  __device__ __forceinline__ void slot(int dd) {
+    w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
+    w2 = __builtin_amdgcn_alignbit(w3, w2, 16); w3 = (w3 >> 16) | ((unsigned)dd << 16);
+    slots++;
+    if ((slots & 7) == 0 && slots <= cap) base[(size_t)((slots >> 3) - 1) * stride] = make_uint4(w0, w1, w2, w3);
+  }
+  __device__ __forceinline__ void entry(int j) {
+    int dd = j - run;
+    while (dd >= NB_HOP) { slot(NB_HOP); dd -= NB_HOP; }
+    while (dd <= -NB_HOP) { slot(-NB_HOP); dd += NB_HOP; }
+    slot(dd);
+    run = j;
+  }
+  // pads the last block with zero deltas (valid indices, masked by the slot count); returns the slot count
+  __device__ __forceinline__ int finish() {
+    const int n = slots;
+    if (n <= cap) while (slots & 7) slot(0);
+    return n;
+  }
+};
+
+// The neighbour loop of every pass: iterate the compact list the grid update built for this step.
 // As in the reference the list is frozen until the next update_grid() while r is recomputed from the
 // current positions (ref: dfsph.py:254-256 and every other `while k < cur_neighbor` loop).
 //
-// Latency structure: entry k of particle i sits in a 16-byte block of four ([k/4][i][k%4]); one trip
-// fetches U entries with U/4 coalesced 16-byte loads, then issues all U position gathers AND all U payload
-// gathers gl(j) (whatever the pass reads from neighbour j: vel_j, k_j, rho_j ...) before any arithmetic, so
-// a trip costs two dependent memory round trips instead of 2 per entry.
+// Latency structure: one trip decodes U slots from one coalesced 16-byte (U = 8) or 8-byte (U = 4) load, then
+// issues all U position gathers AND all U payload gathers gl(j) (whatever the pass reads from neighbour j: vel_j,
+// k_j, rho_j ...) before any arithmetic, so a trip costs two dependent memory round trips instead of 2 per entry.
 // fl(j, r, r2, payload) / fs(j, r, r2) are called for the liquid / solid entries.
-#define NBR_AT(k, stride, i) ((((size_t)((k) >> 2)) * (stride) + (i)) * 4 + ((k) & 3))
 // P: the float4 array positions are gathered from (d.pos, or a per-pass packed copy whose .w already holds
 // the neighbour payload so that one 16-byte gather per entry suffices); gl(j, p4) builds the payload.
-template <int U, class GL, class FL, class FS>
-__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
-  static_assert(U == 4 || U == 8, "U entries per trip");
-  const float3 xi = xyz(pi);
-  const size_t st = (size_t)d.nbr_stride;
-  const int cl = d.ncl[i];
-  const int4 *L = reinterpret_cast<const int4 *>(d.nbr_l) + i;
-  for (int k = 0; k < cl; k += U) {
-    const int4 e0 = L[(size_t)(k >> 2) * st];
-    int4 e1 = e0;
-    if (U == 8 && k + 4 < cl) e1 = L[(size_t)((k >> 2) + 1) * st];  // tail: e1 = e0 re-uses valid indices
-    // scalars, not an indexed array: keeps the indices in VGPRs (an int j[U] lands in scratch here)
-    const int j0 = e0.x, j1 = e0.y, j2 = e0.z, j3 = e0.w, j4 = e1.x, j5 = e1.y, j6 = e1.z, j7 = e1.w;
-    const float4 p0 = P[j0], p1 = P[j1], p2 = P[j2], p3 = P[j3];
-    const auto b0 = gl(j0, p0); const auto b1 = gl(j1, p1); const auto b2 = gl(j2, p2); const auto b3 = gl(j3, p3);
-    if (U == 8) {
-      const float4 p4 = P[j4], p5 = P[j5], p6 = P[j6], p7 = P[j7];
-      const auto b4 = gl(j4, p4); const auto b5 = gl(j5, p5); const auto b6 = gl(j6, p6); const auto b7 = gl(j7, p7);
-#define WALK_ONE(u, jj, pp, bb) if (k + u < cl) { const float3 r = xi - xyz(pp); fl(jj, r, dot3(r, r), bb); }
-      WALK_ONE(0, j0, p0, b0) WALK_ONE(1, j1, p1, b1) WALK_ONE(2, j2, p2, b2) WALK_ONE(3, j3, p3, b3)
-      WALK_ONE(4, j4, p4, b4) WALK_ONE(5, j5, p5, b5) WALK_ONE(6, j6, p6, b6) WALK_ONE(7, j7, p7, b7)
-    } else {
-      WALK_ONE(0, j0, p0, b0) WALK_ONE(1, j1, p1, b1) WALK_ONE(2, j2, p2, b2) WALK_ONE(3, j3, p3, b3)
-    }
-  }
-  const int cs = d.ncs[i];
-  const int4 *S = reinterpret_cast<const int4 *>(d.nbr_s) + i;
-  for (int k = 0; k < cs; k += 4) {
-    const int4 e = S[(size_t)(k >> 2) * st];
-    const int j[4] = {e.x, e.y, e.z, e.w};
-    float4 p[4];
+struct NoPayload {};
+// The first slot of a trip can be a hop, so its body is conditional -- and LLVM then sinks that slot's gathers into
+// the conditional block, behind the branch, which serialises a third memory round trip per trip.  Pinning the
+// loaded values right after the trip's last gather is issued keeps all gathers in front of the first branch.
+template <class T>
+__device__ __forceinline__ void nb_pin(T &v) {
+  if constexpr (sizeof(T) >= 4) {   // one dword of every 16-byte member is enough to hold its load in place
+    float *w = reinterpret_cast<float *>(&v);
 #pragma unroll
-    for (int u = 0; u < 4; u++) p[u] = d.spos[j[u]];
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (k + u < cs) {
-        const float3 r = xi - xyz(p[u]);
-        fs(j[u], r, dot3(r, r));
-      }
+    for (int q = 0; q < (int)(sizeof(T) / 4); q += 4) asm volatile("" : "+v"(w[q]));
   }
 }
-struct NoPayload {};
+// gather of element j of a kernel-argument array with a 32-bit byte offset: lets the compiler use the
+// `global_load vdst, voffset, saddr` form (one VGPR per address, one shift) instead of 64-bit pointer arithmetic
+template <class T>
+__device__ __forceinline__ T nb_ld(const T *base, int j) {
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)j * (unsigned)sizeof(T));
+}
+#define NB_LO(w) ((int)(short)((w) & 0xffffu))
+#define NB_HI(w) ((int)(w) >> 16)
+template <int U, class GL, class FL, class FS>
+__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
+  static_assert(U == 4 || U == 8, "U slots per trip");
+  const float3 xi = xyz(pi);
+  const size_t st = (size_t)d.nbr_stride;
+  const int2 head = d.nhead[i];
+  const int cl = head.x & 0xffff, cs = (int)((unsigned)head.x >> 16);
+  const uint4 *L = d.nbl + i;
+  int run = i;
+  // scalars, not indexed arrays: keeps the indices in VGPRs (an int j[U] lands in scratch here)
+#define WALK_ONE(u, dd, jj, pp, bb) if (dd) { const float3 r = xi - xyz(pp); fl(jj, r, dot3(r, r), bb); }
+#define WALK_OK(u, dd) const bool ok##u = (k + u < cl) & NB_IS_ENTRY(dd);   /* a lane mask in SGPRs: the deltas die here */
+  for (int k = 0; k < cl; k += U) {
+    if (U == 8) {
+      const uint4 e = L[(size_t)(k >> 3) * st];
+      const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
+      const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
+      run = j7;
+      WALK_OK(0, d0) WALK_OK(1, d1) WALK_OK(2, d2) WALK_OK(3, d3) WALK_OK(4, d4) WALK_OK(5, d5) WALK_OK(6, d6) WALK_OK(7, d7)
+      float4 p0 = nb_ld(P, j0);
+      const float4 p1 = nb_ld(P, j1), p2 = nb_ld(P, j2), p3 = nb_ld(P, j3);
+      auto b0 = gl(j0, p0); const auto b1 = gl(j1, p1); const auto b2 = gl(j2, p2); const auto b3 = gl(j3, p3);
+      const float4 p4 = nb_ld(P, j4), p5 = nb_ld(P, j5), p6 = nb_ld(P, j6), p7 = nb_ld(P, j7);
+      const auto b4 = gl(j4, p4); const auto b5 = gl(j5, p5); const auto b6 = gl(j6, p6); const auto b7 = gl(j7, p7);
+      nb_pin(p0); nb_pin(b0);
+      WALK_ONE(0, ok0, j0, p0, b0) WALK_ONE(1, ok1, j1, p1, b1) WALK_ONE(2, ok2, j2, p2, b2) WALK_ONE(3, ok3, j3, p3, b3)
+      WALK_ONE(4, ok4, j4, p4, b4) WALK_ONE(5, ok5, j5, p5, b5) WALK_ONE(6, ok6, j6, p6, b6) WALK_ONE(7, ok7, j7, p7, b7)
+    } else {
+      const uint2 e = reinterpret_cast<const uint2 *>(L + (size_t)(k >> 3) * st)[(k >> 2) & 1];
+      const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y);
+      const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3;
+      run = j3;
+      WALK_OK(0, d0) WALK_OK(1, d1) WALK_OK(2, d2) WALK_OK(3, d3)
+      float4 p0 = nb_ld(P, j0);
+      const float4 p1 = nb_ld(P, j1), p2 = nb_ld(P, j2), p3 = nb_ld(P, j3);
+      auto b0 = gl(j0, p0); const auto b1 = gl(j1, p1); const auto b2 = gl(j2, p2); const auto b3 = gl(j3, p3);
+      nb_pin(p0); nb_pin(b0);
+      WALK_ONE(0, ok0, j0, p0, b0) WALK_ONE(1, ok1, j1, p1, b1) WALK_ONE(2, ok2, j2, p2, b2) WALK_ONE(3, ok3, j3, p3, b3)
+    }
+  }
+#undef WALK_ONE
+#undef WALK_OK
+  const uint4 *S = d.nbs + i;
+  run = head.y;
+#define WALK_SOL(u, dd, jj, pp) if (k + u < cs && NB_IS_ENTRY(dd)) { const float3 r = xi - xyz(pp); fs(jj, r, dot3(r, r)); }
+  for (int k = 0; k < cs; k += 8) {
+    const uint4 e = S[(size_t)(k >> 3) * st];
+    const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
+    const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
+    run = j7;
+    float4 p0 = nb_ld(d.spos, j0);
+    const float4 p1 = nb_ld(d.spos, j1), p2 = nb_ld(d.spos, j2), p3 = nb_ld(d.spos, j3), p4 = nb_ld(d.spos, j4), p5 = nb_ld(d.spos, j5), p6 = nb_ld(d.spos, j6), p7 = nb_ld(d.spos, j7);
+    nb_pin(p0);
+    WALK_SOL(0, d0, j0, p0) WALK_SOL(1, d1, j1, p1) WALK_SOL(2, d2, j2, p2) WALK_SOL(3, d3, j3, p3)
+    WALK_SOL(4, d4, j4, p4) WALK_SOL(5, d5, j5, p5) WALK_SOL(6, d6, j6, p6) WALK_SOL(7, d7, j7, p7)
+  }
+#undef WALK_SOL
+}

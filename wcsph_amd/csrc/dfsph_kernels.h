@@ -4,6 +4,7 @@
 #pragma once
 #include "device.h"
 
+#define WAVES6
 #define LOAD_I                                        \
   const int i = sorted_index();                       \
   const bool live = i < d.nl;                         \
@@ -67,13 +68,13 @@ enum { DRHO_PLAIN = 0, DRHO_WARM = 1, DRHO_BEGIN = 2, DRHO_ITER = 3 };
 // k_i = b_i * alpha_i (dfsph.py:455-456 / 523-525), so that no separate k_make_k launch is needed;
 // kappa += k_i then happens in the prologue of the k_vel_from_k launch that consumes it.
 template <int MODE, bool FUSEK = false>
-__global__ void __launch_bounds__(BLOCK) k_drho_div(Dev d, float dt) {
+__global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_div(Dev d, float dt) {
   LOAD_I
   float a = 0.f;
   if (own) {
     if (MODE == DRHO_WARM) d.kappa_v[i] = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
     const float3 vi = xyz(d.vel[i]);
-    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.vel[j]; },
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
             [&](int, float3 r, float r2, float4 vj) { a += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
             [&](int, float3 r, float r2) { a += d.VS0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     a = fmaxf(a, 0.0f);
@@ -88,13 +89,13 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div(Dev d, float dt) {
 
 // ref: dfsph.py:394-412 update_drho_pressure, inlined at :513 (BEGIN), :545 (ITER)
 template <int MODE, bool FUSEK = false>
-__global__ void __launch_bounds__(BLOCK) k_drho_press(Dev d, float dt) {
+__global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
   LOAD_I
   float e = 0.f;
   if (own) {
     const float3 vi = xyz(d.vel[i]);
     float t = 0.f;
-    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.vel[j]; },
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
             [&](int, float3 r, float r2, float4 vj) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
             [&](int, float3 r, float r2) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
   if (!(d.adv_rho[i] > d.rho_L0)) return;
   const float ki = d.kappa[i], kvi = d.kappa_v[i];
   float3 acc = f3(0, 0, 0);
-  walk<4>(d, i, pi, d.pos, [&](int j, float4) { return d.kappa[j]; },
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.kappa, j); },
           [&](int, float3 r, float r2, float kj) {
             float s = ki + kj;
             if (fabsf(s) > d.eps) acc = acc + r * (dt * s * d.VL0 * cubic_gradW_scale(d, r2));
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_normal(Dev d) {
   LOAD_I
   if (!own) return;
   float3 n = f3(0, 0, 0);
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.rho[j]; },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
           [&](int, float3 r, float r2, float rhoj) { n = n + r * (d.mass / rhoj * cubic_gradW_scale(d, r2)); },
           [&](int, float3, float) {});
   d.normal[i] = f4(n * d.h, 0);
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel(Dev d) {
   const float3 ni = xyz(d.normal[i]);
   const float rhoi = d.rho[i];
   float3 acc = f3(0, 0, 0);
-  walk<4>(d, i, pi, d.pos, [&](int j, float4) { float4 n = d.normal[j]; n.w = d.rho[j]; return n; },
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { float4 n = nb_ld(d.normal, j); n.w = nb_ld(d.rho, j); return n; },
        [&](int, float3, float r2, float4 nj) {
          float kij = 2.0f * d.rho_L0 / (rhoi + nj.w);
          if (r2 <= d.h2) acc = acc + (ni - xyz(nj)) * (-d.tension * kij);
@@ -262,7 +263,7 @@ __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const 
   float3 ret = f3(0, 0, 0);
   const float cl = d.dim_coff * d.visc * d.mass;
   const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = x[j]; xj.w = d.rho[j]; return xj; },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(x, j); xj.w = nb_ld(d.rho, j); return xj; },
           [&](int, float3 r, float r2, float4 xj) {
             float s = cl / xj.w * dot3(xi - xyz(xj), r) / (r2 + e);
             ret = ret + r * (s * cubic_gradW_scale(d, r2));
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
     m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
     m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
   };
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.rho[j]; },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
           [&](int, float3 r, float r2, float rhoj) { accum(r, cl / rhoj / (r2 + e) * cubic_gradW_scale(d, r2)); },
           [&](int, float3 r, float r2) { accum(r, cs / (r2 + e) * cubic_gradW_scale(d, r2)); });
   const float f = dt / rhoi;
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
       m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
       m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
     };
-    walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = d.vel_guess[j]; xj.w = d.rho[j]; return xj; },
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(d.vel_guess, j); xj.w = nb_ld(d.rho, j); return xj; },
             [&](int, float3 r, float r2, float4 xj) {
               const float g = cubic_gradW_scale(d, r2) / (r2 + e);
               const float c = cl / xj.w * g;
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
   const float c2 = d.vort_coff / rhoi * d.mass;
   const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
   struct WV { float4 w, v; };
-  walk<4>(d, i, pi, d.pos, [&](int j, float4) { WV p; p.w = d.omega[j]; p.w.w = d.rho[j]; p.v = d.vel[j]; return p; },
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { WV p; p.w = nb_ld(d.omega, j); p.w.w = nb_ld(d.rho, j); p.v = nb_ld(d.vel, j); return p; },
        [&](int, float3 r, float r2, WV pj) {
          float3 dw = wi - xyz(pj.w);
          float g = cubic_gradW_scale(d, r2);
@@ -529,7 +530,7 @@ __global__ void __launch_bounds__(BLOCK) k_ss_force(Dev d) {
   const float pi2 = prsi / (rhoi * rhoi);
   float3 a = f3(d.gx, d.gy, d.gz);
   struct VP { float4 v; float p; };
-  walk<4>(d, i, pi, d.pos, [&](int j, float4) { VP q; q.v = d.vel[j]; q.v.w = d.rho[j]; q.p = d.pressure[j]; return q; },
+  walk<4>(d, i, pi, d.pos, [&](int j, float4) { VP q; q.v = nb_ld(d.vel, j); q.v.w = nb_ld(d.rho, j); q.p = nb_ld(d.pressure, j); return q; },
        [&](int, float3 r, float r2, VP q) {
          float g = cubic_gradW_scale(d, r2);
          float rhoj = q.v.w;

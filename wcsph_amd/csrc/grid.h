@@ -352,24 +352,24 @@ __global__ void k_ncount_clean(Dev d) {
 __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   const int i = sorted_index();
   if (i >= d.nl) return;
-  if (d.oid[i] >= d.n_owned) { if (liquid_too) d.ncl[i] = 0; d.ncs[i] = 0; return; }  // ghosts never run a neighbour loop
+  int2 head = d.nhead[i];
+  if (d.oid[i] >= d.n_owned) { d.nhead[i] = make_int2(liquid_too ? 0 : (head.x & 0xffff), 0); return; }  // ghosts never run a neighbour loop
   const float4 pi = d.pos[i];
   const size_t st = (size_t)d.nbr_stride;
-  int cl = 0, cs = 0;
   const int cap = d.nbr_cap;
+  NbWriter wl, ws;
+  wl.init(d.nbl + i, st, i, cap);
+  ws.init(d.nbs + i, st, 0, cap);
+  int sbase = -1;
   walk_cells(d, i, pi, liquid_too != 0,
+             [&](int j, float3, float, float m) { for (int rep = (int)m; rep > 0; rep--) wl.entry(j); },
              [&](int j, float3, float, float m) {
-               for (int rep = (int)m; rep > 0; rep--) { if (cl < cap) d.nbr_l[NBR_AT(cl, st, i)] = j; cl++; }
-             },
-             [&](int j, float3, float, float m) {
-               for (int rep = (int)m; rep > 0; rep--) { if (cs < cap) d.nbr_s[NBR_AT(cs, st, i)] = j; cs++; }
+               if (sbase < 0) { sbase = j; ws.run = j; }
+               for (int rep = (int)m; rep > 0; rep--) ws.entry(j);
              });
+  int cl = liquid_too ? wl.finish() : (head.x & 0xffff), cs = ws.finish();
   if (cl > cap || cs > cap) { atomicOr(&d.flags[FLAG_ERR], ERRBIT_LISTCAP); cl = min(cl, cap); cs = min(cs, cap); }
-  // pad the last 16-byte block with a valid index (the loop loads whole blocks)
-  for (int k = cl; (k & 3) && k < cap; k++) d.nbr_l[NBR_AT(k, st, i)] = 0;
-  for (int k = cs; (k & 3) && k < cap; k++) d.nbr_s[NBR_AT(k, st, i)] = 0;
-  if (liquid_too) d.ncl[i] = cl;
-  d.ncs[i] = cs;
+  d.nhead[i] = make_int2(cl | (cs << 16), max(sbase, 0));
 }
 
 // ---- slab decomposition: whole-state load / store in original (row) order -----------------------

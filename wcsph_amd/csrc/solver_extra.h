@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(BLOCK) k_pc_force(Dev d, float visc, float vis
   const float rhoi = d.rho[i];
   const float e = 0.01f * d.h2;
   float3 a = f3(d.gx, d.gy, d.gz);
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 v = d.vel[j]; v.w = d.rho[j]; return v; },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 v = nb_ld(d.vel, j); v.w = nb_ld(d.rho, j); return v; },
           [&](int, float3 r, float r2, float4 vj) {
             a = a + r * (d.ss_dim * visc * d.ss_mass / vj.w * dot3(vi - xyz(vj), r) / (r2 + e) * cubic_gradW_scale(d, r2));
           },
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(BLOCK) k_pc_pressure_force(Dev d) {
   if (!own) return;
   const float prsi = d.pressure[i];
   float3 a = f3(0, 0, 0);
-  walk<8>(d, i, pi, d.pos_star, [&](int j, float4) { return d.pressure[j]; },
+  walk<8>(d, i, pi, d.pos_star, [&](int j, float4) { return nb_ld(d.pressure, j); },
           [&](int, float3 r, float r2, float pj) { a = a + r * (-d.ss_VL0 * (prsi + pj) * cubic_gradW_scale(d, r2)); },
           [&](int, float3 r, float r2) { a = a + r * (-d.ss_VS0 * prsi * cubic_gradW_scale(d, r2)); });
   d.d_vel_pre[i] = f4(a, 0);
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(BLOCK) k_ii_aii(Dev d, float dt) {
   const float cji = d.ss_VL0 / (density * density);
   float adv = density, aii = 0.f;
   d.pressure_pre[i] = 0.5f * d.pressure[i];
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return d.vel[j]; },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
           [&](int, float3 r, float r2, float4 vj) {
             const float g = cubic_gradW_scale(d, r2);
             adv += dt * d.ss_VL0 * g * dot3(vi - xyz(vj), r);
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(BLOCK) k_ii_dijpj(Dev d) {
   if (!own) return;
   float3 s = f3(0, 0, 0);
   struct RP { float rho, pp; };
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { RP q; q.rho = d.rho[j]; q.pp = d.pressure_pre[j]; return q; },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { RP q; q.rho = nb_ld(d.rho, j); q.pp = nb_ld(d.pressure_pre, j); return q; },
           [&](int, float3 r, float r2, RP q) {
             const float dj = q.rho / d.ss_rho0;
             s = s + r * (-d.ss_VL0 / (dj * dj) * q.pp * cubic_gradW_scale(d, r2));
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(BLOCK) k_ii_pressure(Dev d, float dt, float om
     const float3 dpi = xyz(d.dij_pj[i]);
     float sum = 0.f;
     struct DP { float4 dij, dii; };   // dij.w = pressure_pre_j
-    walk<4>(d, i, pi, d.pos, [&](int j, float4) { DP q; q.dij = d.dij_pj[j]; q.dij.w = d.pressure_pre[j]; q.dii = d.d_ii[j]; return q; },
+    walk<4>(d, i, pi, d.pos, [&](int j, float4) { DP q; q.dij = nb_ld(d.dij_pj, j); q.dij.w = nb_ld(d.pressure_pre, j); q.dii = nb_ld(d.d_ii, j); return q; },
             [&](int, float3 r, float r2, DP q) {
               const float g = cubic_gradW_scale(d, r2);
               const float3 d_ji_pi = r * (cji * g * ppi);
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(BLOCK) k_ii_pressure_accel(Dev d) {
   const float di = d.rho[i] / d.ss_rho0, dpi = d.pressure[i] / (di * di);
   float3 a = f3(0, 0, 0);
   struct RP { float rho, p; };
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { RP q; q.rho = d.rho[j]; q.p = d.pressure[j]; return q; },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { RP q; q.rho = nb_ld(d.rho, j); q.p = nb_ld(d.pressure, j); return q; },
           [&](int, float3 r, float r2, RP q) {
             const float dj = q.rho / d.ss_rho0;
             a = a + r * (-d.ss_VL0 * (dpi + q.p / (dj * dj)) * cubic_gradW_scale(d, r2));

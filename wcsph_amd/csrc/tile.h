@@ -234,9 +234,14 @@ __device__ __forceinline__ void walk_tile(const Dev &d, const TileParticle &tp, 
       e = en;
     }
   }
-  const int cs = d.ncs[tp.i];
-  for (int k = 0; k < cs; k++) {
-    const int j0 = d.nbr_s[NBR_AT(k, st, tp.i)];
+  const int2 head = d.nhead[tp.i];
+  const int cs = (int)((unsigned)head.x >> 16);
+  const unsigned short *S = reinterpret_cast<const unsigned short *>(d.nbs + tp.i);
+  int j0 = head.y;
+  for (int k = 0; k < cs; k++) {   // solid delta stream of the global compact list (device.h "neighbour streams")
+    const int dd = (int)(short)S[(size_t)(k >> 3) * st * 8 + (k & 7)];
+    j0 += dd;
+    if (!NB_IS_ENTRY(dd)) continue;
     const float3 r0 = xi - xyz(d.spos[j0]);
     fs(j0, r0, dot3(r0, r0));
   }

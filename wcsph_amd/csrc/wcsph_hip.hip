@@ -18,6 +18,9 @@
 #include "solver_extra.h"
 #include "surface.h"
 #include "sampler.h"
+#include "ablate.h"
+#define ablate_drho kx_drho
+#define ablate_vel kx_vel
 
 struct wcsph_ctx {
   wcsph_params p;
@@ -172,7 +175,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.cg_r, nl); DALLOC(d.cg_dir, nl); DALLOC(d.cg_Ad, nl); DALLOC(d.cg_s, nl);
   DALLOC(d.minv0, nl); DALLOC(d.minv1, nl); DALLOC(d.minv2, nl);
   DALLOC(d.rho, nl); DALLOC(d.adv_rho, nl); DALLOC(d.pressure, nl); DALLOC(d.vel_max, nl); DALLOC(d.alpha, nl); DALLOC(d.kbuf, nl);
-  DALLOC(d.ncount, nl); DALLOC(d.ncl, nl); DALLOC(d.ncs, nl); DALLOC(d.pk, nl);
+  DALLOC(d.ncount, nl); DALLOC(d.nhead, nl); DALLOC(d.pk, nl);
   DALLOC(d.d_vel_pre, nl); DALLOC(d.pos_star, nl); DALLOC(d.vel_star, nl); DALLOC(d.d_ii, nl); DALLOC(d.dij_pj, nl);
   DALLOC(d.a_ii, nl); DALLOC(d.pressure_pre, nl);
   d.nbr_stride = (int)((nl + 63) / 64 * 64);
@@ -180,7 +183,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   if (d.nbr_cap > p->max_neighbour) d.nbr_cap = p->max_neighbour;
   d.nbr_cap = (d.nbr_cap + 7) & ~7;
   if (d.nbr_cap < 1) d.nbr_cap = 1;
-  DALLOC(d.nbr_l, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.nbr_s, (size_t)d.nbr_stride * d.nbr_cap);
+  DALLOC(d.nbl, (size_t)d.nbr_stride * (d.nbr_cap / 8)); DALLOC(d.nbs, (size_t)d.nbr_stride * (d.nbr_cap / 8));
   if (ctx->use_tiles) { DALLOC(d.nbr16, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.cnt16, nl); }
   DALLOC(d.spos, (size_t)d.ns);
   DALLOC(d.acc, 8); DALLOC(d.flags, 4);
@@ -1292,6 +1295,20 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "density_coff") { PASS(k_density_coff); return 0; }
     if (nm == "grid_update") return wcsph_grid_update(ctx);
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
+#define ABLATE_CASE(kern, n) if (nm == #kern ":" #n) { PASS(kern<n>, ctx->dt); return 0; }
+    ABLATE_CASE(ablate_drho, 0) ABLATE_CASE(ablate_drho, 1) ABLATE_CASE(ablate_drho, 2) ABLATE_CASE(ablate_drho, 3) ABLATE_CASE(ablate_drho, 4) ABLATE_CASE(ablate_drho, 5)
+    ABLATE_CASE(ablate_vel, 0) ABLATE_CASE(ablate_vel, 1) ABLATE_CASE(ablate_vel, 2) ABLATE_CASE(ablate_vel, 3)
+    if (nm.rfind("blocked:", 0) == 0) {   // vel then drho slab by slab: do the second pass's list reads hit the Infinity Cache?
+      const int S = std::max(1, atoi(nm.c_str() + 8)), nl = ctx->d.nl, per = (nl + S - 1) / S;
+      for (int s0 = 0; s0 < S; s0++) {
+        const int i0 = s0 * per, n = std::min(per, nl - i0);
+        if (n <= 0) break;
+        hipLaunchKernelGGL(kx_vel<0>, dim3(nblk8(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->dt, i0, n);
+        hipLaunchKernelGGL(kx_drho<0>, dim3(nblk8(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->dt, i0, n);
+      }
+      LAUNCHCHK();
+      return 0;
+    }
     return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");
   };
   if (nm == "pressure_iter" && (rc = pressure_iter_async(ctx))) return rc;      // primes the (pos, k) records
