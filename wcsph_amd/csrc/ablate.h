@@ -6,6 +6,7 @@
 //   2 no index loads, gathers read consecutive records (math + coalesced gathers)
 //   3 full memory traffic, no kernel math (sum of the gathered components)
 //   4 like 0 but the payload gather (vel_j) is dropped (one gather per entry)
+//   6 = 0 + hop-slot test   7 = 6 + block reduction and one double atomic per block   8 = 6 + ownership test (oid)
 //   5 the two gathers of an entry read the two halves of ONE 32-byte aligned record (emulates interleaved pos|vel)
 // (hop slots are treated as entries here: timing only)
 // Measured on the 32-bit index lists this replaced (C3, faithful, us): vel 79 -> own-record 70, no-index 38, no-math 77;
@@ -24,14 +25,14 @@ __device__ __forceinline__ void walk_abl(const Dev &d, int i, float4 pi, const f
   const int top = d.nl - 1;
   int run = i;
   for (int k = 0; k < cl; k += 8) {
-    int j0, j1, j2, j3, j4, j5, j6, j7;
+    int j0, j1, j2, j3, j4, j5, j6, j7, dd0 = 0, dd1 = 0, dd2 = 0, dd3 = 0, dd4 = 0, dd5 = 0, dd6 = 0, dd7 = 0;
     if (ABL == 2) {
       j0 = min(i + k + 1, top); j1 = min(i + k + 2, top); j2 = min(i + k + 3, top); j3 = min(i + k + 4, top);
       j4 = min(i + k + 5, top); j5 = min(i + k + 6, top); j6 = min(i + k + 7, top); j7 = min(i + k + 8, top);
     } else {
       const uint4 e = L[(size_t)(k >> 3) * st];
-      j0 = run + NB_LO(e.x); j1 = j0 + NB_HI(e.x); j2 = j1 + NB_LO(e.y); j3 = j2 + NB_HI(e.y);
-      j4 = j3 + NB_LO(e.z); j5 = j4 + NB_HI(e.z); j6 = j5 + NB_LO(e.w); j7 = j6 + NB_HI(e.w);
+      dd0 = NB_LO(e.x); dd1 = NB_HI(e.x); dd2 = NB_LO(e.y); dd3 = NB_HI(e.y); dd4 = NB_LO(e.z); dd5 = NB_HI(e.z); dd6 = NB_LO(e.w); dd7 = NB_HI(e.w);
+      j0 = run + dd0; j1 = j0 + dd1; j2 = j1 + dd2; j3 = j2 + dd3; j4 = j3 + dd4; j5 = j4 + dd5; j6 = j5 + dd6; j7 = j6 + dd7;
       run = j7;
       if (ABL == 1) {   // keep a data dependence on the loaded slots without following them
         j0 = i + (j0 >> 31); j1 = i + (j1 >> 31); j2 = i + (j2 >> 31); j3 = i + (j3 >> 31);
@@ -50,7 +51,7 @@ __device__ __forceinline__ void walk_abl(const Dev &d, int i, float4 pi, const f
       b4 = p4; b5 = p5; b6 = p6; b7 = p7;
       if (TWO && ABL != 4) { b4 = Q[j4]; b5 = Q[j5]; b6 = Q[j6]; b7 = Q[j7]; }
     }
-#define ABL_ONE(u, pp, bb) if (k + u < cl) { const float3 r = xi - xyz(pp); fl(r, dot3(r, r), bb); }
+#define ABL_ONE(u, pp, bb) if (k + u < cl && (ABL < 6 || NB_IS_ENTRY(dd##u))) { const float3 r = xi - xyz(pp); fl(r, dot3(r, r), bb); }
     ABL_ONE(0, p0, b0) ABL_ONE(1, p1, b1) ABL_ONE(2, p2, b2) ABL_ONE(3, p3, b3)
     ABL_ONE(4, p4, b4) ABL_ONE(5, p5, b5) ABL_ONE(6, p6, b6) ABL_ONE(7, p7, b7)
   }
@@ -86,7 +87,21 @@ __global__ void __launch_bounds__(BLOCK) kx_drho(Dev d, float dt, int i0 = 0, in
     if (ABL == 3) t += r.x + r.y + r.z + vj.x + vj.y + vj.z;
     else t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r);
   });
-  d.adv_rho[i] = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
+  const float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
+  if (ABL == 8 && d.oid[i] >= d.n_owned) return;
+  d.adv_rho[i] = a;
+  if (ABL == 7) block_accumulate(ACC_SLOT(d, ACC_ERR), a - 1.0f);
+  // striped accumulators: 64 targets 8 B / 256 B / 4 KB apart (d.kbuf is scratch here)
+  if (ABL == 9) block_accumulate(reinterpret_cast<double *>(d.kbuf) + (blockIdx.x & 63), a - 1.0f);
+  if (ABL == 10) block_accumulate(reinterpret_cast<double *>(d.kbuf) + (blockIdx.x & 63) * 32, a - 1.0f);
+  if (ABL == 11) block_accumulate(reinterpret_cast<double *>(d.kbuf) + (blockIdx.x & 63) * 512, a - 1.0f);
+  if (ABL == 12) {   // no atomics: one plain store per block
+    __shared__ float sh2[BLOCK / WAVE];
+    float v = wave_sum(a - 1.0f);
+    if ((threadIdx.x & (WAVE - 1)) == 0) sh2[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) d.kbuf[blockIdx.x] = sh2[0] + sh2[1] + sh2[2] + sh2[3];
+  }
 }
 
 template <int ABL>

@@ -68,7 +68,7 @@ struct Dev {
   int *cell_info;     // [ncell] bit0: solids within the 5^3 walk; bits1..: alias slot + 1
   uint16_t *alias;    // [n_alias][ALIAS_STRIDE]
   // reductions
-  double *acc;        // [8]
+  double *acc;        // [8 slots][ACC_STRIPES]
   int *flags;         // [4] error bits, vmax bits
 };
 
@@ -120,8 +120,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
   return v;
 }
+// Reduction slots are STRIPED: slot S owns ACC_STRIPES doubles and block b adds to stripe b % ACC_STRIPES.  Device
+// scope atomics are resolved at the memory side, one per address at a time: 7.8 k blocks adding to ONE double cost a
+// pass 27 us at C3 (tools/ablate.py, drho 7 vs 9); over 64 addresses it is 2 us.  Readers sum the stripes
+// (acc_total on the device, pull_scalars on the host).
+#define ACC_STRIPES 64
+#define ACC_SLOT(d, S) ((d).acc + (S) * ACC_STRIPES)
 // every thread of the block must call this
-__device__ __forceinline__ void block_accumulate(double *dst, float v) {
+__device__ __forceinline__ void block_accumulate(double *slot, float v) {
+  double *dst = slot + (blockIdx.x & (ACC_STRIPES - 1));
   __shared__ float sh[BLOCK / WAVE];
   v = wave_sum(v);
   int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
@@ -133,6 +140,19 @@ __device__ __forceinline__ void block_accumulate(double *dst, float v) {
     for (int k = 0; k < BLOCK / WAVE; k++) s += sh[k];
     atomicAdd(dst, (double)s);
   }
+}
+
+// total of a striped slot; every thread of the block must call this (blocks of at least one wave)
+__device__ __forceinline__ double acc_total(const double *slot) {
+  __shared__ double tot;
+  if (threadIdx.x < WAVE) {
+    double v = slot[threadIdx.x & (ACC_STRIPES - 1)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    if (threadIdx.x == 0) tot = v;
+  }
+  __syncthreads();
+  return tot;
 }
 
 // The cell walk (grid update only).  fl(j, r, r2, m) is called for every liquid list entry j != i

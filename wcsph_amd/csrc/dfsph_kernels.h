@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_div(Dev d, float dt) {
     if (MODE == DRHO_BEGIN) { al = al / dt; d.alpha[i] = al; d.kappa_v[i] = 0.0f; }
     if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * al);
   }
-  if (MODE == DRHO_ITER) block_accumulate(&d.acc[ACC_ERR], a);  // ref: dfsph.py:476 avg_density_err += adv_rho
+  if (MODE == DRHO_ITER) block_accumulate(ACC_SLOT(d, ACC_ERR), a);  // ref: dfsph.py:476 avg_density_err += adv_rho
 }
 
 // ref: dfsph.py:394-412 update_drho_pressure, inlined at :513 (BEGIN), :545 (ITER)
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
     if (MODE == DRHO_BEGIN) { al = al / dt / dt; d.alpha[i] = al; d.kappa[i] = 0.0f; }
     if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, e * al);
   }
-  if (MODE == DRHO_ITER) block_accumulate(&d.acc[ACC_ERR], e);  // ref: dfsph.py:546
+  if (MODE == DRHO_ITER) block_accumulate(ACC_SLOT(d, ACC_ERR), e);  // ref: dfsph.py:546
 }
 
 // first half of divergence_iter / pressure_iter, per-particle part (ref: dfsph.py:456-458, 525-527):
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_residual(Dev d, float dt) {
     d.cg_dir[i] = f4(dir, 0);
     part = dot3(r, dir);
   }
-  block_accumulate(&d.acc[ACC_DZERO], part);
+  block_accumulate(ACC_SLOT(d, ACC_DZERO), part);
 }
 // fused dfsph.py:202-223: one neighbour walk builds the preconditioner block AND A(v_guess) (both read rho_j,
 // the second also v_guess_j); used by the fused host path, the split kernels above stay for the per-phase API
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
     d.cg_dir[i] = f4(dir, 0);
     part = dot3(res, dir);
   }
-  block_accumulate(&d.acc[ACC_DZERO], part);
+  block_accumulate(ACC_SLOT(d, ACC_DZERO), part);
 }
 
 // ref: dfsph.py:227-230: Ad = A(dir); dAd = eps + sum dir.Ad
@@ -380,14 +380,15 @@ __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
     d.cg_Ad[i] = f4(ad, 0);
     part = dot3(xyz(d.cg_dir[i]), ad);
   }
-  block_accumulate(&d.acc[ACC_DAD], part);
+  block_accumulate(ACC_SLOT(d, ACC_DAD), part);
 }
 // ref: dfsph.py:233-240: alpha = delta / dAd; v_guess += alpha d; r -= alpha Ad; s = Minv r; delta' = sum r.s
 __global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float part = 0.f;
+  const double dAd = acc_total(ACC_SLOT(d, ACC_DAD));
   if (i < d.nl && d.oid[i] < d.n_owned) {
-    const float alpha = delta / (float)((double)d.eps + d.acc[ACC_DAD]);
+    const float alpha = delta / (float)((double)d.eps + dAd);
     float3 dir = xyz(d.cg_dir[i]);
     d.vel_guess[i] = f4(xyz(d.vel_guess[i]) + dir * alpha, 0);
     float3 r = xyz(d.cg_r[i]) - xyz(d.cg_Ad[i]) * alpha;
@@ -396,13 +397,14 @@ __global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta) {
     d.cg_s[i] = f4(s, 0);
     part = dot3(r, s);
   }
-  block_accumulate(&d.acc[ACC_DNEW], part);
+  block_accumulate(ACC_SLOT(d, ACC_DNEW), part);
 }
 // ref: dfsph.py:243-246: beta = delta' / delta_old; d = s + beta d
 __global__ void k_visc_dir(Dev d, float delta_old) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double dnew = acc_total(ACC_SLOT(d, ACC_DNEW));
   if (i >= d.nl || d.oid[i] >= d.n_owned) return;
-  const float beta = (float)d.acc[ACC_DNEW] / delta_old;
+  const float beta = (float)dnew / delta_old;
   d.cg_dir[i] = f4(xyz(d.cg_s[i]) + xyz(d.cg_dir[i]) * beta, 0);
 }
 // ref: dfsph.py:339-343 end_viscosity

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(BLOCK) k_pc_predict(Dev d, float dt, float pci
     d.pressure[i] += pci_coff * (a - 1.0f) / (dt * dt);
     e = a - 1.0f;
   }
-  block_accumulate(&d.acc[ACC_ERR], e);
+  block_accumulate(ACC_SLOT(d, ACC_ERR), e);
 }
 // ref: pcisph.py:258-278: gradW(pos_i - pos_star_j) for liquid j, gradW(pos_i - pos_j) for solid j
 __global__ void __launch_bounds__(BLOCK) k_pc_pressure_force(Dev d) {
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(BLOCK) k_ii_pressure(Dev d, float dt, float om
     d.pressure[i] = p;
     if (p != 0.0f) e = (aii * p + sum) * h2 - b;
   }
-  block_accumulate(&d.acc[ACC_ERR], e);
+  block_accumulate(ACC_SLOT(d, ACC_ERR), e);
 }
 // ref: iisph.py:372-391
 __global__ void __launch_bounds__(BLOCK) k_ii_pressure_accel(Dev d) {

@@ -180,7 +180,7 @@ __device__ __forceinline__ void tblock_accumulate(double *dst, float v) {   // e
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < TBLOCK / WAVE; k++) s += sh[k];
-    atomicAdd(dst, (double)s);
+    atomicAdd(dst + (blockIdx.x & (ACC_STRIPES - 1)), (double)s);
   }
 }
 
@@ -384,5 +384,5 @@ __global__ void __launch_bounds__(TBLOCK, 4) kt_drho(Dev d, float dt) {
       }
     }
   TILE_LOOP_END
-  if (MODE == DRHO_ITER) tblock_accumulate(&d.acc[ACC_ERR], part);
+  if (MODE == DRHO_ITER) tblock_accumulate(ACC_SLOT(d, ACC_ERR), part);
 }

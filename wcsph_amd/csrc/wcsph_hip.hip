@@ -43,7 +43,8 @@ struct wcsph_ctx {
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats
   std::vector<float> solid_host;  // original-order solid positions
-  double *h_acc = nullptr;        // pinned [8]
+  double *h_acc_raw = nullptr;    // pinned [8][ACC_STRIPES]
+  double h_acc[8] = {0};          // stripe totals of the last pull_scalars()
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
   float dt = 0.0f;
@@ -107,13 +108,18 @@ static int check_flags(wcsph_ctx *ctx) {
 }
 // copy reduction slots + flags to the host and wait
 static int pull_scalars(wcsph_ctx *ctx) {
-  HIPCHK(hipMemcpyAsync(ctx->h_acc, ctx->d.acc, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_acc_raw, ctx->d.acc, 8 * ACC_STRIPES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->h_flags, ctx->d.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < 8; s++) {
+    double t = 0.0;
+    for (int k = 0; k < ACC_STRIPES; k++) t += ctx->h_acc_raw[s * ACC_STRIPES + k];
+    ctx->h_acc[s] = t;
+  }
   return check_flags(ctx);
 }
 static int zero_acc(wcsph_ctx *ctx, int slot) {
-  HIPCHK(hipMemsetAsync(ctx->d.acc + slot, 0, sizeof(double), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d.acc + slot * ACC_STRIPES, 0, ACC_STRIPES * sizeof(double), ctx->stream));
   return 0;
 }
 
@@ -186,14 +192,14 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.nbl, (size_t)d.nbr_stride * (d.nbr_cap / 8)); DALLOC(d.nbs, (size_t)d.nbr_stride * (d.nbr_cap / 8));
   if (ctx->use_tiles) { DALLOC(d.nbr16, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.cnt16, nl); }
   DALLOC(d.spos, (size_t)d.ns);
-  DALLOC(d.acc, 8); DALLOC(d.flags, 4);
+  DALLOC(d.acc, 8 * ACC_STRIPES); DALLOC(d.flags, 4);
   size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
   DALLOC(ctx->pw, nmax); DALLOC(ctx->slot, nmax);
   size_t stage_n = (nl + d.ns) * 3 > nl * 9 ? (nl + d.ns) * 3 : nl * 9;
   DALLOC(ctx->stage, stage_n);
-  HIPCHK(hipHostMalloc((void **)&ctx->h_acc, 8 * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **)&ctx->h_acc_raw, 8 * ACC_STRIPES * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&ctx->h_flags, 4 * sizeof(int)));
-  memset(ctx->h_acc, 0, 8 * sizeof(double)); memset(ctx->h_flags, 0, 4 * sizeof(int));
+  memset(ctx->h_acc_raw, 0, 8 * ACC_STRIPES * sizeof(double)); memset(ctx->h_flags, 0, 4 * sizeof(int));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return WCSPH_OK;
 }
@@ -202,7 +208,7 @@ int wcsph_destroy(wcsph_ctx *ctx) {
   if (!ctx) return WCSPH_EARG;
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
   for (void *p : ctx->allocs) hipFree(p);
-  if (ctx->h_acc) hipHostFree(ctx->h_acc);
+  if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -1149,8 +1155,10 @@ int wcsph_get_acc(wcsph_ctx *ctx, int slot, double *v) {
 }
 int wcsph_set_acc(wcsph_ctx *ctx, int slot, double v) {
   if (!ctx || slot < 0 || slot >= 8) return WCSPH_EARG;
-  HIPCHK(hipMemcpyAsync(ctx->d.acc + slot, &v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));  // v lives on the caller's stack
+  double row[ACC_STRIPES] = {0};
+  row[0] = v;
+  HIPCHK(hipMemcpyAsync(ctx->d.acc + slot * ACC_STRIPES, row, sizeof row, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // row lives on this stack
   return WCSPH_OK;
 }
 int wcsph_phase(wcsph_ctx *ctx, int ph) {
@@ -1296,7 +1304,7 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "grid_update") return wcsph_grid_update(ctx);
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
 #define ABLATE_CASE(kern, n) if (nm == #kern ":" #n) { PASS(kern<n>, ctx->dt); return 0; }
-    ABLATE_CASE(ablate_drho, 0) ABLATE_CASE(ablate_drho, 1) ABLATE_CASE(ablate_drho, 2) ABLATE_CASE(ablate_drho, 3) ABLATE_CASE(ablate_drho, 4) ABLATE_CASE(ablate_drho, 5)
+    ABLATE_CASE(ablate_drho, 0) ABLATE_CASE(ablate_drho, 1) ABLATE_CASE(ablate_drho, 2) ABLATE_CASE(ablate_drho, 3) ABLATE_CASE(ablate_drho, 4) ABLATE_CASE(ablate_drho, 5) ABLATE_CASE(ablate_drho, 6) ABLATE_CASE(ablate_drho, 7) ABLATE_CASE(ablate_drho, 8) ABLATE_CASE(ablate_drho, 9) ABLATE_CASE(ablate_drho, 10) ABLATE_CASE(ablate_drho, 11) ABLATE_CASE(ablate_drho, 12)
     ABLATE_CASE(ablate_vel, 0) ABLATE_CASE(ablate_vel, 1) ABLATE_CASE(ablate_vel, 2) ABLATE_CASE(ablate_vel, 3)
     if (nm.rfind("blocked:", 0) == 0) {   // vel then drho slab by slab: do the second pass's list reads hit the Infinity Cache?
       const int S = std::max(1, atoi(nm.c_str() + 8)), nl = ctx->d.nl, per = (nl + S - 1) / S;
