@@ -89,11 +89,16 @@ __device__ __forceinline__ float4 f4(float3 v, float w) { return make_float4(v.x
 
 // ref: kernels/CubicKernel.py:43-54 (Cubic_W_P) * m_k*h3 -- caller guarantees r2 <= h2
 __device__ __forceinline__ float cubic_W(const Dev &d, float r2) {
-  float q = sqrtf(r2) * d.inv_h;
+  // |r| = r2 * rsq(r2): the same rsq cubic_gradW_scale needs (one transcendental for both when a pass calls both);
+  // sqrtf() would expand to a ~17-instruction correctly rounded sequence per entry
+  float q = r2 * rsqrtf(fmaxf(r2, 1e-30f)) * d.inv_h;
   float f = 1.0f - q;
   float w = (q <= 0.5f) ? (6.0f * q * q * q - 6.0f * q * q + 1.0f) : (2.0f * f * f * f);
   return (q <= 1.0f) ? w * d.mk_h3 : 0.0f;
 }
+// 1-ulp reciprocal (v_rcp_f32) for the per-entry quotients of the neighbour loops; `/` is the ~10-instruction
+// correctly rounded sequence and stays in the per-particle code
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // ref: kernels/CubicKernel.py:20-32 (CubicGradW) -- returns g with gradW = g * r
 __device__ __forceinline__ float cubic_gradW_scale(const Dev &d, float r2) {
   float inv_rl = rsqrtf(fmaxf(r2, 1e-30f));

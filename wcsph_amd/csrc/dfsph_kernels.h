@@ -60,6 +60,41 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
   d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
 }
 
+// wcsph_dfsph_step only: compute_density + compute_dfsph_coff + the first pass of warmstart_divergence
+// (update_drho_divergence, dfsph.py:418, with the kappa_v rescale of :416) in ONE walk -- all three read only
+// pos_j / vel_j over the same frozen list -- and the (pos, kappa_v) gather record of the warm-start velocity pass.
+__global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
+  LOAD_I
+  if (!own) return;
+  float sl = 0.f, ss = 0.f, sq = 0.f, a = 0.f;
+  float3 sg = f3(0, 0, 0);
+  const float3 vi = xyz(d.vel[i]);
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+          [&](int, float3 r, float r2, float4 vj) {
+            sl += cubic_W(d, r2);
+            const float gw = cubic_gradW_scale(d, r2);
+            const float g = gw * d.VL0;
+            sq += g * g * r2;
+            sg = sg + r * g;
+            a += d.VL0 * gw * dot3(vi - xyz(vj), r);
+          },
+          [&](int, float3 r, float r2) {
+            ss += cubic_W(d, r2);
+            const float gw = cubic_gradW_scale(d, r2);
+            sg = sg + r * (gw * d.VS0);
+            a += d.VS0 * gw * dot3(vi, r);
+          });
+  d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  sq += dot3(sg, sg);
+  d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
+  const float kv = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
+  d.kappa_v[i] = kv;
+  a = fmaxf(a, 0.0f);
+  if (d.ncount[i] < 20) a = 0.0f;  // raw list length, Q2
+  d.adv_rho[i] = a;
+  d.pk[i] = make_float4(pi.x, pi.y, pi.z, kv);
+}
+
 // ---- density-change passes ------------------------------------------------------------------
 enum { DRHO_PLAIN = 0, DRHO_WARM = 1, DRHO_BEGIN = 2, DRHO_ITER = 3 };
 
@@ -219,7 +254,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_normal(Dev d) {
   if (!own) return;
   float3 n = f3(0, 0, 0);
   walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
-          [&](int, float3 r, float r2, float rhoj) { n = n + r * (d.mass / rhoj * cubic_gradW_scale(d, r2)); },
+          [&](int, float3 r, float r2, float rhoj) { n = n + r * (d.mass * frcp(rhoj) * cubic_gradW_scale(d, r2)); },
           [&](int, float3, float) {});
   d.normal[i] = f4(n * d.h, 0);
 }
@@ -237,7 +272,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel(Dev d) {
   float3 acc = f3(0, 0, 0);
   walk<4>(d, i, pi, d.pos, [&](int j, float4) { float4 n = nb_ld(d.normal, j); n.w = nb_ld(d.rho, j); return n; },
        [&](int, float3, float r2, float4 nj) {
-         float kij = 2.0f * d.rho_L0 / (rhoi + nj.w);
+         float kij = 2.0f * d.rho_L0 * frcp(rhoi + nj.w);
          if (r2 <= d.h2) acc = acc + (ni - xyz(nj)) * (-d.tension * kij);
        },
        [&](int j, float3 r, float r2) {
@@ -265,11 +300,11 @@ __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const 
   const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
   walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(x, j); xj.w = nb_ld(d.rho, j); return xj; },
           [&](int, float3 r, float r2, float4 xj) {
-            float s = cl / xj.w * dot3(xi - xyz(xj), r) / (r2 + e);
+            float s = cl * dot3(xi - xyz(xj), r) * frcp(xj.w * (r2 + e));
             ret = ret + r * (s * cubic_gradW_scale(d, r2));
           },
           [&](int, float3 r, float r2) {
-            float s = cs * dot3(xi, r) / (r2 + e);
+            float s = cs * dot3(xi, r) * frcp(r2 + e);
             ret = ret + r * (s * cubic_gradW_scale(d, r2));
           });
   return xi - ret * (dt / rhoi);
@@ -295,8 +330,8 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
     m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
   };
   walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
-          [&](int, float3 r, float r2, float rhoj) { accum(r, cl / rhoj / (r2 + e) * cubic_gradW_scale(d, r2)); },
-          [&](int, float3 r, float r2) { accum(r, cs / (r2 + e) * cubic_gradW_scale(d, r2)); });
+          [&](int, float3 r, float r2, float rhoj) { accum(r, cl * frcp(rhoj * (r2 + e)) * cubic_gradW_scale(d, r2)); },
+          [&](int, float3 r, float r2) { accum(r, cs * frcp(r2 + e) * cubic_gradW_scale(d, r2)); });
   const float f = dt / rhoi;
   float a = 1.0f - m00 * f, b = -m01 * f, c = -m02 * f, dd = 1.0f - m11 * f, ee = -m12 * f, ff = 1.0f - m22 * f;
   // inverse of the symmetric matrix [[a b c][b dd ee][c ee ff]] by adjugate / determinant
@@ -344,13 +379,12 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
     };
     walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(d.vel_guess, j); xj.w = nb_ld(d.rho, j); return xj; },
             [&](int, float3 r, float r2, float4 xj) {
-              const float g = cubic_gradW_scale(d, r2) / (r2 + e);
-              const float c = cl / xj.w * g;
+              const float c = cl * cubic_gradW_scale(d, r2) * frcp(xj.w * (r2 + e));
               accum(r, c);
               ret = ret + r * (c * dot3(xi - xyz(xj), r));
             },
             [&](int, float3 r, float r2) {
-              const float c = cs * cubic_gradW_scale(d, r2) / (r2 + e);
+              const float c = cs * cubic_gradW_scale(d, r2) * frcp(r2 + e);
               accum(r, c);
               ret = ret + r * (c * dot3(xi, r));
             });
@@ -434,7 +468,7 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
        [&](int, float3 r, float r2, WV pj) {
          float3 dw = wi - xyz(pj.w);
          float g = cubic_gradW_scale(d, r2);
-         dom = dom + dw * (c1 / pj.w.w * cubic_W(d, r2));
+         dom = dom + dw * (c1 * frcp(pj.w.w) * cubic_W(d, r2));
          dv = dv + cross3(dw, r) * (c2 * g);
          dom = dom + cross3(vi - xyz(pj.v), r) * (c3 * g);
        },
@@ -536,13 +570,13 @@ __global__ void __launch_bounds__(BLOCK) k_ss_force(Dev d) {
        [&](int, float3 r, float r2, VP q) {
          float g = cubic_gradW_scale(d, r2);
          float rhoj = q.v.w;
-         float visc = d.ss_dim * d.ss_visc * d.ss_mass / rhoj * dot3(vi - xyz(q.v), r) / (r2 + e);
-         float prs = -d.ss_rho0 * d.ss_VL0 * (pi2 + q.p / (rhoj * rhoj));
+         float visc = d.ss_dim * d.ss_visc * d.ss_mass * dot3(vi - xyz(q.v), r) * frcp(rhoj * (r2 + e));
+         float prs = -d.ss_rho0 * d.ss_VL0 * (pi2 + q.p * frcp(rhoj * rhoj));
          a = a + r * ((visc + prs) * g);
        },
        [&](int, float3 r, float r2) {
          float g = cubic_gradW_scale(d, r2);
-         float visc = d.ss_dim * d.ss_visc_b * d.ss_VS0 * (rhoi / d.ss_rho0) * dot3(vi, r) / (r2 + e);
+         float visc = d.ss_dim * d.ss_visc_b * d.ss_VS0 * (rhoi / d.ss_rho0) * dot3(vi, r) * frcp(r2 + e);
          float prs = -d.ss_rho0 * d.ss_VS0 * (pi2 + prsi / (d.ss_rho0 * d.ss_rho0));
          a = a + r * ((visc + prs) * g);
        });

@@ -21,10 +21,10 @@ __global__ void __launch_bounds__(BLOCK) k_pc_force(Dev d, float visc, float vis
   float3 a = f3(d.gx, d.gy, d.gz);
   walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 v = nb_ld(d.vel, j); v.w = nb_ld(d.rho, j); return v; },
           [&](int, float3 r, float r2, float4 vj) {
-            a = a + r * (d.ss_dim * visc * d.ss_mass / vj.w * dot3(vi - xyz(vj), r) / (r2 + e) * cubic_gradW_scale(d, r2));
+            a = a + r * (d.ss_dim * visc * d.ss_mass * dot3(vi - xyz(vj), r) * frcp(vj.w * (r2 + e)) * cubic_gradW_scale(d, r2));
           },
           [&](int, float3 r, float r2) {
-            a = a + r * (d.ss_dim * visc_b * d.ss_VS0 * (rhoi / d.ss_rho0) * dot3(vi, r) / (r2 + e) * cubic_gradW_scale(d, r2));
+            a = a + r * (d.ss_dim * visc_b * d.ss_VS0 * (rhoi / d.ss_rho0) * dot3(vi, r) * frcp(r2 + e) * cubic_gradW_scale(d, r2));
           });
   d.d_vel[i] = f4(a, 0);
 }

@@ -45,6 +45,7 @@ struct wcsph_ctx {
   std::vector<float> solid_host;  // original-order solid positions
   double *h_acc_raw = nullptr;    // pinned [8][ACC_STRIPES]
   double h_acc[8] = {0};          // stripe totals of the last pull_scalars()
+  bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
   float dt = 0.0f;
@@ -805,7 +806,10 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
   NEED_GRID();
   int rc;
   ctx->dv_iter = 0;
-  if ((rc = wcsph_dfsph_warmstart_divergence(ctx))) return rc;
+  if (ctx->warm_fused) {   // wcsph_dfsph_step ran k_density_coff_warm: adv_rho, kappa_v and the (pos, kappa_v) records are in place
+    ctx->warm_fused = false;
+    HOT_VEL(1, ctx->d.kappa_v, ctx->dt, 0);
+  } else if ((rc = wcsph_dfsph_warmstart_divergence(ctx))) return rc;
   double err = -0.1;
   const bool fusek = !ctx->use_tiles && ctx->d.n_owned == ctx->d.nl;
   if (fusek) PASS((k_drho_div<DRHO_BEGIN, true>), ctx->dt);
@@ -842,7 +846,10 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   NEED_SETUP();
   int rc;
   if ((rc = wcsph_grid_update(ctx))) return rc;
-  PASS(k_density_coff);  // compute_density + compute_dfsph_coff in one walk
+  if (!ctx->use_tiles && ctx->d.n_owned == ctx->d.nl) {
+    PASS(k_density_coff_warm, ctx->dt);  // compute_density + compute_dfsph_coff + first warm-start pass in one walk
+    ctx->warm_fused = true;
+  } else PASS(k_density_coff);           // compute_density + compute_dfsph_coff in one walk
   if ((rc = wcsph_dfsph_solve_divergence(ctx))) return rc;
   if ((rc = wcsph_dfsph_compute_nonpressure_force(ctx))) return rc;
   if ((rc = wcsph_dfsph_optimize_time_step(ctx))) return rc;
@@ -1302,6 +1309,9 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "density") { PASS(k_density); return 0; }
     if (nm == "density_coff") { PASS(k_density_coff); return 0; }
     if (nm == "grid_update") return wcsph_grid_update(ctx);
+    if (nm == "vorticity") { PASS(k_vorticity, ctx->dt); return 0; }
+    if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; PASS(k_visc_minv_residual, ctx->dt); return 0; }
+    if (nm == "build_lists") { PASS(k_build_lists, 1); return 0; }
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
 #define ABLATE_CASE(kern, n) if (nm == #kern ":" #n) { PASS(kern<n>, ctx->dt); return 0; }
     ABLATE_CASE(ablate_drho, 0) ABLATE_CASE(ablate_drho, 1) ABLATE_CASE(ablate_drho, 2) ABLATE_CASE(ablate_drho, 3) ABLATE_CASE(ablate_drho, 4) ABLATE_CASE(ablate_drho, 5) ABLATE_CASE(ablate_drho, 6) ABLATE_CASE(ablate_drho, 7) ABLATE_CASE(ablate_drho, 8) ABLATE_CASE(ablate_drho, 9) ABLATE_CASE(ablate_drho, 10) ABLATE_CASE(ablate_drho, 11) ABLATE_CASE(ablate_drho, 12)
