@@ -170,48 +170,50 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
   const int cw = __float_as_int(pi.w);
   if (cw < 0) return;  // outside the grid box: no neighbours (ref: HashGrid.py:80-81, Q4)
   const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
-  const int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
   const float3 xi = xyz(pi);
   const int info = d.cell_info[(cx * d.ny + cy) * d.nz + cz];
-  if (liquids)
-#pragma unroll 1
-  for (int dx = -2; dx <= 2; dx++) {
-    const int x = cx + dx;
-    if ((unsigned)x >= (unsigned)d.nx) continue;
-#pragma unroll 1
-    for (int dy = -2; dy <= 2; dy++) {
-      const int y = cy + dy;
-      if ((unsigned)y >= (unsigned)d.ny) continue;
-      const int base = (x * d.ny + y) * d.nz;
-      const int lo = d.cs_l[base + z0], hi = d.cs_l[base + z1];
-      for (int j = lo; j < hi; j++) {
-        const float4 pj = d.pos[j];
-        const float3 r = xi - xyz(pj);
-        const float r2 = dot3(r, r);
-        if (r2 <= d.list_r2 && j != i) fl(j, r, r2, 1.0f);
-      }
-    }
+  // Row trimming: a row (dx, dy) of the 5x5 columns is walked only over the z-cells the support sphere can reach.
+  // Distances in cell units from the particle to the nearest face of the column; rm = list radius + a margin
+  // for the rounding of the cell assignment.  Purely a candidate filter: the r2 <= list_r2 test below decides.
+  const float ux = (pi.x - d.minx) * d.inv_grid - (float)(cx + d.x0), uy = (pi.y - d.miny) * d.inv_grid - (float)cy;
+  const float fz = (pi.z - d.minz) * d.inv_grid;
+  const float rm = __builtin_amdgcn_sqrtf(d.list_r2) * d.inv_grid * 1.0001f + 1e-3f, rm2 = rm * rm;
+  auto zrange = [&](int dx, int dy, int &za, int &zb) -> bool {
+    const float ex = dx > 0 ? (float)dx - ux : (dx < 0 ? (float)(-dx - 1) + ux : 0.0f);
+    const float ey = dy > 0 ? (float)dy - uy : (dy < 0 ? (float)(-dy - 1) + uy : 0.0f);
+    const float q = rm2 - ex * ex - ey * ey;
+    if (q < 0.0f) return false;
+    const float zr = __builtin_amdgcn_sqrtf(q);
+    za = max(max((int)floorf(fz - zr), cz - 2), 0);
+    zb = min(min((int)floorf(fz + zr), cz + 2), d.nz - 1) + 1;
+    return zb > za;
+  };
+  // per x-plane: the five rows' cell-table lookups are issued together, then the rows are scanned
+#define WALK_PLANE(CS, POS, SELF, CALL)                                                            \
+  _Pragma("unroll 1") for (int dx = -2; dx <= 2; dx++) {                                          \
+    const int x = cx + dx;                                                                        \
+    if ((unsigned)x >= (unsigned)d.nx) continue;                                                  \
+    int lo[5], hi[5];                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
+      const int y = cy + t - 2;                                                                   \
+      int z0, z1;                                                                                 \
+      lo[t] = hi[t] = 0;                                                                          \
+      if ((unsigned)y < (unsigned)d.ny && zrange(dx, t - 2, z0, z1)) {                            \
+        const int base = (x * d.ny + y) * d.nz;                                                   \
+        lo[t] = CS[base + z0]; hi[t] = CS[base + z1];                                             \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 5; t++)                                                 \
+      for (int j = lo[t]; j < hi[t]; j++) {                                                       \
+        const float4 pj = POS[j];                                                                 \
+        const float3 r = xi - xyz(pj);                                                            \
+        const float r2 = dot3(r, r);                                                              \
+        if (r2 <= d.list_r2 && (SELF)) CALL(j, r, r2, 1.0f);                                      \
+      }                                                                                           \
   }
-  if (info & 1) {
-#pragma unroll 1
-    for (int dx = -2; dx <= 2; dx++) {
-      const int x = cx + dx;
-      if ((unsigned)x >= (unsigned)d.nx) continue;
-#pragma unroll 1
-      for (int dy = -2; dy <= 2; dy++) {
-        const int y = cy + dy;
-        if ((unsigned)y >= (unsigned)d.ny) continue;
-        const int base = (x * d.ny + y) * d.nz;
-        const int lo = d.cs_s[base + z0], hi = d.cs_s[base + z1];
-        for (int j = lo; j < hi; j++) {
-          const float4 pj = d.spos[j];
-          const float3 r = xi - xyz(pj);
-          const float r2 = dot3(r, r);
-          if (r2 <= d.list_r2) fs(j, r, r2, 1.0f);
-        }
-      }
-    }
-  }
+  if (liquids) { WALK_PLANE(d.cs_l, d.pos, j != i, fl) }
+  if (info & 1) { WALK_PLANE(d.cs_s, d.spos, true, fs) }
+#undef WALK_PLANE
   if (info >> 1) {
     // faithful mode, rare: some of this cell's 125 walked cells share a hash bucket, so the
     // reference visits their particles again (Q1).  Entries: k = walked-cell index, extra visits.
