@@ -182,12 +182,18 @@ __global__ void k_scan_bsums(int *bsum, int nb) {  // one block
     __syncthreads();
   }
 }
-__global__ void k_scan_final(const int *in, int n, const int *bsum, int *out, const int *bbox, int col_cells) {
+// clear != 0: the counters are zeroed as they are consumed, so the next grid update needs no 65 MB memset (only
+// cells of the active blocks can be non-zero: every counted particle lies inside the occupied box or in the last bin)
+__global__ void k_scan_final(int *in, int n, const int *bsum, int *out, const int *bbox, int col_cells, int clear) {
   if (!scan_block_active(bbox, n, col_cells)) return;
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int v[SCAN_PER_THREAD], s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  for (int k = 0; k < SCAN_PER_THREAD; k++) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    s += v[k];
+    if (clear && v[k] != 0) in[base + k] = 0;
+  }
   int tot;
   int ex = block_exclusive_scan(s, &tot) + bsum[blockIdx.x];
 #pragma unroll

@@ -228,12 +228,12 @@ int wcsph_sync(wcsph_ctx *ctx) {
   return pull_scalars(ctx);
 }
 
-static int run_scan(wcsph_ctx *ctx, const int *in, int n, int *out, const int *bbox) {
+static int run_scan(wcsph_ctx *ctx, int *in, int n, int *out, const int *bbox, int clear = 0) {
   int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   const int col = ctx->d.ny * ctx->d.nz;
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, bbox, col);
   hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->bsum, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out, bbox, col);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out, bbox, col, clear);
   LAUNCHCHK();
   return 0;
 }
@@ -301,7 +301,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.ns)), dim3(BLOCK), 0, ctx->stream, d, (const float4 *)spos_in, d.ns, ctx->cnt,
                        ctx->pw, ctx->slot, d.faithful ? ctx->bcount_s : (int *)nullptr, (int *)nullptr);
     LAUNCHCHK();
-    int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_s, nullptr);
+    int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_s, nullptr, 1);   // leaves the counters zeroed for the liquid updates
     if (rc) return rc;
     hipLaunchKernelGGL(k_scatter_solid, dim3(nblk(d.ns)), dim3(BLOCK), 0, ctx->stream, d, (const float4 *)spos_in, d.spos, d.cs_s,
                        ctx->pw, ctx->slot);
@@ -345,13 +345,13 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   const int nscan = d.ncell + 2;
   hipStream_t s = ctx->stream;
-  HIPCHK(hipMemsetAsync(ctx->cnt, 0, (size_t)nscan * sizeof(int), s));
+  // ctx->cnt is all zero here: k_scan_final clears the counters it consumes
   if (d.faithful) HIPCHK(hipMemcpyAsync(ctx->bcount, ctx->bcount_s, (size_t)d.table_size * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
                        d.faithful ? ctx->bcount : (int *)nullptr, ctx->bbox_part);
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
-  int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox);
+  int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
   if (d.nl > 0) {
     SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.pressure, d.oid,
