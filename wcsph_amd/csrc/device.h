@@ -131,6 +131,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (acc_total on the device, pull_scalars on the host).
 #define ACC_STRIPES 64
 #define ACC_SLOT(d, S) ((d).acc + (S) * ACC_STRIPES)
+// a kernel that does not otherwise touch slot S clears it for the kernel launched next (saves a memset launch)
+__device__ __forceinline__ void acc_clear(double *slot) {
+  if (blockIdx.x == 0 && threadIdx.x < ACC_STRIPES) slot[threadIdx.x] = 0.0;
+}
 // every thread of the block must call this
 __device__ __forceinline__ void block_accumulate(double *slot, float v) {
   double *dst = slot + (blockIdx.x & (ACC_STRIPES - 1));

@@ -169,6 +169,7 @@ __global__ void k_pack_k(Dev d, const float *kb) {
 // kap != nullptr (fused solver loops): kappa_i += k_i here instead of in k_make_k (dfsph.py:458 / 527)
 template <int COND>
 __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, float dt, float *kap = nullptr) {
+  if (kap) acc_clear(ACC_SLOT(d, ACC_ERR));   // fused solver loops: the density-change pass launched next sums into it
   LOAD_I
   if (!own) return;
   if (COND == 1 && !(d.adv_rho[i] > 0.0f)) return;
@@ -311,6 +312,8 @@ __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const 
 }
 // ref: dfsph.py:199-200
 __global__ void k_visc_guess(Dev d) {
+  acc_clear(ACC_SLOT(d, ACC_DZERO));   // summed into by the residual kernel launched next
+  acc_clear(ACC_SLOT(d, ACC_DAD));     // ... and by the first k_visc_Ad
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl) return;
   float4 g = d.vel_guess[i], v = d.vel[i];
@@ -407,6 +410,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
 
 // ref: dfsph.py:227-230: Ad = A(dir); dAd = eps + sum dir.Ad
 __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
+  acc_clear(ACC_SLOT(d, ACC_DNEW));    // k_visc_update (next) sums into it; its last reader, k_visc_dir, has finished
   LOAD_I
   float part = 0.f;
   if (own) {
@@ -437,6 +441,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta) {
 __global__ void k_visc_dir(Dev d, float delta_old) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double dnew = acc_total(ACC_SLOT(d, ACC_DNEW));
+  acc_clear(ACC_SLOT(d, ACC_DAD));     // read by k_visc_update (finished); the next k_visc_Ad sums into it
   if (i >= d.nl || d.oid[i] >= d.n_owned) return;
   const float beta = (float)dnew / delta_old;
   d.cg_dir[i] = f4(xyz(d.cg_s[i]) + xyz(d.cg_dir[i]) * beta, 0);

@@ -641,17 +641,13 @@ static int pressure_iter_async(wcsph_ctx *ctx) {
 // fused-loop variants: k_i comes from the previous drho launch's epilogue (FUSEK), kappa += k_i in the vel launch
 static int divergence_iter_fused(wcsph_ctx *ctx) {
   if (ctx->use_tiles || ctx->d.n_owned < ctx->d.nl) return divergence_iter_async(ctx);
-  PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v);
-  int rc = zero_acc(ctx, ACC_ERR);
-  if (rc) return rc;
+  PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v);   // also clears ACC_ERR
   PASS((k_drho_div<DRHO_ITER, true>), ctx->dt);
   return 0;
 }
 static int pressure_iter_fused(wcsph_ctx *ctx) {
   if (ctx->use_tiles || ctx->d.n_owned < ctx->d.nl) return pressure_iter_async(ctx);
-  PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);
-  int rc = zero_acc(ctx, ACC_ERR);
-  if (rc) return rc;
+  PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);     // also clears ACC_ERR
   PASS((k_drho_press<DRHO_ITER, true>), ctx->dt);
   return 0;
 }
@@ -704,11 +700,9 @@ int wcsph_dfsph_tension(wcsph_ctx *ctx) {
 
 int wcsph_dfsph_visc_init(wcsph_ctx *ctx) {
   NEED_GRID();
-  ELEM(k_visc_guess);
-  int rc = zero_acc(ctx, ACC_DZERO);
-  if (rc) return rc;
+  ELEM(k_visc_guess);                   // also clears ACC_DZERO and ACC_DAD
   PASS(k_visc_minv_residual, ctx->dt);  // dfsph.py:202-223 in one neighbour walk
-  rc = pull_scalars(ctx);
+  int rc = pull_scalars(ctx);
   if (rc) return rc;
   ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
   ctx->cg_delta = ctx->cg_delta_zero;
@@ -716,14 +710,11 @@ int wcsph_dfsph_visc_init(wcsph_ctx *ctx) {
 }
 int wcsph_dfsph_visc_iter(wcsph_ctx *ctx) {
   NEED_GRID();
-  int rc = zero_acc(ctx, ACC_DAD);
-  if (rc) return rc;
+  // ACC_DAD was cleared by k_visc_guess / the previous k_visc_dir, ACC_DNEW is cleared by k_visc_Ad
   PASS(k_visc_Ad, ctx->dt);
-  rc = zero_acc(ctx, ACC_DNEW);
-  if (rc) return rc;
   ELEM(k_visc_update, ctx->cg_delta);
   ELEM(k_visc_dir, ctx->cg_delta);  // delta_old == the delta this iteration started with (dfsph.py:234)
-  rc = pull_scalars(ctx);
+  int rc = pull_scalars(ctx);
   if (rc) return rc;
   ctx->cg_delta_old = ctx->cg_delta;
   ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
