@@ -124,6 +124,11 @@ int wcsph_grid_update(wcsph_ctx *ctx);
 /* ref: HashGrid.neighbor / neighborCount (HashGrid.py:24-25,88-106): materialise the explicit list the
  * reference stores, original indices, for particles [i0, i0+n): counts[n], lists[n][cap] (-1 padded) */
 int wcsph_neighbors_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, int32_t *counts, int32_t *lists);
+/* diagnostics: the compact per-step lists the neighbour passes actually iterate -- the in-support subset of the row
+ * above (`while k < cur_neighbor` loops, e.g. dfsph.py:254-256, weigh everything else by exactly zero), decoded from
+ * the 16-bit delta streams; original indices (solids offset by n_liquid), -1 padded.
+ * counts[n][3] = {liquid entries, solid entries, hop slots}; lists[n][cap] = liquid entries then solid entries */
+int wcsph_compact_lists_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, int32_t *counts, int32_t *lists);
 
 /* ---- dfsph.py kernels (one entry per @ti.kernel) ------------------------------------- */
 int wcsph_dfsph_reset_param(wcsph_ctx *ctx);            /* ref: dfsph.py:167-178 */

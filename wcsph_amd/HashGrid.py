@@ -55,6 +55,16 @@ class _NeighborList:
         _lib.check(ctx, _lib.load().wcsph_neighbors_to_host(ctx, i0, n, cap, counts.ctypes.data, lists.ctypes.data))
         return counts, lists
 
+    def compact_rows(self, i0, n, cap=256):
+        """The compact per-step lists the neighbour passes iterate (in-support subset, multiplicity kept), decoded from
+        the device's 16-bit delta streams: (counts[n,3] = liquid entries, solid entries, hop slots; lists[n,cap])."""
+        pd = self._g.particle_data
+        ctx = pd._need_ctx()
+        counts = np.empty((n, 3), np.int32)
+        lists = np.empty((n, cap), np.int32)
+        _lib.check(ctx, _lib.load().wcsph_compact_lists_to_host(ctx, i0, n, cap, counts.ctypes.data, lists.ctypes.data))
+        return counts, lists
+
     def to_numpy(self):
         n = self._g.particle_data.liquid_count
         if n * self._g.maxNeighbour > (1 << 28):

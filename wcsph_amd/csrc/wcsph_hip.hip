@@ -1116,6 +1116,53 @@ int wcsph_neighbors_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, 
   return WCSPH_OK;
 }
 
+// the compact per-step lists the passes iterate, decoded from the 16-bit delta streams (diagnostics / tests)
+__global__ void k_compact_lists(Dev d, int i0, int n, int cap, int *counts, int *lists) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = d.where[i0 + t];
+  int *row = lists + (size_t)t * cap;
+  const int2 head = d.nhead[i];
+  const int cl = head.x & 0xffff, cs = (int)((unsigned)head.x >> 16);
+  const size_t st = (size_t)d.nbr_stride;
+  const unsigned short *L = reinterpret_cast<const unsigned short *>(d.nbl + i), *S = reinterpret_cast<const unsigned short *>(d.nbs + i);
+  int w = 0, hops = 0, run = i;
+  for (int k = 0; k < cl; k++) {
+    const int dd = (int)(short)L[(size_t)(k >> 3) * st * 8 + (k & 7)];
+    run += dd;
+    if (!NB_IS_ENTRY(dd)) { hops++; continue; }
+    if (w < cap) row[w] = d.oid[run];
+    w++;
+  }
+  counts[3 * t] = w;
+  run = head.y;
+  for (int k = 0; k < cs; k++) {
+    const int dd = (int)(short)S[(size_t)(k >> 3) * st * 8 + (k & 7)];
+    run += dd;
+    if (!NB_IS_ENTRY(dd)) { hops++; continue; }
+    if (w < cap) row[w] = d.nl + __float_as_int(d.spos[run].w);
+    w++;
+  }
+  counts[3 * t + 1] = w - counts[3 * t];
+  counts[3 * t + 2] = hops;
+  for (int k = w; k < cap; k++) row[k] = -1;
+}
+int wcsph_compact_lists_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, int32_t *counts, int32_t *lists) {
+  NEED_GRID();
+  if (i0 < 0 || n < 0 || i0 + n > ctx->d.nl || cap < 1 || !counts || !lists) return WCSPH_EARG;
+  if (n == 0) return WCSPH_OK;
+  int *dc = nullptr, *dl = nullptr;
+  HIPCHK(hipMalloc((void **)&dc, (size_t)n * 12));
+  HIPCHK(hipMalloc((void **)&dl, (size_t)n * cap * 4));
+  hipLaunchKernelGGL(k_compact_lists, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, i0, n, cap, dc, dl);
+  hipError_t e1 = hipMemcpyAsync(counts, dc, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipMemcpyAsync(lists, dl, (size_t)n * cap * 4, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e3 = hipStreamSynchronize(ctx->stream);
+  hipFree(dc); hipFree(dl);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ctx->fail(WCSPH_EHIP, "compact_lists_to_host copy");
+  return WCSPH_OK;
+}
+
 // ---- slab decomposition -----------------------------------------------------------------------------
 int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1) {
   if (!ctx || x1 <= x0) return WCSPH_EARG;
