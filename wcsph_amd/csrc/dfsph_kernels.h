@@ -421,10 +421,13 @@ __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
   block_accumulate(ACC_SLOT(d, ACC_DAD), part);
 }
 // ref: dfsph.py:233-240: alpha = delta / dAd; v_guess += alpha d; r -= alpha Ad; s = Minv r; delta' = sum r.s
-__global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta) {
+// from_dzero (first iteration of the fused host loop): delta = delta_zero is still on the device (ACC_DZERO), the host
+// has not waited for it
+__global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta, int from_dzero = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float part = 0.f;
   const double dAd = acc_total(ACC_SLOT(d, ACC_DAD));
+  if (from_dzero) delta = (float)acc_total(ACC_SLOT(d, ACC_DZERO));
   if (i < d.nl && d.oid[i] < d.n_owned) {
     const float alpha = delta / (float)((double)d.eps + dAd);
     float3 dir = xyz(d.cg_dir[i]);
@@ -438,9 +441,10 @@ __global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta) {
   block_accumulate(ACC_SLOT(d, ACC_DNEW), part);
 }
 // ref: dfsph.py:243-246: beta = delta' / delta_old; d = s + beta d
-__global__ void k_visc_dir(Dev d, float delta_old) {
+__global__ void k_visc_dir(Dev d, float delta_old, int from_dzero = 0) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double dnew = acc_total(ACC_SLOT(d, ACC_DNEW));
+  if (from_dzero) delta_old = (float)acc_total(ACC_SLOT(d, ACC_DZERO));
   acc_clear(ACC_SLOT(d, ACC_DAD));     // read by k_visc_update (finished); the next k_visc_Ad sums into it
   if (i >= d.nl || d.oid[i] >= d.n_owned) return;
   const float beta = (float)dnew / delta_old;

@@ -757,10 +757,20 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
   int rc;
   if ((rc = wcsph_dfsph_clear_nonpressure(ctx))) return rc;
   if ((rc = wcsph_dfsph_tension(ctx))) return rc;
-  if ((rc = wcsph_dfsph_visc_init(ctx))) return rc;
+  // init_viscosity_para + the first compute_viscosity_force with ONE host wait: the loop below always runs once, and
+  // its first iteration can take delta_zero from the device (the reference waits after each, dfsph.py:86-91)
+  ELEM(k_visc_guess);
+  PASS(k_visc_minv_residual, ctx->dt);
+  PASS(k_visc_Ad, ctx->dt);
+  ELEM(k_visc_update, 0.0f, 1);
+  ELEM(k_visc_dir, 0.0f, 1);
+  if ((rc = pull_scalars(ctx))) return rc;
+  ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
+  ctx->cg_delta_old = ctx->cg_delta_zero;
+  ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
   ctx->vs_iter = 0;
   while (ctx->vs_iter < 100) {
-    if ((rc = wcsph_dfsph_visc_iter(ctx))) return rc;
+    if (ctx->vs_iter > 0 && (rc = wcsph_dfsph_visc_iter(ctx))) return rc;
     ctx->vs_iter++;
     if (ctx->fix_vs > 0) {  // fixed count, but never past an exactly-zero residual (beta would be 0/0)
       if (ctx->vs_iter >= ctx->fix_vs || (double)ctx->cg_delta_zero < (double)ctx->p.eps || ctx->cg_delta == 0.0f) break;
@@ -826,9 +836,12 @@ int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
   else if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
   while (ctx->fix_pr > 0 ? ctx->pr_iter < ctx->fix_pr : ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100)) {
     if ((rc = pressure_iter_fused(ctx))) return rc;
+    ctx->pr_iter++;
+    // the reference reads the error after every iteration, but `pr_iter < 2` forces the second one whatever the
+    // first reports: the host only has to wait where the value can change the control flow
+    if (ctx->fix_pr == 0 && ctx->pr_iter < 2 && fusek) { err = 1.0; continue; }
     if ((rc = fused_iter_sync(ctx))) return rc;
     err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
-    ctx->pr_iter++;
   }
   return wcsph_dfsph_end_pressure(ctx);
 }
