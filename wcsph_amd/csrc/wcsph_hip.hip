@@ -45,6 +45,7 @@ struct wcsph_ctx {
   std::vector<float> solid_host;  // original-order solid positions
   double *h_acc_raw = nullptr;    // pinned [8][ACC_STRIPES]
   double h_acc[8] = {0};          // stripe totals of the last pull_scalars()
+  unsigned long long mail_seq = 0;
   bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
@@ -108,15 +109,37 @@ static int check_flags(wcsph_ctx *ctx) {
   return 0;
 }
 // copy reduction slots + flags to the host and wait
+// Device -> host hand-over of the reduction slots and error flags at the solvers' decision points (4-5 per step).
+// One tiny kernel sums the stripes and writes the totals, the flags and then a sequence number straight into pinned
+// host memory; the host polls the sequence word.  A copy + blocking stream wait costs ~25 us of idle GPU per
+// decision, this ~10.
+struct HostMail { double acc[8]; int flags[4]; unsigned long long seq; };
+__global__ void k_publish(const double *acc, const int *flags, HostMail *m, unsigned long long seq) {
+  const int t = threadIdx.x;
+  if (t < 8) {
+    double v = 0.0;
+    for (int k = 0; k < ACC_STRIPES; k++) v += acc[t * ACC_STRIPES + k];
+    m->acc[t] = v;
+  } else if (t < 12) m->flags[t - 8] = flags[t - 8];
+  __syncthreads();
+  if (t == 0) { __threadfence_system(); __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
 static int pull_scalars(wcsph_ctx *ctx) {
-  HIPCHK(hipMemcpyAsync(ctx->h_acc_raw, ctx->d.acc, 8 * ACC_STRIPES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->h_flags, ctx->d.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (int s = 0; s < 8; s++) {
-    double t = 0.0;
-    for (int k = 0; k < ACC_STRIPES; k++) t += ctx->h_acc_raw[s * ACC_STRIPES + k];
-    ctx->h_acc[s] = t;
+  HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw);
+  const unsigned long long seq = ++ctx->mail_seq;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->d.acc, (const int *)ctx->d.flags, m, seq);
+  LAUNCHCHK();
+  volatile unsigned long long *flag = &m->seq;
+  for (unsigned long spins = 0; *flag != seq; spins++) {
+    if ((spins & 0xfffff) == 0xfffff) {   // every ~1 M polls: is the stream still alive?
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return ctx->fail(WCSPH_EHIP, hipGetErrorString(q));
+      if (q == hipSuccess && *flag != seq) return ctx->fail(WCSPH_EHIP, "pull_scalars: stream drained without the mail arriving");
+    }
   }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int s = 0; s < 8; s++) ctx->h_acc[s] = m->acc[s];
+  for (int s = 0; s < 4; s++) ctx->h_flags[s] = m->flags[s];
   return check_flags(ctx);
 }
 static int zero_acc(wcsph_ctx *ctx, int slot) {
