@@ -198,6 +198,20 @@ int wcsph_iisph_step(wcsph_ctx *ctx);                       /* ref: iisph.py:419
 int wcsph_surface_color_map(wcsph_ctx *ctx);                          /* ref: ParticleData.py:187-215 compute_color_map */
 int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR); /* ref: ParticleData.py:220-289 cal_anistropic_kernel */
 
+/* ---- MarchingCubeGrid.py (grid half) --------------------------------------------------------- */
+/* the generated 256-case tables the device uses: edge_table[256], tri_table[256][16] (-1 terminated rows); replaces
+ * the data file MCData.txt read at MarchingCubeGrid.py:82-94 */
+int wcsph_mc_tables(int32_t *edge_table, int32_t *tri_table);
+/* ref: MCGrid.setup_grid_gpu / setup_grid_cpu (MarchingCubeGrid.py:60-103): node pitch grid_r, kernel support search_r,
+ * box [minb, maxb]; dims[a] = int((maxb[a] - minb[a]) / grid_r + 1) */
+int wcsph_mc_setup(wcsph_ctx *ctx, double grid_r, double search_r, const float *maxb, const float *minb, int32_t dims[3]);
+/* ref: MCGrid.cal_surface_point (MarchingCubeGrid.py:159-184); needs the grid of this step and a current rho */
+int wcsph_mc_surface_value(wcsph_ctx *ctx);
+int wcsph_mc_value_to_host(wcsph_ctx *ctx, float *out, int64_t n_nodes);
+/* ref: MCGrid.marching_cube (MarchingCubeGrid.py:232-328): triangle soup, three consecutive vertices per triangle, at
+ * most cap_vertices stored; *n_vertices = vertices generated (> cap_vertices: truncated, the reference's MAX_VERTEX) */
+int wcsph_mc_marching_cube(wcsph_ctx *ctx, float isolevel, float *tri_xyz, int32_t cap_vertices, int32_t *n_vertices);
+
 /* ---- boundary sampler ------------------------------------------------------- */
 /* ref: boundry.py:100-460 -- Poisson-disk sampling of a triangle mesh (tri_xyz: [n_tri][3 vertices][3]) into
  * boundary particles no closer than particle_radius (normal-corrected distance, boundry.py:340-370).

@@ -46,7 +46,7 @@ _STEPS = ["update_grid", "reset_param", "compute_density", "compute_dfsph_coff",
 
 def build_oracle(force=False):
     """Compile oracle/wcsph_ref.c with gcc (oracle/Makefile). Returns the .so path."""
-    srcs = [os.path.join(_HERE, f) for f in ("wcsph_ref.c", "poisson_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("wcsph_ref.c", "poisson_ref.c", "mc_ref.c", "Makefile")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB
@@ -99,6 +99,9 @@ def _load():
             getattr(lib, "orc_ptr_" + f).argtypes = [C.c_void_p]
             getattr(lib, "orc_ptr_" + f).restype = C.POINTER(C.c_int)
         lib.orc_set_num_threads.argtypes = [C.c_int]
+        lib.orc_mc_value.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.orc_mc_crossings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_float, C.c_void_p, C.c_long]
+        lib.orc_mc_crossings.restype = C.c_long
         lib.orc_poisson_sample.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_uint32, C.c_int, C.c_void_p, C.c_int]
         lib.orc_poisson_sample.restype = C.c_int
         lib.orc_ps_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -106,6 +109,27 @@ def _load():
         lib.orc_get_max_threads.restype = C.c_int
         _lib = lib
     return _lib
+
+
+def mc_value(pos, rho, mass, grid_r, search_r, minb, dims):
+    """MCGrid.cal_surface_point restated (oracle/mc_ref.c): node field [nx*ny*nz] from the liquid particles."""
+    pos = np.ascontiguousarray(pos, np.float32); rho = np.ascontiguousarray(rho, np.float32)
+    minb = np.ascontiguousarray(minb, np.float32).ravel(); dims = np.ascontiguousarray(dims, np.int32).ravel()
+    out = np.empty(int(dims[0]) * int(dims[1]) * int(dims[2]), np.float32)
+    _load().orc_mc_value(pos.ctypes.data, rho.ctypes.data, len(pos), float(mass), float(grid_r), float(search_r),
+                         minb.ctypes.data, dims.ctypes.data, out.ctypes.data)
+    return out
+
+
+def mc_crossings(value, dims, minb, grid_r, iso):
+    """every grid edge whose end values straddle iso, interpolated as MCGrid.vertex_interp does -> [n,3]"""
+    value = np.ascontiguousarray(value, np.float32)
+    minb = np.ascontiguousarray(minb, np.float32).ravel(); dims = np.ascontiguousarray(dims, np.int32).ravel()
+    lib = _load()
+    n = lib.orc_mc_crossings(value.ctypes.data, dims.ctypes.data, minb.ctypes.data, float(grid_r), float(iso), None, 0)
+    out = np.empty((n, 3), np.float32)
+    lib.orc_mc_crossings(value.ctypes.data, dims.ctypes.data, minb.ctypes.data, float(grid_r), float(iso), out.ctypes.data, n)
+    return out
 
 
 def poisson_sample(tri, radius=0.025, seed=20240901, trials=10, cap=None):

@@ -17,15 +17,7 @@ from . import _lib
 from .HashGrid import HashGrid
 from .field import Field, ScalarField
 from .kernels.CubicKernel import CubicKernel
-
-
-class _MCGridRadii:
-    """ref: MarchingCubeGrid.py:22-25 (gridR = 0.9 particleR, searchR = 4 gridR); the grid itself is out of scope"""
-
-    def __init__(self, particleR):
-        self.gridR = particleR * 0.9
-        self.invGridR = 1.0 / self.gridR
-        self.searchR = self.gridR * 4.0
+from .MarchingCubeGrid import MCGrid
 
 
 class ParticleData:
@@ -45,9 +37,7 @@ class ParticleData:
         self.neighbor_mode = neighbor_mode
         self.hash_grid = HashGrid(particleR * 2.0, maxInGrid, maxNeighbour, self)
         self.kernel_c = CubicKernel(self.hash_grid.searchR)
-        # the reference builds a full marching-cubes grid here (ParticleData.py:29: MCGrid(particleR, 4, 512, self));
-        # only its radii take part in the per-particle surface kernels below (MarchingCubeGrid.py:22-25)
-        self.mc_grid = _MCGridRadii(particleR)
+        self.mc_grid = MCGrid(particleR, 4, 512, self)   # ref: ParticleData.py:29 (device arrays on first use)
 
         f = lambda name, nc: Field(self, name, nc)  # noqa: E731
         self.pos = Field(self, "pos", 3, full_count=True)
@@ -216,10 +206,13 @@ class ParticleData:
         self._ctx = ctx
         _lib.check(ctx, rc)
         self.hash_grid.setup_grid_gpu()
+        # ref: ParticleData.py:177 -- the MC grid reaches searchR beyond the particles' bounding box
+        self.mc_grid.setup_grid_gpu(self.maxboundarynp + np.float32(self.mc_grid.searchR), self.minboundarynp - np.float32(self.mc_grid.searchR))
 
     def setup_data_cpu(self):
         """ref: ParticleData.py:180-185 -- upload positions, fix the grid box."""
         self.hash_grid.setup_grid_cpu(self.maxboundarynp, self.minboundarynp)
+        self.mc_grid.setup_grid_cpu(self.maxboundarynp + np.float32(self.mc_grid.searchR), self.minboundarynp - np.float32(self.mc_grid.searchR))
         print("liqiud particle num:", self.liquid_count, "solid particle num:", self.solid_count)
 
     # ---- surface reconstruction, per-particle part (ref: ParticleData.py:187-298) ------------------------

@@ -18,6 +18,7 @@
 #include "solver_extra.h"
 #include "surface.h"
 #include "sampler.h"
+#include "mcgrid.h"
 #include "ablate.h"
 #define ablate_drho kx_drho
 #define ablate_vel kx_vel
@@ -46,6 +47,9 @@ struct wcsph_ctx {
   double *h_acc_raw = nullptr;    // pinned [8][ACC_STRIPES]
   double h_acc[8] = {0};          // stripe totals of the last pull_scalars()
   unsigned long long mail_seq = 0;
+  McDev mc = {};                  // MarchingCubeGrid (lazily set up)
+  int *mc_tables = nullptr;       // device: edge[256] + tri[256][MC_TRI_ROW]
+  size_t mc_nodes = 0;
   bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
@@ -1105,6 +1109,81 @@ int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR) {
     hipLaunchKernelGGL(k_surf_aniso, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
   }
   LAUNCHCHK();
+  return WCSPH_OK;
+}
+
+// ---- MarchingCubeGrid.py ----------------------------------------------------------------------------------
+int wcsph_mc_tables(int32_t *edge_table, int32_t *tri_table) {
+  if (!edge_table || !tri_table) return WCSPH_EARG;
+  mc_build_tables(edge_table, tri_table);
+  return WCSPH_OK;
+}
+int wcsph_mc_setup(wcsph_ctx *ctx, double grid_r, double search_r, const float *maxb, const float *minb, int32_t dims[3]) {
+  NEED_SETUP();
+  if (!(grid_r > 0.0) || !(search_r > 0.0) || !maxb || !minb || !dims) return WCSPH_EARG;
+  McDev &m = ctx->mc;
+  long n = 1;
+  for (int a = 0; a < 3; a++) {   // ref: MarchingCubeGrid.py:67-69 (python doubles, int() truncation)
+    dims[a] = (int32_t)(((double)maxb[a] - (double)minb[a]) / grid_r + 1.0);
+    if (dims[a] < 2) return ctx->fail(WCSPH_EARG, "wcsph_mc_setup: empty box");
+    n *= dims[a];
+  }
+  if (n > (1L << 31) - 1) return ctx->fail(WCSPH_EARG, "wcsph_mc_setup: more than 2^31 grid nodes");
+  m.nx = dims[0]; m.ny = dims[1]; m.nz = dims[2];
+  m.minx = minb[0]; m.miny = minb[1]; m.minz = minb[2];
+  m.grid_r = (float)grid_r;
+  m.h = (float)search_r; m.inv_h = 1.0f / m.h;
+  m.mk_h3 = (float)((8.0 / M_PI) / (search_r * search_r * search_r));   // kernels/CubicKernel.py:13-15
+  m.rho_min = ctx->p.liqiudMass * m.mk_h3;                               // MarchingCubeGrid.py:178
+  if ((size_t)n > ctx->mc_nodes) { DALLOC(m.value, (size_t)n); ctx->mc_nodes = (size_t)n; }
+  if (!ctx->mc_tables) {
+    std::vector<int> t(256 + 256 * MC_TRI_ROW);
+    if (mc_build_tables(t.data(), t.data() + 256) > 5) return ctx->fail(WCSPH_EARG, "marching-cubes table: a case with more than 5 triangles");
+    DALLOC(ctx->mc_tables, t.size());
+    DALLOC(m.vertex_count, 1);
+    HIPCHK(hipMemcpyAsync(ctx->mc_tables, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // t lives on this stack
+  }
+  m.edge_table = ctx->mc_tables; m.tri_table = ctx->mc_tables + 256;
+  return WCSPH_OK;
+}
+#define NEED_MC() do { NEED_GRID(); if (!ctx->mc.value) return ctx->fail(WCSPH_EARG, "call wcsph_mc_setup() first"); } while (0)
+int wcsph_mc_surface_value(wcsph_ctx *ctx) {   // ref: MarchingCubeGrid.py:159-184 (rho must be current: compute_density)
+  NEED_MC();
+  const long n = (long)ctx->mc.nx * ctx->mc.ny * ctx->mc.nz;
+  hipLaunchKernelGGL(k_mc_value, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->mc);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_mc_value_to_host(wcsph_ctx *ctx, float *out, int64_t n) {
+  NEED_MC();
+  if (!out || n != (int64_t)ctx->mc.nx * ctx->mc.ny * ctx->mc.nz) return ctx->fail(WCSPH_EARG, "wcsph_mc_value_to_host: size mismatch");
+  HIPCHK(hipMemcpyAsync(out, ctx->mc.value, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return WCSPH_OK;
+}
+int wcsph_mc_marching_cube(wcsph_ctx *ctx, float isolevel, float *tri_xyz, int32_t cap_vertices, int32_t *n_vertices) {
+  NEED_MC();
+  if (cap_vertices < 0 || !n_vertices || (cap_vertices > 0 && !tri_xyz)) return WCSPH_EARG;
+  McDev m = ctx->mc;
+  m.isolevel = isolevel;
+  m.cap = cap_vertices;
+  float *dtri = nullptr;
+  HIPCHK(hipMalloc((void **)&dtri, (size_t)(cap_vertices > 0 ? cap_vertices : 1) * 3 * sizeof(float)));
+  m.tri = dtri;
+  hipError_t e0 = hipMemsetAsync(m.vertex_count, 0, sizeof(int), ctx->stream);
+  const long n = (long)m.nx * m.ny * m.nz;
+  hipLaunchKernelGGL(k_mc_march, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, m);
+  int count = 0;
+  hipError_t e1 = hipMemcpyAsync(&count, m.vertex_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  hipError_t e3 = hipSuccess;
+  const int stored = count < cap_vertices ? count : (cap_vertices / 3) * 3;
+  if (e0 == hipSuccess && e1 == hipSuccess && e2 == hipSuccess && stored > 0)
+    e3 = hipMemcpy(tri_xyz, dtri, (size_t)stored * 3 * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(dtri);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ctx->fail(WCSPH_EHIP, "wcsph_mc_marching_cube");
+  *n_vertices = count;   // > cap_vertices: the mesh was truncated (the reference prints "exceed max tri")
   return WCSPH_OK;
 }
 
