@@ -198,6 +198,13 @@ int wcsph_iisph_step(wcsph_ctx *ctx);                       /* ref: iisph.py:419
 int wcsph_surface_color_map(wcsph_ctx *ctx);                          /* ref: ParticleData.py:187-215 compute_color_map */
 int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR); /* ref: ParticleData.py:220-289 cal_anistropic_kernel */
 
+/* ---- Canvas.py, headless -------------------------------------------------------------------------- */
+/* ref: dfsph.py:585-593 draw_particle over Canvas.py:138-211 -- clears the canvas, draws every liquid particle as a
+ * circle outline (r = 3 px, color_sphere) and every particle as a point (color_point) through proj_view (row-major
+ * 4x4 = Canvas.proj @ Canvas.view), nearest fragment wins; img[size_x][size_y][3] float RGB like Canvas.img */
+int wcsph_canvas_draw(wcsph_ctx *ctx, const float *proj_view, int32_t size_x, int32_t size_y, const float *color_sphere,
+                      const float *color_point, float *img);
+
 /* ---- MarchingCubeGrid.py (grid half) --------------------------------------------------------- */
 /* the generated 256-case tables the device uses: edge_table[256], tri_table[256][16] (-1 terminated rows); replaces
  * the data file MCData.txt read at MarchingCubeGrid.py:82-94 */

@@ -19,6 +19,7 @@
 #include "surface.h"
 #include "sampler.h"
 #include "mcgrid.h"
+#include "canvas.h"
 #include "ablate.h"
 #define ablate_drho kx_drho
 #define ablate_vel kx_vel
@@ -1109,6 +1110,34 @@ int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR) {
     hipLaunchKernelGGL(k_surf_aniso, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
   }
   LAUNCHCHK();
+  return WCSPH_OK;
+}
+
+// ---- Canvas.py (headless) ---------------------------------------------------------------------------------------
+int wcsph_canvas_draw(wcsph_ctx *ctx, const float *proj_view, int32_t size_x, int32_t size_y, const float *color_sphere,
+                      const float *color_point, float *img) {
+  NEED_SETUP();
+  if (!proj_view || size_x < 1 || size_y < 1 || size_x > 16384 || size_y > 16384 || !color_sphere || !color_point || !img) return WCSPH_EARG;
+  CanvasDev c;
+  memcpy(c.vp, proj_view, sizeof c.vp);
+  c.sx = size_x; c.sy = size_y;
+  const size_t npix = (size_t)size_x * size_y;
+  float *dimg = nullptr;
+  c.pix = nullptr;
+  if (hipMalloc((void **)&c.pix, npix * 8) != hipSuccess || hipMalloc((void **)&dimg, npix * 12) != hipSuccess) {
+    if (c.pix) hipFree(c.pix);
+    return ctx->fail(WCSPH_EHIP, "wcsph_canvas_draw: allocation");
+  }
+  const unsigned nb = (unsigned)((npix + BLOCK - 1) / BLOCK);
+  auto pack = [](const float *v) { auto q = [](float x) { x = x < 0 ? 0 : (x > 1 ? 1 : x); return (unsigned)(x * 1023.0f + 0.5f); }; return (q(v[0]) << 20) | (q(v[1]) << 10) | q(v[2]); };
+  hipLaunchKernelGGL(k_canvas_clear, dim3(nb), dim3(BLOCK), 0, ctx->stream, c);
+  if (ctx->d.nl > 0) hipLaunchKernelGGL(k_canvas_liquid, dim3(nblk(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, c, pack(color_sphere), pack(color_point));
+  if (ctx->d.ns > 0) hipLaunchKernelGGL(k_canvas_solid, dim3(nblk(ctx->d.ns)), dim3(BLOCK), 0, ctx->stream, ctx->d, c, pack(color_point));
+  hipLaunchKernelGGL(k_canvas_resolve, dim3(nb), dim3(BLOCK), 0, ctx->stream, c, dimg);
+  hipError_t e1 = hipMemcpyAsync(img, dimg, npix * 12, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  hipFree(c.pix); hipFree(dimg);
+  if (e1 != hipSuccess || e2 != hipSuccess) return ctx->fail(WCSPH_EHIP, "wcsph_canvas_draw");
   return WCSPH_OK;
 }
 
