@@ -101,3 +101,14 @@ def test_gpu_frame_matches_restatement(cam, tmp_path):
     c.export_png_frame(3)
     assert (tmp_path / "3.png").exists() and c.frame == 3
     g.close()
+
+
+@pytest.mark.gpu
+def test_driver_writes_frames_and_meshes(tmp_path):
+    """the reference's main loop body, headless: PNG frames (dfsph.py:643) and marching-cubes meshes (:635)"""
+    from wcsph_amd import dfsph
+    dfsph.main(steps=3, particleDim=6, png_dir=str(tmp_path), surface_dir=str(tmp_path))
+    assert (tmp_path / "0.png").exists()
+    mesh = (tmp_path / "mc_0.obj").read_text().splitlines()
+    assert sum(l.startswith("f ") for l in mesh) > 100
+    dfsph.particle_data.close()

@@ -28,6 +28,8 @@ from .kernels.CohesionKernel import CohesionKernel
 from .kernels.CubicKernel import CubicKernel
 
 # ---- module constants (ref: dfsph.py:19-41) --------------------------------------------------
+imgSizeX = 512                 # dfsph.py:19-20
+imgSizeY = 512
 current_time = 0.0
 total_time = 5.0
 eps = 1e-5
@@ -261,14 +263,38 @@ def step_reference_loop():
     return float(dt)
 
 
-def main(steps=None, filename=None, particleDim=None, neighbor_mode="faithful"):
-    """Headless version of the reference script body (dfsph.py:594-647)."""
+def draw_particle():
+    """ref: dfsph.py:585-593 (liquid: white circles, every particle: a grey point)"""
+    sph_canvas.draw_particle(particle_data)
+
+
+sph_canvas = None
+
+
+def main(steps=None, filename=None, particleDim=None, neighbor_mode="faithful", png_dir=None, surface_dir=None):
+    """Headless version of the reference script body (dfsph.py:594-647).  png_dir: write the reference's frames
+    (sph_canvas.export_png, :643, 30 fps of simulated time); surface_dir: write the marching-cubes meshes
+    (particle_data.mc_grid.export_surface, :635, 20 fps)."""
+    global sph_canvas
+    from .Canvas import Canvas
+    sph_canvas = Canvas(imgSizeX, imgSizeY)            # dfsph.py:596
     init_particle(filename, particleDim, neighbor_mode)
     reset_param()
+    if png_dir is not None:
+        sph_canvas.out_dir = png_dir
+    if surface_dir is not None:
+        particle_data.mc_grid.out_dir = surface_dir
     n = 0
     while steps is None or n < steps:
+        sph_canvas.static_cam(0.0, 1.0, 0.0)           # dfsph.py:604
         dt = step()
         n += 1
+        if png_dir is not None:
+            sph_canvas.clear_canvas()                  # dfsph.py:621-622
+            draw_particle()
+            sph_canvas.export_png(current_time)        # dfsph.py:643
+        if surface_dir is not None:
+            particle_data.mc_grid.export_surface(current_time)   # dfsph.py:635
         print("time:%.3f" % current_time, "step:%.4f" % dt, "viscorcity:", vs_iter, "divergence:", dv_iter,
               "particle_data.pressure:", pr_iter)
         if math.isnan(particle_data.pos.to_numpy()[test_id, 0]) or current_time >= total_time:
