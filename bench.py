@@ -28,10 +28,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_sim(n, mode):
+def build_sim(n, mode, **attrs):
     from wcsph_amd import dfsph
     t0 = time.time()
-    pd = dfsph.init_particle(particleDim=n, neighbor_mode=mode)
+    pd = dfsph.init_particle(particleDim=n, neighbor_mode=mode, **attrs)
     dfsph.reset_param()
     pd.sync()
     return dfsph, pd, time.time() - t0
@@ -203,6 +203,21 @@ def main():
         out["config"]["C2_100k"] = {"value": round(p3.liquid_count * args.steps / el3 / 1e6, 3), "ms_per_step": round(el3 / args.steps * 1e3, 3),
                                     "n_liquid": p3.liquid_count}
         p3.close()
+    if args.config == "C3" and not args.no_clean:
+        # BASELINE.json configs[4] (C5): 1 M particles with the Akinci surface tension switched on as well (the reference's
+        # default coefficients are 0, which skips both tension passes)
+        d5, p5, _ = build_sim(scene.CONFIGS["C5"], args.mode, tension_coff=0.05, tension_coff_b=0.05)
+        for _ in range(args.warmup):
+            d5.step()
+        p5.sync(); tsync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d5.step()
+        p5.sync(); tsync()
+        el5 = time.perf_counter() - t0
+        out["config"]["C5_1M_tension"] = {"value": round(p5.liquid_count * args.steps / el5 / 1e6, 3), "ms_per_step": round(el5 / args.steps * 1e3, 3),
+                                          "n_liquid": p5.liquid_count, "tension_coff": 0.05, "tension_coff_b": 0.05}
+        p5.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
     print(json.dumps(out))

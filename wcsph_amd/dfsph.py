@@ -58,9 +58,11 @@ def _call(name):
     _lib.check(ctx, getattr(_lib.load(), name)(ctx))
 
 
-def init_particle(filename=None, particleDim=None, neighbor_mode="faithful", boundary=None, maxNeighbour=2048):
+def init_particle(filename=None, particleDim=None, neighbor_mode="faithful", boundary=None, maxNeighbour=2048, **attrs):
     """ref: dfsph.py:59-82.  filename: OBJ point cloud of boundary particles (`v x y z` lines) as in the
-    reference; None generates the equivalent box shell (scene.box_shell).  particleDim scales the scene."""
+    reference; None generates the equivalent box shell (scene.box_shell).  particleDim scales the scene.
+    attrs: ParticleData attributes set before the device setup (e.g. tension_coff=0.05; the reference edits them in
+    ParticleData.py:61-87)."""
     global particle_data, kernel_c, kernel_adh, kernel_coh, deltaT, alpha_coff, kappa, kappa_v
     global particleDimX, particleDimY, particleDimZ, particleLiquidNum, vs_iter, dv_iter, pr_iter, current_time
     if particleDim is not None:
@@ -73,6 +75,10 @@ def init_particle(filename=None, particleDim=None, neighbor_mode="faithful", bou
 
     particle_data = ParticleData(particleRadius, neighbor_mode=neighbor_mode, maxNeighbour=maxNeighbour)
     particle_data.user_max_t, particle_data.user_min_t = user_max_t, user_min_t
+    for k, v in attrs.items():
+        if not hasattr(particle_data, k):
+            raise AttributeError("ParticleData has no attribute %r" % k)
+        setattr(particle_data, k, v)
     particle_data.add_liquid_points(scene.dam_break_liquid(particleDimX, particleDimY, particleDimZ, particleRadius))
 
     kernel_c = CubicKernel(particle_data.hash_grid.searchR)
