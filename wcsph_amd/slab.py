@@ -208,40 +208,45 @@ class SlabSim:
         return from_left, from_right
 
     def _sendrecv(self, to_left, to_right, from_left, from_right):
+        """tensors or equally long lists of tensors per direction; everything goes out as one batch"""
+        as_list = lambda t: list(t) if isinstance(t, (list, tuple)) else [t]   # noqa: E731
+        to_left, to_right, from_left, from_right = as_list(to_left), as_list(to_right), as_list(from_left), as_list(from_right)
         left, right = self._neighbours()
         staged = self.comm_device != self.device
         if staged:
             dst_l, dst_r = from_left, from_right
-            to_left, to_right = to_left.to(self.comm_device), to_right.to(self.comm_device)
-            from_left, from_right = torch.empty_like(dst_l, device=self.comm_device), torch.empty_like(dst_r, device=self.comm_device)
+            to_left = [t.to(self.comm_device) for t in to_left]; to_right = [t.to(self.comm_device) for t in to_right]
+            from_left = [torch.empty_like(t, device=self.comm_device) for t in dst_l]
+            from_right = [torch.empty_like(t, device=self.comm_device) for t in dst_r]
         ops = []
         if left is not None:
-            if to_left.numel():
-                ops.append(dist.P2POp(dist.isend, to_left.contiguous(), left, group=self.group))
-            if from_left.numel():
-                ops.append(dist.P2POp(dist.irecv, from_left, left, group=self.group))
+            ops += [dist.P2POp(dist.isend, t.contiguous(), left, group=self.group) for t in to_left if t.numel()]
+            ops += [dist.P2POp(dist.irecv, t, left, group=self.group) for t in from_left if t.numel()]
         if right is not None:
-            if to_right.numel():
-                ops.append(dist.P2POp(dist.isend, to_right.contiguous(), right, group=self.group))
-            if from_right.numel():
-                ops.append(dist.P2POp(dist.irecv, from_right, right, group=self.group))
+            ops += [dist.P2POp(dist.isend, t.contiguous(), right, group=self.group) for t in to_right if t.numel()]
+            ops += [dist.P2POp(dist.irecv, t, right, group=self.group) for t in from_right if t.numel()]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if staged:
-            dst_l.copy_(from_left); dst_r.copy_(from_right)
+            for d, s_ in zip(dst_l, from_left):
+                d.copy_(s_)
+            for d, s_ in zip(dst_r, from_right):
+                d.copy_(s_)
         self.n_exchanges += 1
 
-    def xchg(self, field):
-        """Refresh the ghost rows of `field` from their owners (one halo exchange)."""
+    def xchg(self, *fields):
+        """Refresh the ghost rows of the given fields from their owners: ONE grouped send/recv with each slab neighbour
+        however many fields travel (the cost of an exchange is its latency, not its bytes)."""
         if self.world == 1:
             return
         B = self.B
         nl, ngl = self.send_l.numel(), self.ghost_l.numel()
-        out = B.gather_rows(field, self.send_all)            # one pack kernel for both neighbours
-        inc = torch.empty((self.ghost_all.numel(), out.shape[1]), dtype=torch.float32, device=self.device)
-        self._sendrecv(out[:nl], out[nl:], inc[:ngl], inc[ngl:])
-        B.scatter_rows(field, self.ghost_all, inc)            # one unpack kernel
+        outs = [B.gather_rows(f, self.send_all) for f in fields]            # one pack kernel per field, both neighbours
+        incs = [torch.empty((self.ghost_all.numel(), o.shape[1]), dtype=torch.float32, device=self.device) for o in outs]
+        self._sendrecv([o[:nl] for o in outs], [o[nl:] for o in outs], [i[:ngl] for i in incs], [i[ngl:] for i in incs])
+        for f, inc in zip(fields, incs):
+            B.scatter_rows(f, self.ghost_all, inc)                         # one unpack kernel per field
 
     def _allreduce(self, v, op):
         if self.world == 1:
@@ -300,11 +305,11 @@ class SlabSim:
         self.redistribute()
         B.set_scalar("deltaT", self.dt)
         B.grid_update()                                   # particle_data.hash_grid.update_grid()
-        ph("DENSITY_COFF"); x("rho")                      # compute_density(); compute_dfsph_coff()
+        ph("DENSITY_COFF")                                # compute_density(); compute_dfsph_coff()
 
         # solve_vel_divergence()  (dfsph.py:131-146)
         self.dv_iter = 0
-        ph("DRHO_DIV_WARM"); x("kappa_v")
+        ph("DRHO_DIV_WARM"); x("rho", "kappa_v")          # the warm-start pass reads pos_j / vel_j only: rho_j travels with kappa_v
         ph("VEL_WARM"); x("vel")
         err = -0.1
         ph("DRHO_DIV_BEGIN")
@@ -369,9 +374,12 @@ class SlabSim:
             ph("MAKE_K_PRESS"); x("kbuf")
             ph("VEL_ITER"); x("vel")
             ph("DRHO_PRESS_ITER")
+            self.pr_iter += 1
+            if self.pr_iter < 2:      # `pr_iter < 2` forces the second iteration whatever the first reports:
+                err = 1.0             # no device wait, no all-reduce for a value that cannot change the control flow
+                continue
             self.avg_density_err = np.float32(self.allsum(B.get_acc(ACC_ERR)))
             err = float(self.avg_density_err) / N
-            self.pr_iter += 1
         ph("END_PRESS")
         ph("UPDATE_POS")
         self.rows = B.store_state()
