@@ -18,6 +18,8 @@ _PH = {
     "VISC_UPDATE": ["visc_update"], "VISC_DIR": ["visc_dir"], "VISC_END": ["end_viscosity"],
     "VORTICITY": ["vorticity_accumulate"], "VORTICITY_INT": ["vorticity_integrate"], "UPDATE_VEL": ["update_vel"],
     "UPDATE_POS": ["update_pos"],
+    "DENSITY_COFF_WARM": ["compute_density", "compute_dfsph_coff", "warmstart_divergence_drho"],
+    "VISC_MINV_RESIDUAL": ["visc_minv", "visc_residual"],
 }
 
 

@@ -305,11 +305,10 @@ class SlabSim:
         self.redistribute()
         B.set_scalar("deltaT", self.dt)
         B.grid_update()                                   # particle_data.hash_grid.update_grid()
-        ph("DENSITY_COFF")                                # compute_density(); compute_dfsph_coff()
-
-        # solve_vel_divergence()  (dfsph.py:131-146)
+        # compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146), which
+        # reads pos_j / vel_j only, in one walk; rho_j then travels with kappa_v
         self.dv_iter = 0
-        ph("DRHO_DIV_WARM"); x("rho", "kappa_v")          # the warm-start pass reads pos_j / vel_j only: rho_j travels with kappa_v
+        ph("DENSITY_COFF_WARM"); x("rho", "kappa_v")
         ph("VEL_WARM"); x("vel")
         err = -0.1
         ph("DRHO_DIV_BEGIN")
@@ -328,8 +327,7 @@ class SlabSim:
         if self.tension:
             ph("TENSION_NORMAL"); x("normal"); ph("TENSION_ACCEL")
         ph("VISC_GUESS"); x("vel_guess")
-        ph("VISC_MINV")
-        ph("VISC_RESIDUAL")
+        ph("VISC_MINV_RESIDUAL")
         self.cg_delta_zero = np.float32(self.allsum(B.get_acc(ACC_DZERO)))
         self.cg_delta = self.cg_delta_zero
         x("cg_dir")
