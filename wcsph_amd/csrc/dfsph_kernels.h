@@ -408,6 +408,70 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
   block_accumulate(ACC_SLOT(d, ACC_DZERO), part);
 }
 
+// wcsph_dfsph_step only: k_visc_minv_residual + k_vorticity in one walk
+__global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float dt) {
+  LOAD_I
+  float part = 0.f;
+  if (own) {
+    const float rhoi = d.rho[i];
+    const float e = 0.01f * d.h2;
+    const float cl = d.dim_coff * d.visc * d.mass;
+    const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
+    const float3 xi = xyz(d.vel_guess[i]);
+    float m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+    float3 ret = f3(0, 0, 0);
+    auto accum = [&](float3 r, float s) {
+      m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
+      m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
+    };
+    // compute_vorticity's sums (dfsph.py:307-330, see k_vorticity) ride on the same walk: they read vel_j, omega_j,
+    // rho_j, none of which the viscosity solve changes
+    const float3 wi = xyz(d.omega[i]), vi = xyz(d.vel[i]);
+    float3 dom = f3(0, 0, 0), dv = f3(0, 0, 0);
+    const float c1 = -1.0f / dt * d.vort_init * d.visc_omega * d.mass;
+    const float c2 = d.vort_coff / rhoi * d.mass;
+    const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
+    struct XVW { float4 x, v, w; };
+    walk<4>(d, i, pi, d.pos, [&](int j, float4) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = nb_ld(d.rho, j); q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
+            [&](int, float3 r, float r2, XVW q) {
+              const float g = cubic_gradW_scale(d, r2);
+              const float irho = frcp(q.x.w);
+              const float c = cl * g * irho * frcp(r2 + e);
+              accum(r, c);
+              ret = ret + r * (c * dot3(xi - xyz(q.x), r));
+              const float3 dw = wi - xyz(q.w);
+              dom = dom + dw * (c1 * irho * cubic_W(d, r2));
+              dv = dv + cross3(dw, r) * (c2 * g);
+              dom = dom + cross3(vi - xyz(q.v), r) * (c3 * g);
+            },
+            [&](int, float3 r, float r2) {
+              const float g = cubic_gradW_scale(d, r2);
+              const float c = cs * g * frcp(r2 + e);
+              accum(r, c);
+              ret = ret + r * (c * dot3(xi, r));
+              dv = dv + cross3(wi, r) * (d.vort_coff / rhoi * d.rho_L0 * d.VS0 * g);
+              dom = dom + cross3(vi, r) * (d.vort_coff / rhoi * d.vort_init * d.rho_L0 * d.VL0 * g);
+            });
+    dom = dom + wi * (-2.0f * d.vort_init * d.vort_coff * (float)d.ncount[i]);
+    d.d_omega[i] = f4(dom, 0);
+    { float4 a4 = d.d_vel[i]; a4.x += dv.x; a4.y += dv.y; a4.z += dv.z; d.d_vel[i] = a4; }
+    const float f = dt / rhoi;
+    float a = 1.0f - m00 * f, b = -m01 * f, c = -m02 * f, dd = 1.0f - m11 * f, ee = -m12 * f, ff = 1.0f - m22 * f;
+    float A = dd * ff - ee * ee, B = -(b * ff - ee * c), C = b * ee - dd * c;
+    float id = 1.0f / (a * A + b * B + c * C);
+    float i11 = (a * ff - c * c) * id, i12 = -(a * ee - c * b) * id, i22 = (a * dd - b * b) * id;
+    const float4 r0 = make_float4(A * id, B * id, C * id, 0), r1 = make_float4(B * id, i11, i12, 0), r2 = make_float4(C * id, i12, i22, 0);
+    d.minv0[i] = r0; d.minv1[i] = r1; d.minv2[i] = r2;
+    const float3 res = xyz(d.vel[i]) - (xi - ret * f);
+    const float3 dir = f3(r0.x * res.x + r0.y * res.y + r0.z * res.z, r1.x * res.x + r1.y * res.y + r1.z * res.z,
+                          r2.x * res.x + r2.y * res.y + r2.z * res.z);
+    d.cg_r[i] = f4(res, 0);
+    d.cg_dir[i] = f4(dir, 0);
+    part = dot3(res, dir);
+  }
+  block_accumulate(ACC_SLOT(d, ACC_DZERO), part);
+}
+
 // ref: dfsph.py:227-230: Ad = A(dir); dAd = eps + sum dir.Ad
 __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
   acc_clear(ACC_SLOT(d, ACC_DNEW));    // k_visc_update (next) sums into it; its last reader, k_visc_dir, has finished

@@ -51,6 +51,7 @@ struct wcsph_ctx {
   McDev mc = {};                  // MarchingCubeGrid (lazily set up)
   int *mc_tables = nullptr;       // device: edge[256] + tri[256][MC_TRI_ROW]
   size_t mc_nodes = 0;
+  bool vort_fuse = getenv("WCSPH_NO_VORT_FUSE") == nullptr;   // compute_nonpressure_force: vorticity sums in the residual walk
   bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
@@ -788,7 +789,8 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
   // init_viscosity_para + the first compute_viscosity_force with ONE host wait: the loop below always runs once, and
   // its first iteration can take delta_zero from the device (the reference waits after each, dfsph.py:86-91)
   ELEM(k_visc_guess);
-  PASS(k_visc_minv_residual, ctx->dt);
+  const bool fuse_vort = ctx->vort_fuse;
+  if (fuse_vort) PASS(k_visc_minv_residual_vort, ctx->dt); else PASS(k_visc_minv_residual, ctx->dt);
   PASS(k_visc_Ad, ctx->dt);
   ELEM(k_visc_update, 0.0f, 1);
   ELEM(k_visc_dir, 0.0f, 1);
@@ -809,6 +811,7 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
       break;
   }
   if ((rc = wcsph_dfsph_visc_end(ctx))) return rc;
+  if (fuse_vort) { ELEM(k_vorticity_integrate, ctx->dt); return WCSPH_OK; }   // the sums were taken in the residual walk
   return wcsph_dfsph_vorticity(ctx);
 }
 
@@ -1493,6 +1496,7 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "density") { PASS(k_density); return 0; }
     if (nm == "density_coff") { PASS(k_density_coff); return 0; }
     if (nm == "grid_update") return wcsph_grid_update(ctx);
+    if (nm == "visc_minv_residual_vort") { PASS(k_visc_minv_residual_vort, ctx->dt); return 0; }
     if (nm == "vorticity") { PASS(k_vorticity, ctx->dt); return 0; }
     if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; PASS(k_visc_minv_residual, ctx->dt); return 0; }
     if (nm == "build_lists") { PASS(k_build_lists, 1); return 0; }
