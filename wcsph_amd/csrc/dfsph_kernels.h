@@ -584,13 +584,21 @@ __global__ void __launch_bounds__(BLOCK) k_cfl(Dev d, float dt) {
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 1; k < BLOCK / WAVE; k++) vm = fmaxf(vm, sh[k]);
-    // positive floats order like their bit patterns; skip the atomic when this block cannot raise the max
-    if (vm > 0.f && __float_as_int(vm) > __hip_atomic_load(&d.flags[FLAG_VMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(&d.flags[FLAG_VMAX], __float_as_int(vm));
+    // positive floats order like their bit patterns; 64 striped targets (flags[4..67]) instead of one: same-address
+    // device-scope atomics are resolved one at a time at the memory side (see ACC_STRIPES)
+    if (vm > 0.f) atomicMax(&d.flags[4 + (blockIdx.x & (ACC_STRIPES - 1))], __float_as_int(vm));
   }
 }
-__global__ void k_cfl_store(Dev d) {  // slot 0 of the reference's vel_max field holds the result
-  if (d.nl > 0 && d.n_owned > 0) d.vel_max[d.where[0]] = __int_as_float(d.flags[FLAG_VMAX]);
+// one wave: max over the stripes -> flags[FLAG_VMAX] and slot 0 of the reference's vel_max field; stripes cleared
+__global__ void k_cfl_store(Dev d) {
+  int v = d.flags[4 + threadIdx.x];
+  d.flags[4 + threadIdx.x] = 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, WAVE));
+  if (threadIdx.x == 0) {
+    d.flags[FLAG_VMAX] = v;
+    if (d.nl > 0 && d.n_owned > 0) d.vel_max[d.where[0]] = __int_as_float(v);
+  }
 }
 
 // ref: dfsph.py:572-580

@@ -222,7 +222,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.nbl, (size_t)d.nbr_stride * (d.nbr_cap / 8)); DALLOC(d.nbs, (size_t)d.nbr_stride * (d.nbr_cap / 8));
   if (ctx->use_tiles) { DALLOC(d.nbr16, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.cnt16, nl); }
   DALLOC(d.spos, (size_t)d.ns);
-  DALLOC(d.acc, 8 * ACC_STRIPES); DALLOC(d.flags, 4);
+  DALLOC(d.acc, 8 * ACC_STRIPES); DALLOC(d.flags, 4 + ACC_STRIPES);   // [4..]: striped vmax
   size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
   DALLOC(ctx->pw, nmax); DALLOC(ctx->slot, nmax);
   size_t stage_n = (nl + d.ns) * 3 > nl * 9 ? (nl + d.ns) * 3 : nl * 9;
@@ -763,9 +763,8 @@ int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx) {
   // ref: dfsph.py:108-111 `while size < particleLiquidNum`: with a single liquid particle the reference launches
   // nothing, vel_max[0] keeps its initial 0 and the time step is never adapted
   if (ctx->d.faithful && ctx->d.nl <= 1) { ctx->vel_max0 = 0.0f; return WCSPH_OK; }
-  HIPCHK(hipMemsetAsync(ctx->d.flags + FLAG_VMAX, 0, sizeof(int), ctx->stream));
   ELEM(k_cfl, ctx->dt);
-  hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(1), 0, ctx->stream, ctx->d);
+  hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d);
   LAUNCHCHK();
   int rc = pull_scalars(ctx);
   if (rc) return rc;
