@@ -792,22 +792,26 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
   if (fuse_vort) PASS(k_visc_minv_residual_vort, ctx->dt); else PASS(k_visc_minv_residual, ctx->dt);
   PASS(k_visc_Ad, ctx->dt);
   ELEM(k_visc_update, 0.0f, 1);
-  ELEM(k_visc_dir, 0.0f, 1);
   if ((rc = pull_scalars(ctx))) return rc;
   ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
   ctx->cg_delta_old = ctx->cg_delta_zero;
   ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
-  ctx->vs_iter = 0;
+  ctx->vs_iter = 1;
+  // the search direction of the NEXT iteration (dfsph.py:243-246) is only formed if there is one: with the usual single
+  // iteration k_visc_dir never runs (cg_dir is scratch of this loop, rebuilt by the next init_viscosity_para)
   while (ctx->vs_iter < 100) {
-    if (ctx->vs_iter > 0 && (rc = wcsph_dfsph_visc_iter(ctx))) return rc;
-    ctx->vs_iter++;
     if (ctx->fix_vs > 0) {  // fixed count, but never past an exactly-zero residual (beta would be 0/0)
       if (ctx->vs_iter >= ctx->fix_vs || (double)ctx->cg_delta_zero < (double)ctx->p.eps || ctx->cg_delta == 0.0f) break;
-      continue;
-    }
-    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero ||
-        (double)ctx->cg_delta_zero < (double)ctx->p.eps)
+    } else if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero ||
+               (double)ctx->cg_delta_zero < (double)ctx->p.eps)
       break;
+    ELEM(k_visc_dir, ctx->cg_delta_old);   // beta = delta_new (still in ACC_DNEW) / delta the last iteration started with
+    PASS(k_visc_Ad, ctx->dt);
+    ELEM(k_visc_update, ctx->cg_delta);
+    if ((rc = pull_scalars(ctx))) return rc;
+    ctx->cg_delta_old = ctx->cg_delta;
+    ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+    ctx->vs_iter++;
   }
   if ((rc = wcsph_dfsph_visc_end(ctx))) return rc;
   if (fuse_vort) { ELEM(k_vorticity_integrate, ctx->dt); return WCSPH_OK; }   // the sums were taken in the residual walk
