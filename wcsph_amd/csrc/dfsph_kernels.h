@@ -601,6 +601,41 @@ __global__ void k_cfl_store(Dev d) {
   }
 }
 
+// wcsph_dfsph_step only: end_viscosity (dfsph.py:339-343) + the integration loop of compute_vorticity (:329-330) + the
+// per-particle part of the CFL reduction (:555-568) in one elementwise launch -- all three touch only particle i and
+// nothing reads their outputs from a neighbour before the next launch
+__global__ void __launch_bounds__(BLOCK) k_finish_nonpressure(Dev d, float dt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float vm = 0.f;
+  if (i < d.nl) {
+    const int o = d.oid[i];
+    const float3 v = xyz(d.vel[i]);
+    float3 a = xyz(d.d_vel[i]);
+    if (o < d.n_owned) {
+      const float3 g = xyz(d.vel_guess[i]);
+      a = a + (g - v) * (1.0f / dt);
+      d.d_vel[i] = f4(a, 0);
+      d.vel_guess[i] = f4(g - v, 0);
+      const float4 w = d.omega[i], dw = d.d_omega[i];
+      d.omega[i] = make_float4(w.x + dw.x * dt, w.y + dw.y * dt, w.z + dw.z * dt, 0);
+    }
+    const float3 vn = v + a * dt;
+    const float m = fmaxf(dot3(vn, vn), 0.1f);
+    d.vel_max[i] = m;
+    if (o < d.cfl_prefix && o < d.n_owned) vm = m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_down(vm, o, WAVE));
+  __shared__ float sh[BLOCK / WAVE];
+  if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE] = vm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 1; k < BLOCK / WAVE; k++) vm = fmaxf(vm, sh[k]);
+    if (vm > 0.f) atomicMax(&d.flags[4 + (blockIdx.x & (ACC_STRIPES - 1))], __float_as_int(vm));
+  }
+}
+
 // ref: dfsph.py:572-580
 __global__ void k_update_vel(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -52,6 +52,7 @@ struct wcsph_ctx {
   int *mc_tables = nullptr;       // device: edge[256] + tri[256][MC_TRI_ROW]
   size_t mc_nodes = 0;
   bool vort_fuse = getenv("WCSPH_NO_VORT_FUSE") == nullptr;   // compute_nonpressure_force: vorticity sums in the residual walk
+  bool in_step = false, cfl_done = false;   // wcsph_dfsph_step in progress; CFL maxima already taken
   bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
@@ -763,7 +764,8 @@ int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx) {
   // ref: dfsph.py:108-111 `while size < particleLiquidNum`: with a single liquid particle the reference launches
   // nothing, vel_max[0] keeps its initial 0 and the time step is never adapted
   if (ctx->d.faithful && ctx->d.nl <= 1) { ctx->vel_max0 = 0.0f; return WCSPH_OK; }
-  ELEM(k_cfl, ctx->dt);
+  if (ctx->cfl_done) ctx->cfl_done = false;   // k_finish_nonpressure already took the per-particle maxima
+  else ELEM(k_cfl, ctx->dt);
   hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d);
   LAUNCHCHK();
   int rc = pull_scalars(ctx);
@@ -812,6 +814,12 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
     ctx->cg_delta_old = ctx->cg_delta;
     ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
     ctx->vs_iter++;
+  }
+  if (fuse_vort && ctx->in_step && !(ctx->d.faithful && ctx->d.nl <= 1)) {
+    // inside wcsph_dfsph_step the CFL reduction follows immediately: its per-particle part rides along
+    ELEM(k_finish_nonpressure, ctx->dt);
+    ctx->cfl_done = true;
+    return WCSPH_OK;
   }
   if ((rc = wcsph_dfsph_visc_end(ctx))) return rc;
   if (fuse_vort) { ELEM(k_vorticity_integrate, ctx->dt); return WCSPH_OK; }   // the sums were taken in the residual walk
@@ -889,7 +897,10 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
     ctx->warm_fused = true;
   } else PASS(k_density_coff);           // compute_density + compute_dfsph_coff in one walk
   if ((rc = wcsph_dfsph_solve_divergence(ctx))) return rc;
-  if ((rc = wcsph_dfsph_compute_nonpressure_force(ctx))) return rc;
+  ctx->in_step = true;
+  rc = wcsph_dfsph_compute_nonpressure_force(ctx);
+  ctx->in_step = false;
+  if (rc) { ctx->cfl_done = false; return rc; }
   if ((rc = wcsph_dfsph_optimize_time_step(ctx))) return rc;
   if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
   if ((rc = wcsph_dfsph_solve_pressure(ctx))) return rc;
