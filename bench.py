@@ -77,6 +77,15 @@ def cpu_baseline(n, steps):
 
 
 def main():
+    # the reference's classes print scene statistics (ParticleData.py:185, HashGrid.py:54); stdout carries the JSON line only
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        out = _main()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -220,7 +229,7 @@ def main():
         p5.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

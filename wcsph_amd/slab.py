@@ -450,9 +450,17 @@ def bench_main(args):
     cnt = torch.tensor([sim.n_owned], dtype=torch.int64, device=cdev)
     allc = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(allc, cnt)
+    result = None
     if rank == 0:
-        import json
         elapsed = float(el.item())
+        # dominant kernel pair on this rank's slab, timed live on the context's stream (the unfused launches of the
+        # phase path: k_make_k + k_vel_from_k + k_drho_press); algorithmic bytes as in bench.py
+        ms = C.c_float()
+        with torch.cuda.stream(sim.B.stream):
+            _lib.check(sim.B.ctx, sim.B.lib.wcsph_time_kernel(sim.B.ctx, b"pressure_iter", 10, C.byref(ms)))
+        ns_local = sim.B.pd.solid_count
+        alg_bytes = 84.0 * sim.n_owned + 24.0 * ns_local
+        achieved = alg_bytes / (ms.value * 1e-3) / 1e9
         it = np.array(iters, dtype=np.float64)
         out = {
             "metric": "M particle-steps/sec, DFSPH dam-break", "value": round(n_global * args.steps / elapsed / 1e6, 3),
@@ -465,7 +473,12 @@ def bench_main(args):
                        "owned_per_rank": [int(c.item()) for c in allc],
                        "halo_exchanges_per_step": round(sim.n_exchanges / float(args.steps + args.warmup), 1),
                        "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)}},
+            "roofline": {"bound": "hbm", "kernel": "pressure_iter on rank 0's slab (k_make_k + k_vel_from_k + k_drho_press<ITER>), ref dfsph.py:518-547",
+                         "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "avg_launch_us": round(ms.value * 1e3, 1), "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
-        print(json.dumps(out))
+        result = out
+    dist.barrier()
     sim.B.close()
     dist.destroy_process_group()
+    return result
