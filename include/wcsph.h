@@ -281,6 +281,11 @@ enum wcsph_phase {
   WCSPH_PH__COUNT
 };
 int wcsph_phase(wcsph_ctx *ctx, int phase);
+/* Halo/compute overlap: restrict the NEIGHBOUR passes launched next to a part of the owned particles.  mode 0: all;
+ * 1: only particles in global cell columns [x_lo, x_hi) -- the slab interior, whose 5^3 cells hold no ghost, so the
+ * pass may run while a halo exchange is in flight; 2: only the others (run after the exchange; reduction slots are
+ * not cleared again).  Elementwise phases ignore it. */
+int wcsph_set_part(wcsph_ctx *ctx, int32_t mode, int32_t x_lo, int32_t x_hi);
 
 /* gather / scatter `n` rows of a field by ORIGINAL liquid indices (device int32 array) into / from a
  * packed device buffer (rows of 3 f32 for vec3 fields, 1 f32 for scalar fields) for halo exchange */

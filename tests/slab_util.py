@@ -55,7 +55,13 @@ class OracleBackend:
         self.o.update_grid()
         assert self.o.overflow_neighbor == 0 and self.o.overflow_grid == 0
 
+    def set_part(self, mode, x_lo=0, x_hi=0):
+        # the checker computes a split phase in one go: nothing for the interior call, everything for the second
+        self._part = int(mode)
+
     def phase(self, name):
+        if getattr(self, "_part", 0) == 1:
+            return
         for f in _PH[name]:
             getattr(self.o, f)()
 

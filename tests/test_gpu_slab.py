@@ -81,3 +81,31 @@ def test_hip_slab_two_ranks_match_one_rank(tmp_path):
     np.testing.assert_array_equal(l2[0][:, :3], l2[1][:, :3])
     assert (l2[0][:, 4] + l2[1][:, 4] == n ** 3).all()
     assert l2[0][0, 4] != l2[0][-1, 4]
+
+
+def test_overlapped_halo_exchange_changes_nothing(tmp_path):
+    """WCSPH_SLAB_OVERLAP: every neighbour pass that needs a halo refresh runs on the slab interior while the exchange is
+    in flight and on the rest afterwards -- same particles, same inputs, same results as exchange-then-pass."""
+    from test_slab_gloo import _free_port
+    n = 14
+    outs = []
+    for flag in ("0", "1"):
+        out = os.path.join(str(tmp_path), "ov" + flag)
+        os.makedirs(out)
+        os.environ["WCSPH_SLAB_OVERLAP"] = flag
+        try:
+            mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+        finally:
+            os.environ.pop("WCSPH_SLAB_OVERLAP", None)
+        outs.append(out)
+    rows = [np.concatenate([np.load(os.path.join(o, "hrows_w2_r%d.npy" % r)) for r in range(2)]) for o in outs]
+    logs = [np.load(os.path.join(o, "hlog_w2_r0.npy")) for o in outs]
+    np.testing.assert_array_equal(logs[0][:, :3], logs[1][:, :3])
+    assert len(rows[0]) == len(rows[1]) == n ** 3
+    import slab_util
+    dpos, dvel, _ = slab_util.match_rows(rows[0], rows[1])
+    assert dpos < 1e-6 and dvel < 1e-4
+    # the split is not vacuous on this scene: each rank's slab is wider than its two boundary strips
+    liquid, solid, bounds = slab_util.test_scene(n)
+    cuts, _ = slab_util.split_scene(liquid, bounds, 2)
+    assert cuts[1] - cuts[0] > 4 and cuts[2] - cuts[1] > 4

@@ -19,6 +19,9 @@ struct Dev {
   int nl, ns, n_owned;
   int nx, ny, nz, ncell;
   int x0;          // first global cell column of this context's window (slab decomposition); 0 otherwise
+  // slab halo/compute overlap: 0 = every owned particle; 1 = only those in global cell columns [part_x0, part_x1)
+  // (the interior: no ghost within their 5^3 cells); 2 = only the others (see part_ok)
+  int part_mode, part_x0, part_x1;
   int table_size;  // reference hash table size (HashGrid.py:114)
   int faithful;
   int cfl_prefix;  // Q5: CFL max covers original indices [0, cfl_prefix)
@@ -108,6 +111,15 @@ __device__ __forceinline__ float cubic_gradW_scale(const Dev &d, float r2) {
   float s = (q <= 0.5f) ? q * (3.0f * q - 2.0f) : -(f * f);
   float g = s * d.ml_h3 * inv_rl * d.inv_h;
   return (rl > 1.0e-5f && q <= 1.0f) ? g : 0.0f;
+}
+
+// which owned particles a neighbour pass computes in this launch (Dev::part_mode); particles outside the grid box
+// have no neighbours and count as interior
+__device__ __forceinline__ bool part_ok(const Dev &d, float4 pi) {
+  if (d.part_mode == 0) return true;
+  const int w = __float_as_int(pi.w);
+  const bool in = (w < 0) || (unsigned)((w & 1023) + d.x0 - d.part_x0) < (unsigned)(d.part_x1 - d.part_x0);
+  return (d.part_mode == 1) == in;
 }
 
 // XCD-aware block remap: the dispatcher places block b on XCD b%8 (MI355X_MICROARCH "Workgroup

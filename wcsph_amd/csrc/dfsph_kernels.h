@@ -9,7 +9,7 @@
   const int i = sorted_index();                       \
   const bool live = i < d.nl;                         \
   const float4 pi = live ? d.pos[i] : make_float4(0, 0, 0, __int_as_float(-1)); \
-  const bool own = live && d.oid[i] < d.n_owned;
+  const bool own = live && d.oid[i] < d.n_owned && part_ok(d, pi);
 
 // ref: dfsph.py:248-262 compute_density
 __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {

@@ -1367,6 +1367,11 @@ int wcsph_set_acc(wcsph_ctx *ctx, int slot, double v) {
   HIPCHK(hipStreamSynchronize(ctx->stream));  // row lives on this stack
   return WCSPH_OK;
 }
+int wcsph_set_part(wcsph_ctx *ctx, int32_t mode, int32_t x_lo, int32_t x_hi) {
+  if (!ctx || mode < 0 || mode > 2) return WCSPH_EARG;
+  ctx->d.part_mode = mode; ctx->d.part_x0 = x_lo; ctx->d.part_x1 = x_hi > x_lo ? x_hi : x_lo;
+  return WCSPH_OK;
+}
 int wcsph_phase(wcsph_ctx *ctx, int ph) {
   NEED_GRID();
   int rc = 0;
@@ -1374,27 +1379,27 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
   switch (ph) {
     case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); break;
     case WCSPH_PH_DENSITY_COFF_WARM: if (ctx->use_tiles) { PASS(k_density_coff); HOT_DRHO_DIV(DRHO_WARM, dt); } else PASS(k_density_coff_warm, dt); break;
-    case WCSPH_PH_VISC_MINV_RESIDUAL: if ((rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual, dt); break;
+    case WCSPH_PH_VISC_MINV_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual, dt); break;
     case WCSPH_PH_DRHO_DIV_WARM: HOT_DRHO_DIV(DRHO_WARM, dt); break;
     case WCSPH_PH_VEL_WARM: HOT_VEL(1, ctx->d.kappa_v, dt, 1); break;
     case WCSPH_PH_DRHO_DIV_BEGIN: HOT_DRHO_DIV(DRHO_BEGIN, dt); break;
     case WCSPH_PH_MAKE_K_DIV: ELEM(k_make_k, ctx->d.kappa_v, 0.0f); break;
     case WCSPH_PH_VEL_ITER: HOT_VEL(0, ctx->d.kbuf, dt, ctx->d.n_owned < ctx->d.nl); break;
-    case WCSPH_PH_DRHO_DIV_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_DIV(DRHO_ITER, dt); break;
+    case WCSPH_PH_DRHO_DIV_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_DIV(DRHO_ITER, dt); break;
     case WCSPH_PH_END_DIV: ELEM(k_end_div, dt); break;
     case WCSPH_PH_WARM_PRESS_SCALE: ELEM(k_warm_press_scale, dt); break;
     case WCSPH_PH_WARM_PRESS_VEL: PASS(k_warm_press_vel, dt); break;
     case WCSPH_PH_DRHO_PRESS_BEGIN: HOT_DRHO_PRESS(DRHO_BEGIN, dt); break;
     case WCSPH_PH_MAKE_K_PRESS: ELEM(k_make_k, ctx->d.kappa, 1.0f); break;
-    case WCSPH_PH_DRHO_PRESS_ITER: if ((rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_PRESS(DRHO_ITER, dt); break;
+    case WCSPH_PH_DRHO_PRESS_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_PRESS(DRHO_ITER, dt); break;
     case WCSPH_PH_END_PRESS: ELEM(k_end_press, dt); break;
     case WCSPH_PH_CLEAR: ELEM(k_clear_nonpressure); break;
     case WCSPH_PH_TENSION_NORMAL: PASS(k_tension_normal); break;
     case WCSPH_PH_TENSION_ACCEL: PASS(k_tension_accel); break;
     case WCSPH_PH_VISC_GUESS: ELEM(k_visc_guess); break;
     case WCSPH_PH_VISC_MINV: PASS(k_visc_minv, dt); break;
-    case WCSPH_PH_VISC_RESIDUAL: if ((rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_residual, dt); break;
-    case WCSPH_PH_VISC_AD: if ((rc = zero_acc(ctx, ACC_DAD))) return rc; PASS(k_visc_Ad, dt); break;
+    case WCSPH_PH_VISC_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_residual, dt); break;
+    case WCSPH_PH_VISC_AD: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DAD))) return rc; PASS(k_visc_Ad, dt); break;
     case WCSPH_PH_VISC_UPDATE: if ((rc = zero_acc(ctx, ACC_DNEW))) return rc; ELEM(k_visc_update, ctx->cg_delta); break;
     case WCSPH_PH_VISC_DIR: ELEM(k_visc_dir, ctx->cg_delta); break;
     case WCSPH_PH_VISC_END: ELEM(k_visc_end, dt); break;

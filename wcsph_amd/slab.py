@@ -89,6 +89,10 @@ class HipBackend:
         self._chk(self.lib.wcsph_get_scalar(self.ctx, _lib.SCALAR_ID["vel_max0"], C.byref(v)))
         return float(v.value)
 
+    def set_part(self, mode, x_lo=0, x_hi=0):
+        """restrict the neighbour passes launched next: 0 all, 1 interior columns [x_lo, x_hi), 2 the rest"""
+        self._chk(self.lib.wcsph_set_part(self.ctx, int(mode), int(x_lo), int(x_hi)))
+
     def get_acc(self, slot):
         v = C.c_double()
         self._chk(self.lib.wcsph_get_acc(self.ctx, slot, C.byref(v)))
@@ -179,6 +183,12 @@ class SlabSim:
         self.user_max_t, self.user_min_t = 0.005, 0.0001
         self.tension = False
         self.n_exchanges = 0
+        # halo/compute overlap: a neighbour pass that needs a halo refresh runs on the slab interior (columns at least
+        # GHOST_CELLS away from a cut with a neighbour: no ghost within reach) while the exchange is in flight, then on
+        # the rest.  WCSPH_SLAB_OVERLAP=0 switches it off.
+        self.overlap = world > 1 and os.environ.get("WCSPH_SLAB_OVERLAP", "1") != "0"
+        big = 1 << 20
+        self.interior = (self.lo + GHOST_CELLS if rank > 0 else -big, self.hi - GHOST_CELLS if rank < world - 1 else big)
 
     # ---- geometry -------------------------------------------------------------------------------------
     def _cellx_np(self, x):
@@ -208,16 +218,22 @@ class SlabSim:
         return from_left, from_right
 
     def _sendrecv(self, to_left, to_right, from_left, from_right):
-        """tensors or equally long lists of tensors per direction; everything goes out as one batch"""
+        self._complete(self._post(to_left, to_right, from_left, from_right))
+
+    def _post(self, to_left, to_right, from_left, from_right):
+        """tensors or equally long lists of tensors per direction; everything goes out as one batch.  Returns what
+        _complete needs.  With nccl the transfers run on the process group's own stream: work queued on the current
+        stream after this call overlaps with them until _complete makes the stream wait."""
         as_list = lambda t: list(t) if isinstance(t, (list, tuple)) else [t]   # noqa: E731
         to_left, to_right, from_left, from_right = as_list(to_left), as_list(to_right), as_list(from_left), as_list(from_right)
         left, right = self._neighbours()
         staged = self.comm_device != self.device
+        dst = None
         if staged:
-            dst_l, dst_r = from_left, from_right
+            dst = (from_left, from_right)
             to_left = [t.to(self.comm_device) for t in to_left]; to_right = [t.to(self.comm_device) for t in to_right]
-            from_left = [torch.empty_like(t, device=self.comm_device) for t in dst_l]
-            from_right = [torch.empty_like(t, device=self.comm_device) for t in dst_r]
+            from_left = [torch.empty_like(t, device=self.comm_device) for t in from_left]
+            from_right = [torch.empty_like(t, device=self.comm_device) for t in from_right]
         ops = []
         if left is not None:
             ops += [dist.P2POp(dist.isend, t.contiguous(), left, group=self.group) for t in to_left if t.numel()]
@@ -225,28 +241,58 @@ class SlabSim:
         if right is not None:
             ops += [dist.P2POp(dist.isend, t.contiguous(), right, group=self.group) for t in to_right if t.numel()]
             ops += [dist.P2POp(dist.irecv, t, right, group=self.group) for t in from_right if t.numel()]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if staged:
-            for d, s_ in zip(dst_l, from_left):
-                d.copy_(s_)
-            for d, s_ in zip(dst_r, from_right):
-                d.copy_(s_)
+        reqs = dist.batch_isend_irecv(ops) if ops else []
         self.n_exchanges += 1
+        return reqs, dst, (from_left, from_right), (to_left, to_right)      # the send buffers stay referenced until done
+
+    def _complete(self, pending):
+        reqs, dst, src, _keep = pending
+        for req in reqs:
+            req.wait()
+        if dst is not None:
+            for d, s_ in zip(dst[0], src[0]):
+                d.copy_(s_)
+            for d, s_ in zip(dst[1], src[1]):
+                d.copy_(s_)
 
     def xchg(self, *fields):
         """Refresh the ghost rows of the given fields from their owners: ONE grouped send/recv with each slab neighbour
         however many fields travel (the cost of an exchange is its latency, not its bytes)."""
+        self.xchg_end(self.xchg_begin(*fields))
+
+    def xchg_begin(self, *fields):
+        """pack + post the sends/receives; returns a handle for xchg_end (None when there is nobody to talk to)"""
         if self.world == 1:
-            return
+            return None
         B = self.B
         nl, ngl = self.send_l.numel(), self.ghost_l.numel()
         outs = [B.gather_rows(f, self.send_all) for f in fields]            # one pack kernel per field, both neighbours
         incs = [torch.empty((self.ghost_all.numel(), o.shape[1]), dtype=torch.float32, device=self.device) for o in outs]
-        self._sendrecv([o[:nl] for o in outs], [o[nl:] for o in outs], [i[:ngl] for i in incs], [i[ngl:] for i in incs])
+        pending = self._post([o[:nl] for o in outs], [o[nl:] for o in outs], [i[:ngl] for i in incs], [i[ngl:] for i in incs])
+        return fields, incs, outs, pending
+
+    def xchg_end(self, h):
+        if h is None:
+            return
+        fields, incs, outs, pending = h
+        self._complete(pending)
         for f, inc in zip(fields, incs):
-            B.scatter_rows(f, self.ghost_all, inc)                         # one unpack kernel per field
+            self.B.scatter_rows(f, self.ghost_all, inc)                    # one unpack kernel per field
+
+    def xp(self, fields, phase):
+        """halo refresh of `fields`, then the neighbour phase that reads them from the ghosts -- overlapped: the phase runs
+        on the slab interior while the exchange is in flight, on the rest once it has landed"""
+        if isinstance(fields, str):
+            fields = (fields,)
+        if not self.overlap:
+            self.xchg(*fields)
+            self.B.phase(phase)
+            return
+        h = self.xchg_begin(*fields)
+        self.B.set_part(1, *self.interior); self.B.phase(phase)
+        self.xchg_end(h)
+        self.B.set_part(2, *self.interior); self.B.phase(phase)
+        self.B.set_part(0)
 
     def _allreduce(self, v, op):
         if self.world == 1:
@@ -308,15 +354,14 @@ class SlabSim:
         # compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146), which
         # reads pos_j / vel_j only, in one walk; rho_j then travels with kappa_v
         self.dv_iter = 0
-        ph("DENSITY_COFF_WARM"); x("rho", "kappa_v")
-        ph("VEL_WARM"); x("vel")
+        xp = self.xp
+        ph("DENSITY_COFF_WARM"); xp(("rho", "kappa_v"), "VEL_WARM")
         err = -0.1
-        ph("DRHO_DIV_BEGIN")
+        xp("vel", "DRHO_DIV_BEGIN")
         dt = float(self.dt)
         while float(self.avg_density_err) > err and self.dv_iter < 10:
-            ph("MAKE_K_DIV"); x("kbuf")
-            ph("VEL_ITER"); x("vel")
-            ph("DRHO_DIV_ITER")
+            ph("MAKE_K_DIV"); xp("kbuf", "VEL_ITER")
+            xp("vel", "DRHO_DIV_ITER")
             self.avg_density_err = np.float32(self.allsum(B.get_acc(ACC_ERR)))
             err = 0.001 * N / dt
             self.dv_iter += 1
@@ -326,20 +371,18 @@ class SlabSim:
         ph("CLEAR")
         if self.tension:
             ph("TENSION_NORMAL"); x("normal"); ph("TENSION_ACCEL")
-        ph("VISC_GUESS"); x("vel_guess")
-        ph("VISC_MINV_RESIDUAL")
+        ph("VISC_GUESS"); xp("vel_guess", "VISC_MINV_RESIDUAL")
         self.cg_delta_zero = np.float32(self.allsum(B.get_acc(ACC_DZERO)))
         self.cg_delta = self.cg_delta_zero
-        x("cg_dir")
         self.vs_iter = 0
         while self.vs_iter < 100:
             B.set_scalar("cg_delta", self.cg_delta)
-            ph("VISC_AD")
+            xp("cg_dir", "VISC_AD")
             B.set_acc(ACC_DAD, self.allsum(B.get_acc(ACC_DAD)))
             ph("VISC_UPDATE")
             dnew = self.allsum(B.get_acc(ACC_DNEW))
             B.set_acc(ACC_DNEW, dnew)
-            ph("VISC_DIR"); x("cg_dir")
+            ph("VISC_DIR")
             self.cg_delta = np.float32(dnew)
             self.vs_iter += 1
             if float(self.cg_delta) <= self.viscosity_err * float(self.cg_delta_zero) or float(self.cg_delta_zero) < self.eps:
@@ -360,18 +403,17 @@ class SlabSim:
                 d = np.float32(d * 1.1)
             self.dt = np.float32(min(d, time_step))
             B.set_scalar("deltaT", self.dt)
-        ph("UPDATE_VEL"); x("vel")
+        ph("UPDATE_VEL")
 
         # solve_pressure()  (dfsph.py:150-164); the warm start is a no-op in the reference (Q7): its gate
-        # adv_rho > rho_L0 never opens, so kappa_j of ghosts is not refreshed for it
+        # adv_rho > rho_L0 never opens, so kappa_j of ghosts is not refreshed for it and it changes no velocity
         ph("WARM_PRESS_SCALE"); ph("WARM_PRESS_VEL")
         self.pr_iter = 0
         err = 0.0
-        ph("DRHO_PRESS_BEGIN")
+        xp("vel", "DRHO_PRESS_BEGIN")
         while (err > 0.001 or self.pr_iter < 2) and self.pr_iter < 100:
-            ph("MAKE_K_PRESS"); x("kbuf")
-            ph("VEL_ITER"); x("vel")
-            ph("DRHO_PRESS_ITER")
+            ph("MAKE_K_PRESS"); xp("kbuf", "VEL_ITER")
+            xp("vel", "DRHO_PRESS_ITER")
             self.pr_iter += 1
             if self.pr_iter < 2:      # `pr_iter < 2` forces the second iteration whatever the first reports:
                 err = 1.0             # no device wait, no all-reduce for a value that cannot change the control flow
