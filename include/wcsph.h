@@ -278,6 +278,7 @@ enum wcsph_phase {
   WCSPH_PH_UPDATE_POS,        /* dfsph.py:577-580 */
   WCSPH_PH_DENSITY_COFF_WARM, /* DENSITY_COFF + DRHO_DIV_WARM in one walk (neither reads a neighbour field the other writes) */
   WCSPH_PH_VISC_MINV_RESIDUAL, /* VISC_MINV + VISC_RESIDUAL in one walk, slot 3 <- local sum */
+  WCSPH_PH_VISC_MINV_RESIDUAL_VORT, /* ... + the sums of VORTICITY (reads vel_j, omega_j, rho_j: unchanged by the viscosity solve) */
   WCSPH_PH__COUNT
 };
 int wcsph_phase(wcsph_ctx *ctx, int phase);

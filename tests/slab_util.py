@@ -20,6 +20,7 @@ _PH = {
     "UPDATE_POS": ["update_pos"],
     "DENSITY_COFF_WARM": ["compute_density", "compute_dfsph_coff", "warmstart_divergence_drho"],
     "VISC_MINV_RESIDUAL": ["visc_minv", "visc_residual"],
+    "VISC_MINV_RESIDUAL_VORT": ["visc_minv", "visc_residual", "vorticity_accumulate"],
 }
 
 

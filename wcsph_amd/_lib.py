@@ -78,7 +78,7 @@ ALL_SYMBOLS = CTX_ONLY + OTHER
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
           "WARM_PRESS_SCALE", "WARM_PRESS_VEL", "DRHO_PRESS_BEGIN", "MAKE_K_PRESS", "DRHO_PRESS_ITER", "END_PRESS", "CLEAR",
           "TENSION_NORMAL", "TENSION_ACCEL", "VISC_GUESS", "VISC_MINV", "VISC_RESIDUAL", "VISC_AD", "VISC_UPDATE", "VISC_DIR",
-          "VISC_END", "VORTICITY", "VORTICITY_INT", "UPDATE_VEL", "UPDATE_POS", "DENSITY_COFF_WARM", "VISC_MINV_RESIDUAL"]
+          "VISC_END", "VORTICITY", "VORTICITY_INT", "UPDATE_VEL", "UPDATE_POS", "DENSITY_COFF_WARM", "VISC_MINV_RESIDUAL", "VISC_MINV_RESIDUAL_VORT"]
 PHASE_ID = {n: i for i, n in enumerate(PHASES)}
 ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = 0, 1, 2, 3
 

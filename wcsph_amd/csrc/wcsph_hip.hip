@@ -1380,6 +1380,7 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); break;
     case WCSPH_PH_DENSITY_COFF_WARM: if (ctx->use_tiles) { PASS(k_density_coff); HOT_DRHO_DIV(DRHO_WARM, dt); } else PASS(k_density_coff_warm, dt); break;
     case WCSPH_PH_VISC_MINV_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual, dt); break;
+    case WCSPH_PH_VISC_MINV_RESIDUAL_VORT: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual_vort, dt); break;
     case WCSPH_PH_DRHO_DIV_WARM: HOT_DRHO_DIV(DRHO_WARM, dt); break;
     case WCSPH_PH_VEL_WARM: HOT_VEL(1, ctx->d.kappa_v, dt, 1); break;
     case WCSPH_PH_DRHO_DIV_BEGIN: HOT_DRHO_DIV(DRHO_BEGIN, dt); break;

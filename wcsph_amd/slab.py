@@ -371,7 +371,9 @@ class SlabSim:
         ph("CLEAR")
         if self.tension:
             ph("TENSION_NORMAL"); x("normal"); ph("TENSION_ACCEL")
-        ph("VISC_GUESS"); xp("vel_guess", "VISC_MINV_RESIDUAL")
+        # the sums of compute_vorticity() (dfsph.py:307-328) ride on the residual walk: vel_j, omega_j, rho_j do not change
+        # during the viscosity solve
+        ph("VISC_GUESS"); xp("vel_guess", "VISC_MINV_RESIDUAL_VORT")
         self.cg_delta_zero = np.float32(self.allsum(B.get_acc(ACC_DZERO)))
         self.cg_delta = self.cg_delta_zero
         self.vs_iter = 0
@@ -382,13 +384,13 @@ class SlabSim:
             ph("VISC_UPDATE")
             dnew = self.allsum(B.get_acc(ACC_DNEW))
             B.set_acc(ACC_DNEW, dnew)
-            ph("VISC_DIR")
             self.cg_delta = np.float32(dnew)
             self.vs_iter += 1
             if float(self.cg_delta) <= self.viscosity_err * float(self.cg_delta_zero) or float(self.cg_delta_zero) < self.eps:
                 break
+            ph("VISC_DIR")                                # the next search direction, only if there is a next iteration
         ph("VISC_END")
-        ph("VORTICITY"); ph("VORTICITY_INT")
+        ph("VORTICITY_INT")
 
         # optimize_time_step()  (dfsph.py:107-129)
         vmax = np.float32(self.allmax(B.cfl_local_max()))
