@@ -148,16 +148,23 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
 // Scan blocks wholly outside the cell columns [xmin-2, xmax+2] of the occupied box hold only zeros: their block sum
 // is written as 0 without reading, their outputs are left alone (nothing reads cells that far from every particle).
 // The last block (out-of-box bin, grand total) is always processed.  bbox == nullptr: everything.
-__device__ __forceinline__ bool scan_block_active(const int *bbox, int n, int col_cells) {
+// nz > 0 additionally skips blocks that lie in one x-plane but wholly outside the rows [ymin-2, ymax+2] of the box
+// (a 2048-cell block spans ~8 rows of a 254-cell column): no particle's 5^3 cells reach them either.
+__device__ __forceinline__ bool scan_block_active(const int *bbox, int n, int col_cells, int nz) {
   if (!bbox || (int)blockIdx.x == (n - 1) / SCAN_TILE) return true;
   const int xmin = bbox[0], xmax = bbox[3];
   if (xmax < 0) return false;
   const long lo = (long)max(xmin - 2, 0) * col_cells, hi = (long)(xmax + 3) * col_cells + 1;
   const long b0 = (long)blockIdx.x * SCAN_TILE, b1 = b0 + SCAN_TILE;
-  return b1 > lo && b0 <= hi;
+  if (!(b1 > lo && b0 <= hi)) return false;
+  if (nz > 0 && b0 / col_cells == (b1 - 1) / col_cells) {
+    const int y0 = (int)((b0 % col_cells) / nz), y1 = (int)(((b1 - 1) % col_cells) / nz);
+    if (y1 < bbox[1] - 2 || y0 > bbox[4] + 3) return false;   // +3: a row's end bound is the first cell of the next row
+  }
+  return true;
 }
-__global__ void k_scan_reduce(const int *in, int n, int *bsum, const int *bbox, int col_cells) {
-  if (!scan_block_active(bbox, n, col_cells)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
+__global__ void k_scan_reduce(const int *in, int n, int *bsum, const int *bbox, int col_cells, int nz) {
+  if (!scan_block_active(bbox, n, col_cells, nz)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int s = 0;
 #pragma unroll
@@ -166,26 +173,18 @@ __global__ void k_scan_reduce(const int *in, int n, int *bsum, const int *bbox, 
   block_exclusive_scan(s, &tot);
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ void k_scan_bsums(int *bsum, int nb) {  // one block
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += BLOCK) {
-    int idx = base + threadIdx.x;
-    int v = idx < nb ? bsum[idx] : 0;
-    int tot;
-    int ex = block_exclusive_scan(v, &tot);
-    int c = carry;
-    if (idx < nb) bsum[idx] = c + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry = c + tot;
-    __syncthreads();
-  }
+__global__ void k_scan_bsums(int *bsum, int nb) {  // one block: every thread owns a contiguous chunk of the block sums
+  const int per = (nb + BLOCK - 1) / BLOCK, b = threadIdx.x * per, e = min(b + per, nb);
+  int s = 0;
+  for (int k = b; k < e; k++) s += bsum[k];
+  int tot;
+  int run = block_exclusive_scan(s, &tot);
+  for (int k = b; k < e; k++) { const int v = bsum[k]; bsum[k] = run; run += v; }
 }
 // clear != 0: the counters are zeroed as they are consumed, so the next grid update needs no 65 MB memset (only
 // cells of the active blocks can be non-zero: every counted particle lies inside the occupied box or in the last bin)
-__global__ void k_scan_final(int *in, int n, const int *bsum, int *out, const int *bbox, int col_cells, int clear) {
-  if (!scan_block_active(bbox, n, col_cells)) return;
+__global__ void k_scan_final(int *in, int n, const int *bsum, int *out, const int *bbox, int col_cells, int clear, int nz) {
+  if (!scan_block_active(bbox, n, col_cells, nz)) return;
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int v[SCAN_PER_THREAD], s = 0;
 #pragma unroll

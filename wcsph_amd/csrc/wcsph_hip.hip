@@ -261,9 +261,11 @@ int wcsph_sync(wcsph_ctx *ctx) {
 static int run_scan(wcsph_ctx *ctx, int *in, int n, int *out, const int *bbox, int clear = 0) {
   int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   const int col = ctx->d.ny * ctx->d.nz;
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, bbox, col);
+  // y-row skipping only with the list path: the experimental LDS tiles read whole tile rows of the cell table
+  const int nz = (bbox && !ctx->use_tiles) ? ctx->d.nz : 0;
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, bbox, col, nz);
   hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->bsum, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out, bbox, col, clear);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out, bbox, col, clear, nz);
   LAUNCHCHK();
   return 0;
 }
