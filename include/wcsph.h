@@ -282,6 +282,11 @@ enum wcsph_phase {
   WCSPH_PH__COUNT
 };
 int wcsph_phase(wcsph_ctx *ctx, int phase);
+/* Use a caller-owned device buffer of 8 x 64 doubles (slot s = doubles [64 s, 64 s + 64), striped partial sums) for the
+ * reduction slots, so that a slab driver can all-reduce a slot IN PLACE on the device (torch.distributed on the
+ * context's stream): elementwise SUM over ranks of the stripes leaves the global total to every reader.  The buffer
+ * must outlive the context's use of it. */
+int wcsph_set_acc_buffer(wcsph_ctx *ctx, void *device_doubles);
 /* Halo/compute overlap: restrict the NEIGHBOUR passes launched next to a part of the owned particles.  mode 0: all;
  * 1: only particles in global cell columns [x_lo, x_hi) -- the slab interior, whose 5^3 cells hold no ghost, so the
  * pass may run while a halo exchange is in flight; 2: only the others (run after the exchange; reduction slots are

@@ -1369,6 +1369,14 @@ int wcsph_set_acc(wcsph_ctx *ctx, int slot, double v) {
   HIPCHK(hipStreamSynchronize(ctx->stream));  // row lives on this stack
   return WCSPH_OK;
 }
+int wcsph_set_acc_buffer(wcsph_ctx *ctx, void *device_doubles) {
+  NEED_SETUP();
+  if (!device_doubles) return WCSPH_EARG;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->d.acc = (double *)device_doubles;   // the context's own buffer stays in ctx->allocs and is freed with it
+  HIPCHK(hipMemsetAsync(ctx->d.acc, 0, 8 * ACC_STRIPES * sizeof(double), ctx->stream));
+  return WCSPH_OK;
+}
 int wcsph_set_part(wcsph_ctx *ctx, int32_t mode, int32_t x_lo, int32_t x_hi) {
   if (!ctx || mode < 0 || mode > 2) return WCSPH_EARG;
   ctx->d.part_mode = mode; ctx->d.part_x0 = x_lo; ctx->d.part_x1 = x_hi > x_lo ? x_hi : x_lo;

@@ -56,6 +56,9 @@ class HipBackend:
         self.stream = torch.cuda.Stream(self.device)
         _lib.check(self.ctx, self.lib.wcsph_set_stream(self.ctx, C.c_void_p(self.stream.cuda_stream)))
         pd.setup_data_cpu()
+        # reduction slots in a torch tensor: the slab driver all-reduces them in place on the device (SlabSim.reduce_acc)
+        self.acc = torch.zeros(8 * _lib.ACC_STRIPES, dtype=torch.float64, device=self.device)
+        _lib.check(self.ctx, self.lib.wcsph_set_acc_buffer(self.ctx, C.c_void_p(self.acc.data_ptr())))
         torch.cuda.synchronize(self.device)
         self.pd = pd
         self.capacity = int(capacity)
@@ -301,6 +304,26 @@ class SlabSim:
         dist.all_reduce(t, op=op, group=self.group)
         return float(t.item())
 
+    def reduce_acc(self, slot, fetch=True):
+        """Global total of reduction slot `slot`.  With a device-resident slot buffer (HipBackend.acc) the stripes are
+        all-reduced in place on the stream -- kernels launched next read the global total, no host round trip -- and the
+        host value, when asked for, costs one wait.  Other backends: local value -> all-reduce -> written back."""
+        B = self.B
+        acc = getattr(B, "acc", None)
+        if acc is None or self.world == 1:
+            v = self.allsum(B.get_acc(slot)) if self.world > 1 else B.get_acc(slot)
+            if self.world > 1:
+                B.set_acc(slot, v)
+            return v
+        sl = acc[slot * _lib.ACC_STRIPES:(slot + 1) * _lib.ACC_STRIPES]
+        if self.comm_device != self.device:        # gloo dry run: stage through the host
+            t = sl.to(self.comm_device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            sl.copy_(t)
+        else:
+            dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
+        return B.get_acc(slot) if fetch else None
+
     def allsum(self, v): return self._allreduce(v, dist.ReduceOp.SUM)   # noqa: E704
     def allmax(self, v): return self._allreduce(v, dist.ReduceOp.MAX)   # noqa: E704
 
@@ -362,7 +385,7 @@ class SlabSim:
         while float(self.avg_density_err) > err and self.dv_iter < 10:
             ph("MAKE_K_DIV"); xp("kbuf", "VEL_ITER")
             xp("vel", "DRHO_DIV_ITER")
-            self.avg_density_err = np.float32(self.allsum(B.get_acc(ACC_ERR)))
+            self.avg_density_err = np.float32(self.reduce_acc(ACC_ERR))
             err = 0.001 * N / dt
             self.dv_iter += 1
         ph("END_DIV")
@@ -374,16 +397,15 @@ class SlabSim:
         # the sums of compute_vorticity() (dfsph.py:307-328) ride on the residual walk: vel_j, omega_j, rho_j do not change
         # during the viscosity solve
         ph("VISC_GUESS"); xp("vel_guess", "VISC_MINV_RESIDUAL_VORT")
-        self.cg_delta_zero = np.float32(self.allsum(B.get_acc(ACC_DZERO)))
+        self.cg_delta_zero = np.float32(self.reduce_acc(ACC_DZERO))
         self.cg_delta = self.cg_delta_zero
         self.vs_iter = 0
         while self.vs_iter < 100:
             B.set_scalar("cg_delta", self.cg_delta)
             xp("cg_dir", "VISC_AD")
-            B.set_acc(ACC_DAD, self.allsum(B.get_acc(ACC_DAD)))
+            self.reduce_acc(ACC_DAD, fetch=False)          # k_visc_update reads the global dAd on the device
             ph("VISC_UPDATE")
-            dnew = self.allsum(B.get_acc(ACC_DNEW))
-            B.set_acc(ACC_DNEW, dnew)
+            dnew = self.reduce_acc(ACC_DNEW)               # k_visc_dir reads the global delta' on the device
             self.cg_delta = np.float32(dnew)
             self.vs_iter += 1
             if float(self.cg_delta) <= self.viscosity_err * float(self.cg_delta_zero) or float(self.cg_delta_zero) < self.eps:
@@ -420,7 +442,7 @@ class SlabSim:
             if self.pr_iter < 2:      # `pr_iter < 2` forces the second iteration whatever the first reports:
                 err = 1.0             # no device wait, no all-reduce for a value that cannot change the control flow
                 continue
-            self.avg_density_err = np.float32(self.allsum(B.get_acc(ACC_ERR)))
+            self.avg_density_err = np.float32(self.reduce_acc(ACC_ERR))
             err = float(self.avg_density_err) / N
         ph("END_PRESS")
         ph("UPDATE_POS")
