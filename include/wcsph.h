@@ -241,6 +241,8 @@ int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1);
  * (the fields the reference carries across steps).  Rows [0,n_owned) are this rank's particles, the rest are
  * ghost copies: read as neighbours, never updated, excluded from reductions.  n_total <= params.n_liquid. */
 int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows);
+/* the same from two row blocks (owned rows, then ghost rows): saves the driver a concatenation of the whole state */
+int wcsph_load_state_split(wcsph_ctx *ctx, int32_t n_owned, const float *d_owned_rows, int32_t n_ghost, const float *d_ghost_rows);
 int wcsph_store_state(wcsph_ctx *ctx, float *d_rows /* device [n_owned][14] */);
 /* reduction slots of the running phase (double): 0 density-error sum, 1 d.Ad, 2 r.s, 3 delta_zero */
 int wcsph_get_acc(wcsph_ctx *ctx, int slot, double *v);   /* synchronises */

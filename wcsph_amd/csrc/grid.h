@@ -379,10 +379,11 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
 
 // ---- slab decomposition: whole-state load / store in original (row) order -----------------------
 #define STATE_W 14
-__global__ void k_load_state(Dev d, const float *rows, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float *r = rows + (size_t)i * STATE_W;
+__global__ void k_load_state(Dev d, const float *rows, int n, int first) {   // rows[t] -> particle first + t
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = first + t;
+  const float *r = rows + (size_t)t * STATE_W;
   d.pos[i] = make_float4(r[0], r[1], r[2], __int_as_float(-1));
   d.vel[i] = make_float4(r[3], r[4], r[5], 0);
   d.omega[i] = make_float4(r[6], r[7], r[8], 0);

@@ -1339,9 +1339,20 @@ int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const flo
   ctx->d.nl = n_total; ctx->d.n_owned = n_owned;
   if (n_total > 0) {
     if (!d_rows) return WCSPH_EARG;
-    hipLaunchKernelGGL(k_load_state, dim3(nblk(n_total)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows, n_total);
+    hipLaunchKernelGGL(k_load_state, dim3(nblk(n_total)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows, n_total, 0);
     LAUNCHCHK();
   }
+  ctx->grid_valid = false;
+  return WCSPH_OK;
+}
+int wcsph_load_state_split(wcsph_ctx *ctx, int32_t n_owned, const float *d_owned_rows, int32_t n_ghost, const float *d_ghost_rows) {
+  NEED_SETUP();
+  if (n_owned < 0 || n_ghost < 0 || (long)n_owned + n_ghost > ctx->capacity) return ctx->fail(WCSPH_EARG, "load_state: counts exceed the context capacity");
+  if ((n_owned > 0 && !d_owned_rows) || (n_ghost > 0 && !d_ghost_rows)) return WCSPH_EARG;
+  ctx->d.nl = n_owned + n_ghost; ctx->d.n_owned = n_owned;
+  if (n_owned > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_owned)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_owned_rows, n_owned, 0);
+  if (n_ghost > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_ghost)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_ghost_rows, n_ghost, n_owned);
+  LAUNCHCHK();
   ctx->grid_valid = false;
   return WCSPH_OK;
 }

@@ -67,6 +67,17 @@ class HipBackend:
     def _chk(self, rc):
         _lib.check(self.ctx, rc)
 
+    def load_state_split(self, owned, ghosts):
+        """owned rows and ghost rows as two tensors (no concatenation of the whole state)"""
+        owned = owned.contiguous(); ghosts = [g.contiguous() for g in ghosts if g.shape[0]]
+        ghost = ghosts[0] if len(ghosts) == 1 else (torch.cat(ghosts, 0) if ghosts else owned[:0])
+        if owned.shape[0] + ghost.shape[0] > self.capacity:
+            raise RuntimeError("slab capacity %d exceeded (%d rows)" % (self.capacity, owned.shape[0] + ghost.shape[0]))
+        self.n_owned = int(owned.shape[0])
+        self._chk(self.lib.wcsph_load_state_split(self.ctx, self.n_owned, C.c_void_p(owned.data_ptr()), int(ghost.shape[0]),
+                                                  C.c_void_p(ghost.data_ptr())))
+        self._keep = (owned, ghost)  # keep alive until the stream has consumed them
+
     def load_state(self, n_owned, rows):
         rows = rows.contiguous()
         if rows.shape[0] > self.capacity:
@@ -332,32 +343,40 @@ class SlabSim:
         """Migrate particles that crossed a cut, then rebuild the ghost layers and load the backend."""
         rows = self.rows
         i32 = torch.int32
+        gl = gr = None
         if self.world > 1:
             cx = self._cellx(rows)
             go_l = (cx < self.lo) if self.rank > 0 else torch.zeros_like(cx, dtype=torch.bool)
             go_r = (cx >= self.hi) if self.rank < self.world - 1 else torch.zeros_like(cx, dtype=torch.bool)
-            in_l, in_r = self._exchange_var(rows[go_l], rows[go_r])
-            rows = torch.cat([rows[~(go_l | go_r)], in_l, in_r], 0)
-            cx = self._cellx(rows)
+            n_l, n_r = torch.stack([go_l.sum(), go_r.sum()]).tolist()        # one host wait; both are 0 on most steps
+            empty = rows[:0]
+            out_l = rows.index_select(0, torch.nonzero(go_l).flatten()) if n_l else empty
+            out_r = rows.index_select(0, torch.nonzero(go_r).flatten()) if n_r else empty
+            in_l, in_r = self._exchange_var(out_l, out_r)
+            if n_l or n_r or in_l.shape[0] or in_r.shape[0]:                 # otherwise the owned rows stay where they are
+                rows = torch.cat([rows[~(go_l | go_r)], in_l, in_r], 0)
+                cx = self._cellx(rows)
             near_l = (cx < self.lo + GHOST_CELLS) if self.rank > 0 else torch.zeros_like(cx, dtype=torch.bool)
             near_r = (cx >= self.hi - GHOST_CELLS) if self.rank < self.world - 1 else torch.zeros_like(cx, dtype=torch.bool)
-            self.send_l = torch.nonzero(near_l).flatten().to(i32)
-            self.send_r = torch.nonzero(near_r).flatten().to(i32)
-            gl, gr = self._exchange_var(rows[near_l], rows[near_r])
+            self.send_l = torch.nonzero(near_l).flatten()
+            self.send_r = torch.nonzero(near_r).flatten()
+            gl, gr = self._exchange_var(rows.index_select(0, self.send_l), rows.index_select(0, self.send_r))
+            self.send_l, self.send_r = self.send_l.to(i32), self.send_r.to(i32)
             n = rows.shape[0]
             self.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=self.device)
             self.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=self.device)
-            allrows = torch.cat([rows, gl, gr], 0)
         else:
             n = rows.shape[0]
             empty = torch.zeros(0, dtype=i32, device=self.device)
             self.send_l = self.send_r = self.ghost_l = self.ghost_r = empty
-            allrows = rows
         self.send_all = torch.cat([self.send_l, self.send_r])
         self.ghost_all = torch.cat([self.ghost_l, self.ghost_r])
         self.rows = rows
         self.n_owned = rows.shape[0]
-        self.B.load_state(self.n_owned, allrows)
+        if gl is not None and hasattr(self.B, "load_state_split"):
+            self.B.load_state_split(rows, (gl, gr))
+        else:
+            self.B.load_state(self.n_owned, rows if gl is None else torch.cat([rows, gl, gr], 0))
 
     # ---- the step -------------------------------------------------------------------------------------------
     def step(self):
