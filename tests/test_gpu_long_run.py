@@ -35,3 +35,28 @@ def test_default_scene_statistics_track_the_oracle():
     assert np.abs(ig.mean(0) - io.mean(0)).max() < 0.5                         # solver effort per step
     assert (pg[:, 1] > -1e-3).all() and (np.abs(pg[:, [0, 2]]) < 1.0 + 1e-3).all()   # nobody left the box
     pd.close()
+
+
+@pytest.mark.parametrize("mode", ["faithful", "clean"])
+def test_midsize_scene_first_steps_match_the_oracle(mode):
+    """56^3 = 175 616 liquid + ~200 k boundary particles: big enough for everything size-dependent in the library (scan
+    restriction to the occupied box, XCD block remap over >1000 blocks, multi-block reductions, alias tables of a
+    ~1.5 M-cell grid) and still seconds for the oracle; three steps, field by field."""
+    from oracle import Oracle
+    from wcsph_amd import dfsph
+    pd = dfsph.init_particle(particleDim=56, neighbor_mode=mode)
+    nl = pd.liquid_count
+    o = Oracle(pd.pos.to_numpy(), nl, 0.025, mode=mode)
+    dfsph.reset_param(); o.reset_param()
+    for s in range(3):
+        dt = dfsph.step()
+        o.dfsph_step()
+        assert (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter) == (o.vs_iter, o.dv_iter, o.pr_iter)
+        assert abs(dt - o.deltaT) <= 1e-6 * o.deltaT
+        np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)
+    rho = pd.rho.to_numpy()
+    assert np.abs(rho - o.rho).max() / o.rho.max() < 1e-4                      # north star: per-particle density error
+    assert np.abs(pd.pos.to_numpy()[:nl] - o.pos[:nl]).max() < 2e-6
+    v = pd.vel.to_numpy()
+    assert np.abs(v - o.vel).max() < 2e-3 * max(np.abs(o.vel).max(), 1e-3)
+    pd.close()
