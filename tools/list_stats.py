@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Compact neighbour-list statistics early and late in a C3 run: python tools/list_stats.py <late_step> [mode]"""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np
@@ -5,7 +7,6 @@ from wcsph_amd import dfsph, scene
 pd = dfsph.init_particle(particleDim=126, neighbor_mode=sys.argv[2] if len(sys.argv) > 2 else "faithful")
 dfsph.reset_param()
 for tgt in [10, int(sys.argv[1])]:
-    while dfsph_steps if False else False: pass
     while getattr(pd, "_n", 0) < tgt:
         dfsph.step(); pd._n = getattr(pd, "_n", 0) + 1
     pd.hash_grid.update_grid()
