@@ -501,6 +501,9 @@ def bench_main(args):
     local = int(os.environ.get("LOCAL_RANK", rank))
     # WCSPH_BENCH_COMM=gloo: dry run of this path with every rank on ONE GPU (halo buffers staged through the
     # host); the real thing is RCCL (backend "nccl") with one GPU per rank
+    # a wedged collective must not hold the node: dump the stacks and exit after 20 minutes
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("WCSPH_BENCH_WATCHDOG_S", "1200")), exit=True)
     comm = os.environ.get("WCSPH_BENCH_COMM", "nccl")
     if comm == "gloo":
         local = 0
@@ -566,4 +569,5 @@ def bench_main(args):
     dist.barrier()
     sim.B.close()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
     return result
