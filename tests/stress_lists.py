@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Randomised check of the compact neighbour streams against the CPU oracle (TEST TOOL: imports oracle/):
+"""Randomised check of the compact neighbour streams against the CPU oracle (test infrastructure, not collected by pytest: run by hand on a GPU box):
 for several scenes / jitters / modes, after every DFSPH step the decoded stream of EVERY liquid particle must equal the
 in-support part of the oracle's list (entries within 1e-5 of the list radius may fall on either side).
-    python tools/stress_lists.py [seeds]"""
+    python tests/stress_lists.py [seeds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from util import make_pair
 
