@@ -337,9 +337,13 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   // scalars, not indexed arrays: keeps the indices in VGPRs (an int j[U] lands in scratch here)
 #define WALK_ONE(u, dd, jj, pp, bb) if (dd) { const float3 r = xi - xyz(pp); fl(jj, r, dot3(r, r), bb); }
 #define WALK_OK(u, dd) const bool ok##u = (k + u < cl) & NB_IS_ENTRY(dd);   /* a lane mask in SGPRs: the deltas die here */
+  // the stream block of the NEXT trip is requested before this trip's gathers go out: its (HBM) latency hides behind
+  // the gathers and the arithmetic instead of heading the next trip's dependency chain
+  uint4 en = cl > 0 ? L[0] : make_uint4(0, 0, 0, 0);
   for (int k = 0; k < cl; k += U) {
     if (U == 8) {
-      const uint4 e = L[(size_t)(k >> 3) * st];
+      const uint4 e = en;
+      if (k + 8 < cl) en = L[(size_t)((k >> 3) + 1) * st];
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
       run = j7;
@@ -353,7 +357,8 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
       WALK_ONE(0, ok0, j0, p0, b0) WALK_ONE(1, ok1, j1, p1, b1) WALK_ONE(2, ok2, j2, p2, b2) WALK_ONE(3, ok3, j3, p3, b3)
       WALK_ONE(4, ok4, j4, p4, b4) WALK_ONE(5, ok5, j5, p5, b5) WALK_ONE(6, ok6, j6, p6, b6) WALK_ONE(7, ok7, j7, p7, b7)
     } else {
-      const uint2 e = reinterpret_cast<const uint2 *>(L + (size_t)(k >> 3) * st)[(k >> 2) & 1];
+      const uint2 e = (k & 4) ? make_uint2(en.z, en.w) : make_uint2(en.x, en.y);   // k is wave-uniform
+      if ((k & 4) && k + 4 < cl) en = L[(size_t)((k >> 3) + 1) * st];
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3;
       run = j3;
