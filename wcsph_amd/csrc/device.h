@@ -323,9 +323,20 @@ template <class T>
 __device__ __forceinline__ T nb_ld(const T *base, int j) {
   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)j * (unsigned)sizeof(T));
 }
+// a stream block, optionally non-temporal (see walk<.., NT>)
+template <bool NT>
+__device__ __forceinline__ uint4 nb_stream(const uint4 *p) {
+  if (!NT) return *p;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 #define NB_LO(w) ((int)(short)((w) & 0xffffu))
 #define NB_HI(w) ((int)(w) >> 16)
-template <int U, class GL, class FL, class FS>
+// NT: the stream is loaded non-temporally.  For passes that run once per step it keeps the stream from displacing the
+// gather records in L2 / Infinity Cache; the solver-loop passes leave it off, because the velocity pass and the
+// density-change pass of an iteration read the SAME 180 MB stream 50 us apart and the second finds it cached.
+template <int U, bool NT = false, class GL, class FL, class FS>
 __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
   static_assert(U == 4 || U == 8, "U slots per trip");
   const float3 xi = xyz(pi);
@@ -339,11 +350,11 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
 #define WALK_OK(u, dd) const bool ok##u = (k + u < cl) & NB_IS_ENTRY(dd);   /* a lane mask in SGPRs: the deltas die here */
   // the stream block of the NEXT trip is requested before this trip's gathers go out: its (HBM) latency hides behind
   // the gathers and the arithmetic instead of heading the next trip's dependency chain
-  uint4 en = cl > 0 ? L[0] : make_uint4(0, 0, 0, 0);
+  uint4 en = cl > 0 ? nb_stream<NT>(L) : make_uint4(0, 0, 0, 0);
   for (int k = 0; k < cl; k += U) {
     if (U == 8) {
       const uint4 e = en;
-      if (k + 8 < cl) en = L[(size_t)((k >> 3) + 1) * st];
+      if (k + 8 < cl) en = nb_stream<NT>(L + (size_t)((k >> 3) + 1) * st);
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
       run = j7;
@@ -358,7 +369,7 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
       WALK_ONE(4, ok4, j4, p4, b4) WALK_ONE(5, ok5, j5, p5, b5) WALK_ONE(6, ok6, j6, p6, b6) WALK_ONE(7, ok7, j7, p7, b7)
     } else {
       const uint2 e = (k & 4) ? make_uint2(en.z, en.w) : make_uint2(en.x, en.y);   // k is wave-uniform
-      if ((k & 4) && k + 4 < cl) en = L[(size_t)((k >> 3) + 1) * st];
+      if ((k & 4) && k + 4 < cl) en = nb_stream<NT>(L + (size_t)((k >> 3) + 1) * st);
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3;
       run = j3;
@@ -376,7 +387,7 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   run = head.y;
 #define WALK_SOL(u, dd, jj, pp) if (k + u < cs && NB_IS_ENTRY(dd)) { const float3 r = xi - xyz(pp); fs(jj, r, dot3(r, r)); }
   for (int k = 0; k < cs; k += 8) {
-    const uint4 e = S[(size_t)(k >> 3) * st];
+    const uint4 e = nb_stream<NT>(S + (size_t)(k >> 3) * st);
     const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
     const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
     run = j7;

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
   LOAD_I
   if (!own) return;
   float sl = 0.f, ss = 0.f;
-  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
+  walk<8, true>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
           [&](int, float3, float r2) { ss += cubic_W(d, r2); });
   d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
 }
@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(BLOCK) k_coff(Dev d) {
   if (!own) return;
   float3 sg = f3(0, 0, 0);
   float sq = 0.f;
-  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8, true>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             float g = cubic_gradW_scale(d, r2) * d.VL0;
             sq += g * g * r2;
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
   if (!own) return;
   float sl = 0.f, ss = 0.f, sq = 0.f;
   float3 sg = f3(0, 0, 0);
-  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8, true>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             sl += cubic_W(d, r2);
             float g = cubic_gradW_scale(d, r2) * d.VL0;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
   float sl = 0.f, ss = 0.f, sq = 0.f, a = 0.f;
   float3 sg = f3(0, 0, 0);
   const float3 vi = xyz(d.vel[i]);
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+  walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
           [&](int, float3 r, float r2, float4 vj) {
             sl += cubic_W(d, r2);
             const float gw = cubic_gradW_scale(d, r2);
@@ -299,7 +299,7 @@ __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const 
   float3 ret = f3(0, 0, 0);
   const float cl = d.dim_coff * d.visc * d.mass;
   const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(x, j); xj.w = nb_ld(d.rho, j); return xj; },
+  walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(x, j); xj.w = nb_ld(d.rho, j); return xj; },
           [&](int, float3 r, float r2, float4 xj) {
             float s = cl * dot3(xi - xyz(xj), r) * frcp(xj.w * (r2 + e));
             ret = ret + r * (s * cubic_gradW_scale(d, r2));
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
     m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
     m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
   };
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
+  walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
           [&](int, float3 r, float r2, float rhoj) { accum(r, cl * frcp(rhoj * (r2 + e)) * cubic_gradW_scale(d, r2)); },
           [&](int, float3 r, float r2) { accum(r, cs * frcp(r2 + e) * cubic_gradW_scale(d, r2)); });
   const float f = dt / rhoi;
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
       m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
       m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
     };
-    walk<8>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(d.vel_guess, j); xj.w = nb_ld(d.rho, j); return xj; },
+    walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(d.vel_guess, j); xj.w = nb_ld(d.rho, j); return xj; },
             [&](int, float3 r, float r2, float4 xj) {
               const float c = cl * cubic_gradW_scale(d, r2) * frcp(xj.w * (r2 + e));
               accum(r, c);
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float 
     const float c2 = d.vort_coff / rhoi * d.mass;
     const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
     struct XVW { float4 x, v, w; };
-    walk<4>(d, i, pi, d.pos, [&](int j, float4) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = nb_ld(d.rho, j); q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
+    walk<4, true>(d, i, pi, d.pos, [&](int j, float4) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = nb_ld(d.rho, j); q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
             [&](int, float3 r, float r2, XVW q) {
               const float g = cubic_gradW_scale(d, r2);
               const float irho = frcp(q.x.w);
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
   const float c2 = d.vort_coff / rhoi * d.mass;
   const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
   struct WV { float4 w, v; };
-  walk<4>(d, i, pi, d.pos, [&](int j, float4) { WV p; p.w = nb_ld(d.omega, j); p.w.w = nb_ld(d.rho, j); p.v = nb_ld(d.vel, j); return p; },
+  walk<4, true>(d, i, pi, d.pos, [&](int j, float4) { WV p; p.w = nb_ld(d.omega, j); p.w.w = nb_ld(d.rho, j); p.v = nb_ld(d.vel, j); return p; },
        [&](int, float3 r, float r2, WV pj) {
          float3 dw = wi - xyz(pj.w);
          float g = cubic_gradW_scale(d, r2);
