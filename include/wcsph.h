@@ -228,6 +228,11 @@ int wcsph_sample_surface(const float *tri_xyz, int32_t n_tri, double particle_ra
                          float *out_xyz, int32_t cap, int32_t *n_out);
 
 /* ---- measurement ---------------------------------------------------------------------- */
+/* In-situ timing of the dominant kernel pair: between begin and end every fused `pressure_iter` launch group
+ * (k_vel_from_k + k_drho_press<ITER>, dfsph.py:518-547) inside wcsph_dfsph_step / _solve_pressure is bracketed by HIP
+ * events on the context's stream (at most max_launches of them); end returns their average duration. */
+int wcsph_profile_begin(wcsph_ctx *ctx, int32_t max_launches);
+int wcsph_profile_end(wcsph_ctx *ctx, float *avg_ms, int32_t *launches);
 /* Times `reps` back-to-back launches of one named kernel group with hipEvents on the context's
  * stream; *ms_per_launch is the average.  Names: "pressure_iter", "divergence_iter", "density",
  * "grid_update", "visc_iter".  State is not preserved across the call. */

@@ -52,6 +52,10 @@ struct wcsph_ctx {
   int *mc_tables = nullptr;       // device: edge[256] + tri[256][MC_TRI_ROW]
   size_t mc_nodes = 0;
   bool vort_fuse = getenv("WCSPH_NO_VORT_FUSE") == nullptr;   // compute_nonpressure_force: vorticity sums in the residual walk
+  // in-situ timing of the fused pressure_iter launches (wcsph_profile_begin/end): event pairs on the context's stream
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  bool prof_on = false;
   bool in_step = false, cfl_done = false;   // wcsph_dfsph_step in progress; CFL maxima already taken
   bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
@@ -240,6 +244,7 @@ int wcsph_destroy(wcsph_ctx *ctx) {
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
+  for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -679,8 +684,11 @@ static int divergence_iter_fused(wcsph_ctx *ctx) {
 }
 static int pressure_iter_fused(wcsph_ctx *ctx) {
   if (ctx->use_tiles || ctx->d.n_owned < ctx->d.nl) return pressure_iter_async(ctx);
+  const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
+  if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
   PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);     // also clears ACC_ERR
   PASS((k_drho_press<DRHO_ITER, true>), ctx->dt);
+  if (prof) { HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream)); ctx->prof_used += 2; }
   return 0;
 }
 static int fused_iter_sync(wcsph_ctx *ctx) {
@@ -1521,6 +1529,34 @@ int wcsph_sample_surface(const float *tri_xyz, int32_t n_tri, double R, uint32_t
 }
 
 // ---- measurement --------------------------------------------------------------------------------
+int wcsph_profile_begin(wcsph_ctx *ctx, int32_t max_launches) {
+  NEED_SETUP();
+  if (max_launches < 1 || max_launches > (1 << 20)) return WCSPH_EARG;
+  while (ctx->prof_ev.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    ctx->prof_ev.push_back(e);
+  }
+  ctx->prof_used = 0;
+  ctx->prof_on = true;
+  return WCSPH_OK;
+}
+int wcsph_profile_end(wcsph_ctx *ctx, float *avg_ms, int32_t *launches) {
+  NEED_SETUP();
+  if (!avg_ms || !launches) return WCSPH_EARG;
+  ctx->prof_on = false;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  for (size_t k = 0; k + 1 < ctx->prof_used; k += 2) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, ctx->prof_ev[k], ctx->prof_ev[k + 1]));
+    tot += t;
+  }
+  *launches = (int32_t)(ctx->prof_used / 2);
+  *avg_ms = *launches ? (float)(tot / *launches) : 0.0f;
+  return WCSPH_OK;
+}
+
 int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
   NEED_GRID();
   if (!name || reps < 1 || !ms) return WCSPH_EARG;
