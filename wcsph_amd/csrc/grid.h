@@ -379,11 +379,17 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
 
 // ---- slab decomposition: whole-state load / store in original (row) order -----------------------
 #define STATE_W 14
-__global__ void k_load_state(Dev d, const float *rows, int n, int first) {   // rows[t] -> particle first + t
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int i = first + t;
-  const float *r = rows + (size_t)t * STATE_W;
+// A row is 14 floats = 56 bytes: read or written straight from a lane it is a 56-byte-stride access (1.5 TB/s); the
+// 256 rows of a block are one contiguous 14 KB piece, so they go through LDS with fully coalesced global accesses.
+__global__ void __launch_bounds__(BLOCK) k_load_state(Dev d, const float *rows, int n, int first) {   // rows[t] -> particle first + t
+  __shared__ float sh[BLOCK * STATE_W];
+  const int t0 = blockIdx.x * BLOCK, cnt = min(BLOCK, n - t0);
+  const float *src = rows + (size_t)t0 * STATE_W;
+  for (int k = threadIdx.x; k < cnt * STATE_W; k += BLOCK) sh[k] = src[k];
+  __syncthreads();
+  if ((int)threadIdx.x >= cnt) return;
+  const int i = first + t0 + threadIdx.x;
+  const float *r = sh + threadIdx.x * STATE_W;
   d.pos[i] = make_float4(r[0], r[1], r[2], __int_as_float(-1));
   d.vel[i] = make_float4(r[3], r[4], r[5], 0);
   d.omega[i] = make_float4(r[6], r[7], r[8], 0);
@@ -393,15 +399,20 @@ __global__ void k_load_state(Dev d, const float *rows, int n, int first) {   // 
   d.oid[i] = i;
   d.where[i] = i;
 }
-__global__ void k_store_state(Dev d, float *rows) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl) return;
-  int o = d.oid[i];
-  if (o >= d.n_owned) return;
-  float *r = rows + (size_t)o * STATE_W;
-  float4 p = d.pos[i], v = d.vel[i], w = d.omega[i], g = d.vel_guess[i];
-  r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = v.x; r[4] = v.y; r[5] = v.z; r[6] = w.x; r[7] = w.y; r[8] = w.z;
-  r[9] = g.x; r[10] = g.y; r[11] = g.z; r[12] = d.kappa[i]; r[13] = d.kappa_v[i];
+__global__ void __launch_bounds__(BLOCK) k_store_state(Dev d, float *rows) {   // one thread per ORIGINAL (row) index
+  __shared__ float sh[BLOCK * STATE_W];
+  const int o0 = blockIdx.x * BLOCK, cnt = min(BLOCK, d.n_owned - o0);
+  if (cnt <= 0) return;
+  if ((int)threadIdx.x < cnt) {
+    const int i = d.where[o0 + threadIdx.x];
+    float *r = sh + threadIdx.x * STATE_W;
+    const float4 p = d.pos[i], v = d.vel[i], w = d.omega[i], g = d.vel_guess[i];
+    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = v.x; r[4] = v.y; r[5] = v.z; r[6] = w.x; r[7] = w.y; r[8] = w.z;
+    r[9] = g.x; r[10] = g.y; r[11] = g.z; r[12] = d.kappa[i]; r[13] = d.kappa_v[i];
+  }
+  __syncthreads();
+  float *dst = rows + (size_t)o0 * STATE_W;
+  for (int k = threadIdx.x; k < cnt * STATE_W; k += BLOCK) dst[k] = sh[k];
 }
 
 // ---- original-order <-> sorted-order field transfer ---------------------------------------

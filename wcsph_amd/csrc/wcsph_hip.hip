@@ -1368,7 +1368,7 @@ int wcsph_store_state(wcsph_ctx *ctx, float *d_rows) {
   NEED_SETUP();
   if (ctx->d.nl > 0) {
     if (!d_rows) return WCSPH_EARG;
-    hipLaunchKernelGGL(k_store_state, dim3(nblk(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows);
+    if (ctx->d.n_owned > 0) hipLaunchKernelGGL(k_store_state, dim3(nblk(ctx->d.n_owned)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows);
     LAUNCHCHK();
   }
   return WCSPH_OK;
