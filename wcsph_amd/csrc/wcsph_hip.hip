@@ -173,6 +173,8 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   wcsph_ctx *ctx = new wcsph_ctx();
   *out = ctx;  // returned even on failure so that wcsph_last_error() works
   ctx->p = *p;
+  // gathers use 32-bit byte offsets into 16-byte records (device.h nb_ld): 2^28 particles of one kind is the ceiling
+  if (p->n_liquid >= (1 << 28) || p->n_solid >= (1 << 28)) return ctx->fail(WCSPH_EARG, "at most 2^28 - 1 liquid and 2^28 - 1 boundary particles per context");
   if (p->tension_fixed != 1 && (p->tension_coff != 0.0f))
     return ctx->fail(WCSPH_EARG, "tension_fixed=0 (literal Q8 normals) is order dependent in the reference and not implemented");
   HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
