@@ -26,6 +26,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["achieved"] > 0
+    assert rf["launches_timed"] >= 2 * d["steps"] and rf["avg_launch_us"] > 0       # in-situ events: >= 2 pressure iterations per step
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 0 and abs(d["ms_per_step"] - d["config"]["n_liquid"] / d["value"] / 1e3) / d["ms_per_step"] < 0.02
