@@ -43,54 +43,55 @@ class Canvas:
         self.fps = 30.0
         self.out_dir = "."
 
-    # ---- camera: ref Canvas.py:38-122, unchanged arithmetic (python doubles, stored as f32) ---------------------
+    # ---- camera (ref: Canvas.py:38-122; same numbers, python doubles stored as float32) -------------------------
+    def _aim(self, target, fov, ortho):
+        self.fov, self.ortho = fov, ortho
+        self.target[:] = target
+
     def yaw_cam(self, targetx, targety, targetz):
-        self.fov = 1.0
-        self.ortho = 0
-        self.target[:] = (targetx, targety, targetz)
+        """perspective orbit about the vertical axis, 0.003 rad per call up to half a turn"""
+        self._aim((targetx, targety, targetz), 1.0, 0)
         if self.yaw < 3.14:
             self.set_view_point(self.yaw + 0.003, 0.0, 0.0, 3.0)
 
     def pitch_cam(self, targetx, targety, targetz):
-        self.fov = 1.0
-        self.ortho = 0
-        self.target[:] = (targetx, targety, targetz)
+        """perspective tilt, 0.003 rad per call up to 0.5 rad"""
+        self._aim((targetx, targety, targetz), 1.0, 0)
         if self.pitch < 0.5:
             self.set_view_point(0.0, self.pitch + 0.003, 0.0, 3.0)
 
     def static_cam(self, targetx, targety, targetz):
-        self.fov = 2.0
-        self.ortho = 1
-        self.target[:] = (targetx, targety, targetz)
+        """orthographic front view from distance 3 (the camera dfsph.py:604 uses)"""
+        self._aim((targetx, targety, targetz), 2.0, 1)
         self.set_view_point(0.0, 0.0, 0.0, 3.0)
 
     def update_cam(self):
-        self.pitch = max(min(self.pitch, 1.57), -1.57)
-        self.eye[0] = self.target[0] + self.scale * math.cos(self.pitch) * math.sin(self.yaw)
-        self.eye[1] = self.target[1] + self.scale * math.sin(self.pitch)
-        self.eye[2] = self.target[2] + self.scale * math.cos(self.pitch) * math.cos(self.yaw)
-        self.up[0] = -math.sin(self.pitch) * math.sin(self.yaw)
-        self.up[1] = math.cos(self.pitch)
-        self.up[2] = -math.sin(self.pitch) * math.cos(self.yaw)
-        zaxis = self.eye - self.target
-        zaxis = zaxis / np.linalg.norm(zaxis)
-        xaxis = np.cross(self.up, zaxis)
-        xaxis = xaxis / np.linalg.norm(xaxis)
-        yaxis = np.cross(zaxis, xaxis)
-        yScale = 1.0 / math.tan(self.fov / 2.0)
-        xScale = yScale / self.ratio
-        self.view = np.array([[xaxis[0], xaxis[1], xaxis[2], -np.dot(xaxis, self.eye)],
-                              [yaxis[0], yaxis[1], yaxis[2], -np.dot(yaxis, self.eye)],
-                              [zaxis[0], zaxis[1], zaxis[2], -np.dot(zaxis, self.eye)],
-                              [0.0, 0.0, 0.0, 1.0]], dtype=np.float32)
+        self.pitch = float(np.clip(self.pitch, -1.57, 1.57))
+        cp, sp, cy, sy = math.cos(self.pitch), math.sin(self.pitch), math.cos(self.yaw), math.sin(self.yaw)
+        self.eye[:] = self.target + self.scale * np.array([cp * sy, sp, cp * cy])
+        self.up[:] = (-sp * sy, cp, -sp * cy)
+        # right-handed look-at: rows are the camera axes, the last column moves the eye to the origin
+        back = self.eye - self.target
+        back /= np.linalg.norm(back)
+        right = np.cross(self.up, back)
+        right /= np.linalg.norm(right)
+        axes = np.stack([right, np.cross(back, right), back])
+        view = np.eye(4)
+        view[:3, :3] = axes
+        view[:3, 3] = -axes @ self.eye
+        self.view = view.astype(np.float32)
+        ys = 1.0 / math.tan(self.fov / 2.0)
         n, f = self.near, self.far
+        proj = np.zeros((4, 4))
+        proj[0, 0], proj[1, 1] = ys / self.ratio, ys
         if self.ortho == 0:
-            self.proj = np.array([[xScale, 0, 0, 0], [0, yScale, 0, 0], [0, 0, f / (n - f), n * f / (n - f)], [0, 0, -1.0, 0]], dtype=np.float32)
+            proj[2, 2], proj[2, 3], proj[3, 2] = f / (n - f), n * f / (n - f), -1.0
         else:
-            self.proj = np.array([[xScale, 0, 0, 0], [0, yScale, 0, 0], [0, 0, 1.0 / (n - f), n / (n - f)], [0, 0, 0, 1.0]], dtype=np.float32)
+            proj[2, 2], proj[2, 3], proj[3, 3] = 1.0 / (n - f), n / (n - f), 1.0
+        self.proj = proj.astype(np.float32)
 
     def set_view_point(self, yaw, pitch, roll, scale):
-        self.pitch, self.yaw, self.roll, self.scale = pitch, yaw, roll, scale
+        self.yaw, self.pitch, self.roll, self.scale = yaw, pitch, roll, scale
         self.update_cam()
 
     def set_fov(self, fov):

@@ -1,21 +1,14 @@
-import math
-
-import numpy as np
+from ._akinci import F, RadialSpline, adhesion_constant, np
 
 
-class AdhesionKernel:
-    """ref: kernels/AdhesionKernel.py:12-33 (Akinci 2013 adhesion spline)."""
+class AdhesionKernel(RadialSpline):
+    """ref: kernels/AdhesionKernel.py:12-33.  Non-zero only on the outer half of the support:
+    m_k (-4 r^2 / h + 6 r - 2 h)^(1/4); the radicand is clamped at 0 (it is -1e-9 at r = h in float32)."""
 
     def __init__(self, searchR):
-        self.searchR = searchR
-        self.m_k = 0.007 / math.pow(searchR, 3.25)
+        super().__init__(searchR)
+        self.m_k = adhesion_constant(searchR)
 
-    def Cubic_W_norm(self, r):
-        r = np.asarray(r, dtype=np.float32)
-        h = np.float32(self.searchR)
-        with np.errstate(invalid="ignore"):
-            v = np.float32(self.m_k) * np.power(np.maximum(-4.0 * r * r / h + 6.0 * r - 2.0 * h, 0.0), 0.25)
-        return np.where((r * r <= h * h) & (r > 0.5 * h), v, np.float32(0.0)).astype(np.float32)
-
-    def Cubic_W(self, r_vec):
-        return self.Cubic_W_norm(np.linalg.norm(np.asarray(r_vec, np.float32), axis=-1))
+    def profile(self, dist, h):
+        radicand = np.maximum(F(-4.0) * dist * dist / h + F(6.0) * dist - F(2.0) * h, F(0.0))
+        return np.where(dist > F(0.5) * h, F(self.m_k) * np.power(radicand, F(0.25)), F(0.0))
