@@ -52,7 +52,7 @@ typedef struct wcsph_params {
   int32_t max_neighbour;     /* 2048 (ParticleData.py:27) */
   int32_t hash_table_size;   /* 0 => n_liquid + n_solid (HashGrid.py:114); slabs pass the global count */
   int32_t tension_fixed;     /* 0 literal Q8/Q9 loop is NOT reproducible; only 1 (fixed normals) is implemented */
-  int32_t list_cap;          /* entries per particle of the compact lists; 0 => 128.  pcisph needs the reference's 2048 */
+  int32_t list_cap;          /* entries per particle of the compact lists; 0 => 256 slots.  pcisph needs the reference's 2048 */
   double particle_radius;    /* what the script passes to ParticleData(): radius (dfsph) or diameter (sesph, Q11) */
   double cfl_radius;         /* dfsph.py:27 particleRadius used by optimize_time_step */
   double user_max_t, user_min_t; /* dfsph.py:39-40 */

@@ -1,0 +1,130 @@
+"""BASELINE.json configurations at their OWN sizes against the oracle (one full DFSPH step from rest, every field), plus
+the adhesion branch of compute_tension on a scene where its gate (ref: dfsph.py:300-302) actually opens.
+
+C2 = 46^3, C3 = 126^3 (the headline config; the oracle's 8 KiB/particle neighbour table needs ~17 GB of host memory),
+C5 = 100^3 with the Akinci tension passes on and the reference's adhesion ball (scene.dam_break_with_ball) inside the
+liquid.  C4 (16 M particles over 8 GPUs) cannot run on a one-GPU test box."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        return 0.0
+
+
+def _one_step(n, mode, need_gb, liquid=None, boundary=None, steps=1, **attrs):
+    if _host_gb() < need_gb:
+        pytest.skip("oracle needs ~%d GB of free host memory for this size" % need_gb)
+    from oracle import Oracle
+    from wcsph_amd import dfsph
+    pd = dfsph.init_particle(particleDim=n, neighbor_mode=mode, liquid=liquid, boundary=boundary, **attrs)
+    nl = pd.liquid_count
+    o = Oracle(pd.pos.to_numpy(), nl, 0.025, mode=mode)
+    for k in ("tension_coff", "tension_coff_b", "tension_fixed"):
+        if k in attrs:
+            setattr(o, k, attrs[k])
+    dfsph.reset_param(); o.reset_param()
+    for _ in range(steps):
+        dt = dfsph.step()
+        o.dfsph_step()
+        assert (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter) == (o.vs_iter, o.dv_iter, o.pr_iter)
+        assert abs(dt - o.deltaT) <= 1e-6 * o.deltaT
+        np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)   # exact raw list length
+    rho = pd.rho.to_numpy()
+    assert np.abs(rho - o.rho).max() / o.rho.max() < 1e-4          # north star: per-particle density error <= 1e-4
+    assert np.abs(pd.pos.to_numpy()[:nl] - o.pos[:nl]).max() < 2e-6
+    v = pd.vel.to_numpy()
+    assert np.abs(v - o.vel).max() < 2e-3 * max(np.abs(o.vel).max(), 1e-3)
+    for name, a, b in (("kappa", dfsph.kappa.to_numpy(), o.kappa), ("kappa_v", dfsph.kappa_v.to_numpy(), o.kappa_v)):
+        assert np.abs(a - b).max() <= 2e-3 * max(np.abs(b).max(), 1e-6), name     # DFSPH's "pressure" fields (Q14)
+    return pd, o, dfsph
+
+
+@pytest.mark.parametrize("mode", ["faithful", "clean"])
+def test_C2_100k_first_steps(mode):
+    pd, o, _ = _one_step(46, mode, 3, steps=3)
+    pd.close(); o.close()
+
+
+def test_C3_2M_one_step_faithful():
+    """The headline configuration: 126^3 = 2 000 376 liquid + ~1.0 M boundary particles, faithful neighbour semantics."""
+    pd, o, _ = _one_step(126, "faithful", 24)
+    assert pd.liquid_count == 2000376
+    pd.close(); o.close()
+
+
+def test_C5_1M_tension_one_step():
+    """100^3 lattice minus the adhesion ball's volume, tension_coff = tension_coff_b = 0.05 (the reference ships 0.0 for
+    both); the ball lies inside the 0.26 gate, so the solid branch of compute_tension contributes."""
+    from wcsph_amd import scene
+    liquid, solid = scene.dam_break_with_ball(100)
+    pd, o, _ = _one_step(100, "faithful", 14, liquid=liquid, boundary=solid, tension_coff=0.05, tension_coff_b=0.05, tension_fixed=1)
+    assert abs(pd.liquid_count - 1000000) < 1000
+    pd.close(); o.close()
+
+
+@pytest.mark.parametrize("mode", ["faithful", "clean"])
+@pytest.mark.parametrize("fixed", [1, 0])
+def test_adhesion_branch_runs_and_matches(mode, fixed):
+    """compute_tension on the ball scene, kernel by kernel: the adhesion sum must be non-zero (the gate is open for the
+    ball's 5447 particles and for no box particle) and equal to the oracle's; fixed = 0 is the reference-literal loop
+    (normal scaled by h once per raw list entry, curvature term over every raw liquid entry, ref: dfsph.py:264-305)."""
+    if fixed == 0 and mode == "clean":
+        pytest.skip("the literal loop is defined on the reference's raw bucket lists (faithful mode)")
+    from oracle import Oracle
+    from wcsph_amd import scene
+    from util import GpuSim, rel_err
+    from wcsph_amd.field import ScalarField
+    liquid, solid = scene.dam_break_with_ball(16)
+    rng = np.random.default_rng(7)
+    liquid = liquid + rng.uniform(-0.3, 0.3, liquid.shape) * scene.PARTICLE_RADIUS
+    g = GpuSim(liquid, solid, mode=mode, tension_coff=0.5, tension_coff_b=0.5, tension_fixed=fixed)
+    o = Oracle(g.pd.pos.to_numpy(), len(liquid), 0.025, mode=mode)
+    o.tension_coff, o.tension_coff_b, o.tension_fixed = 0.5, 0.5, fixed
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.call("dfsph_clear_nonpressure"); o.clear_nonpressure()
+    # adhesion alone: gamma = 0 leaves only the solid branch
+    gamma = ScalarField(g.pd, "tension_coff")
+    gamma[0] = 0.0
+    o.tension_coff = 0.0
+    g.call("dfsph_tension"); o.compute_tension()
+    adh_g = g.pd.d_vel.to_numpy() - np.array([0, -9.81, 0], np.float32)
+    adh_o = o.d_vel - np.array([0, -9.81, 0], np.float32)
+    touched = np.abs(adh_o).max(1) > 0
+    assert touched.sum() > 50, "no liquid particle within the adhesion kernel's shell of the ball"
+    assert rel_err(adh_g, adh_o) < 2e-5
+    # both terms
+    gamma[0] = 0.5
+    o.tension_coff = 0.5
+    g.call("dfsph_clear_nonpressure"); o.clear_nonpressure()
+    g.call("dfsph_tension"); o.compute_tension()
+    assert rel_err(g.pd.normal.to_numpy(), o.normal) < 2e-5
+    assert rel_err(g.pd.d_vel.to_numpy(), o.d_vel) < 2e-5
+    g.close(); o.close()
+
+
+def test_nonfinite_state_is_reported():
+    """ref: dfsph.py:645-647 -- the reference's only failure check is a NaN position; the library reports -5 from the
+    solver entry points (a NaN error sum would otherwise read as "converged")."""
+    from wcsph_amd._lib import WcsphError
+    from util import make_pair
+    g, o = make_pair(8, "clean")
+    g.call("dfsph_reset_param")
+    g.call("dfsph_step")
+    v = g.pd.vel.to_numpy()
+    v[17] = np.nan
+    g.pd.vel.from_numpy(v)
+    with pytest.raises(WcsphError) as e:
+        g.call("dfsph_step")
+        g.call("dfsph_step")
+    assert e.value.code == -5
+    # the state stays readable (a sticky flag made every later transfer fail)
+    assert np.isnan(g.pd.vel.to_numpy()[17]).all()
+    g.close(); o.close()

@@ -238,23 +238,3 @@ def test_escaped_particle_has_no_neighbours():
     assert g.pd.hash_grid.neighborCount.to_numpy()[3] == 0 == o.neighborCount[3]
     assert np.abs(g.pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-5
     g.close()
-
-
-def test_lds_tile_path_matches_too(monkeypatch):
-    """The experimental LDS-tile iteration kernels (csrc/tile.h, WCSPH_TILES=1) must give the same step."""
-    monkeypatch.setenv("WCSPH_TILES", "1")
-    from oracle import Oracle
-    from wcsph_amd import dfsph
-    import util
-    liquid, solid = util.small_scene(8, jitter=0.2)
-    pd = dfsph.init_particle(particleDim=8, neighbor_mode="faithful", boundary=solid)
-    pd.pos.from_numpy(np.concatenate([liquid, solid]).astype(np.float32))
-    o = Oracle(pd.pos.to_numpy(), pd.liquid_count, 0.025, mode="faithful")
-    dfsph.reset_param(); o.reset_param()
-    for s in range(3):
-        dfsph.step(); o.dfsph_step()
-        assert (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter) == (o.vs_iter, o.dv_iter, o.pr_iter)
-        assert np.abs(pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-4
-        assert np.abs(pd.pos.to_numpy() - o.pos).max() < 1e-5
-        assert rel_err(pd.vel.to_numpy(), o.vel) < 1e-3
-    pd.close()

@@ -107,8 +107,8 @@ def test_compact_list_capacity_is_an_error_not_silent():
     """a pathological clump: more in-support neighbours than the compact list holds"""
     from wcsph_amd._lib import WcsphError
     rng = np.random.default_rng(0)
-    liquid = np.array([0.0, 0.5, 0.0]) + rng.uniform(-0.02, 0.02, (200, 3))
-    g = GpuSim(liquid, BOX, mode="clean", maxInGrid=256)
+    liquid = np.array([0.0, 0.5, 0.0]) + rng.uniform(-0.02, 0.02, (400, 3))
+    g = GpuSim(liquid, BOX, mode="clean", maxInGrid=512)
     g.pd.hash_grid.update_grid()
     with pytest.raises(WcsphError) as e:
         g.pd.sync()

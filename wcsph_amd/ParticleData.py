@@ -77,6 +77,9 @@ class ParticleData:
         # tension
         self.tension_coff = 0.0
         self.tension_coff_b = 0.0
+        # 1: n_i = h * sum (m/rho_j) gradW, curvature term over the support (the documented repair of Q8);
+        # 0: the reference loop literally (dfsph.py:264-305) over its raw bucket lists -- faithful neighbour mode only
+        self.tension_fixed = 1
 
         # vorticity
         self.viscosity_omega = 0.1
@@ -99,7 +102,7 @@ class ParticleData:
         self.sesph_particle_radius = 0.025
         self.hash_table_size = 0  # 0 => count (HashGrid.py:114)
         self.list_radius = 0.0    # 0 => HashGrid.searchR; sesph.py sets its own (smaller) kernel support
-        self.list_cap = 0         # 0 => 128 entries per particle
+        self.list_cap = 0         # 0 => 256 slots of each kind per particle
         self.ss_VS0_factor = 2.0  # sesph.py:37 / pcisph.py:38 VS0 = 2 VL0 ; iisph.py:37 VS0 = VL0
         self.pci_coff = 0.0       # pcisph.py:299 GetPciCoff()
         self.pc_visc, self.pc_visc_b = 0.05, 0.0              # pcisph.py:68-70
@@ -170,7 +173,7 @@ class ParticleData:
         p.neighbor_mode = _lib.MODE_FAITHFUL if self.neighbor_mode == "faithful" else _lib.MODE_CLEAN
         p.max_in_grid, p.max_neighbour = self.hash_grid.maxInGrid, self.hash_grid.maxNeighbour
         p.hash_table_size = int(self.hash_table_size)
-        p.tension_fixed = 1
+        p.tension_fixed = int(self.tension_fixed)
         p.list_cap = int(self.list_cap)
         p.particle_radius, p.cfl_radius = float(self.particleR), float(self.cfl_radius)
         p.user_max_t, p.user_min_t = float(self.user_max_t), float(self.user_min_t)

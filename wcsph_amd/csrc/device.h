@@ -57,12 +57,7 @@ struct Dev {
   int2 *nhead;                            // x = liquid slots | solid slots << 16, y = sorted solid index the solid stream starts from
   int nbr_stride, nbr_cap;
   float list_r2;                          // squared support radius the lists are built with
-  // LDS tiles (tile.h): active-tile list of the step, tile-local 16-bit neighbour lists
-  int ntx, nty, ntz, ntile;
-  int *tile_list, *tile_qoff, *tile_meta; // [ntile] tile ids / first list slot; meta[0] = active tiles
-  int tile_ablate;                        // experiments: 1 = stage only, 2 = compute only (WCSPH_TILE_ABLATE)
   int *bbox;                              // [6] {xmin,ymin,zmin,xmax,ymax,zmax} of the in-box liquid cells of this step
-  uint16_t *nbr16, *cnt16;                // [nbr_cap][nbr_stride] staged indices, [nl] entries
   // solids, cell-sorted once
   float4 *spos;
   // cell tables
@@ -77,7 +72,7 @@ struct Dev {
 
 enum { ACC_ERR = 0, ACC_DAD = 1, ACC_DNEW = 2, ACC_DZERO = 3 };
 enum { FLAG_ERR = 0, FLAG_VMAX = 1 };
-enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2, ERRBIT_LISTCAP = 4 };
+enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2, ERRBIT_LISTCAP = 4, ERRBIT_NONFINITE = 8 };
 
 __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
 __device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -166,6 +161,7 @@ __device__ __forceinline__ void block_accumulate(double *slot, float v) {
 // total of a striped slot; every thread of the block must call this (blocks of at least one wave)
 __device__ __forceinline__ double acc_total(const double *slot) {
   __shared__ double tot;
+  __syncthreads();   // a kernel may call this twice: every wave must have read the previous total before it is overwritten
   if (threadIdx.x < WAVE) {
     double v = slot[threadIdx.x & (ACC_STRIPES - 1)];
 #pragma unroll

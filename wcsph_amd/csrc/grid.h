@@ -12,11 +12,12 @@ __device__ __forceinline__ int ref_hash(int x, int y, int z, int T) {
 }
 
 // ref: HashGrid.py:68 -- ti.cast((pos - min) * invGridR, i32): f32 sub, f32 mul (no fma), trunc to zero
-__device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin) {
+__device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin, bool *finite = nullptr) {
   float fx = __fmul_rn(__fsub_rn(p.x, d.minx), d.inv_grid);
   float fy = __fmul_rn(__fsub_rn(p.y, d.miny), d.inv_grid);
   float fz = __fmul_rn(__fsub_rn(p.z, d.minz), d.inv_grid);
   bool fin = (fabsf(fx) < 1e9f) && (fabsf(fy) < 1e9f) && (fabsf(fz) < 1e9f);  // NaN/inf => outside
+  if (finite) *finite = (fabsf(fx) <= 3.0e38f) && (fabsf(fy) <= 3.0e38f) && (fabsf(fz) <= 3.0e38f);
   int cx = (int)fx - d.x0, cy = (int)fy, cz = (int)fz;  // truncation toward zero BEFORE the window shift (Q4)
   bool in = fin && (unsigned)cx < (unsigned)d.nx && (unsigned)cy < (unsigned)d.ny && (unsigned)cz < (unsigned)d.nz;
   *lin = in ? (cx * d.ny + cy) * d.nz + cz : d.ncell;
@@ -32,7 +33,10 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
   if (i < n) {
     float4 p = pos[i];
     int lin;
-    int w = cell_packed(d, xyz(p), &lin);
+    bool finite;
+    int w = cell_packed(d, xyz(p), &lin, &finite);
+    // the reference's only failure check is a NaN position (dfsph.py:645-647, one particle); here every particle, every step
+    if (!finite) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NONFINITE);
     pw[i] = w;
     slot[i] = atomicAdd(&cnt[lin], 1);
     if (w >= 0) {

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,15 +15,11 @@
 #include "device.h"
 #include "grid.h"
 #include "dfsph_kernels.h"
-#include "tile.h"
 #include "solver_extra.h"
 #include "surface.h"
 #include "sampler.h"
 #include "mcgrid.h"
 #include "canvas.h"
-#include "ablate.h"
-#define ablate_drho kx_drho
-#define ablate_vel kx_vel
 
 struct wcsph_ctx {
   wcsph_params p;
@@ -37,10 +34,7 @@ struct wcsph_ctx {
   // grid scratch
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
   int *bcount = nullptr, *bcount_s = nullptr, *cellval = nullptr, *celltmp = nullptr;
-  int *tile_p = nullptr, *bbox_part = nullptr;
-  int tile_blocks1 = 1024, tile_blocks2 = 512;  // persistent grids: 4 / 2 workgroups per CU (LDS bound)
-  int tile_ablate_env = 0;
-  bool use_tiles = false;  // LDS-tiled iteration passes (tile.h); experimental, WCSPH_TILES=1
+  int *bbox_part = nullptr;
   int n_alias = 0, scan_blocks = 0;
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats
@@ -116,7 +110,8 @@ static int check_flags(wcsph_ctx *ctx) {
   int f = ctx->h_flags[FLAG_ERR];
   if (f & ERRBIT_BUCKET) return ctx->fail(WCSPH_EBUCKET, "more than maxInGrid particles in one hash bucket (ref: HashGrid.py:72-74)");
   if (f & ERRBIT_NEIGH) return ctx->fail(WCSPH_ENEIGH, "more than maxNeighbour neighbour-list entries (ref: HashGrid.py:100-103)");
-  if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "compact neighbour list capacity (wcsph_params.list_cap, default 128 entries of one kind) exceeded");
+  if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "compact neighbour list capacity (wcsph_params.list_cap, default 256 slots of one kind) exceeded");
+  if (f & ERRBIT_NONFINITE) return ctx->fail(WCSPH_ENONFINITE, "non-finite particle position (ref: dfsph.py:645-647)");
   return 0;
 }
 // copy reduction slots + flags to the host and wait
@@ -151,7 +146,13 @@ static int pull_scalars(wcsph_ctx *ctx) {
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int s = 0; s < 8; s++) ctx->h_acc[s] = m->acc[s];
   for (int s = 0; s < 4; s++) ctx->h_flags[s] = m->flags[s];
-  return check_flags(ctx);
+  int rc = check_flags(ctx);
+  if (rc) return rc;
+  // a NaN error sum makes every `err > tol` test of the reference's host loops false, i.e. "converged" (dfsph.py:141-163)
+  for (int s = 0; s < 8; s++)
+    if (!std::isfinite(ctx->h_acc[s])) return ctx->fail(WCSPH_ENONFINITE, "non-finite reduction result (solver error sum / PCG dot product)");
+  { float vm; memcpy(&vm, &ctx->h_flags[FLAG_VMAX], 4); if (!std::isfinite(vm)) return ctx->fail(WCSPH_ENONFINITE, "non-finite CFL velocity maximum"); }
+  return 0;
 }
 static int zero_acc(wcsph_ctx *ctx, int slot) {
   HIPCHK(hipMemsetAsync(ctx->d.acc + slot * ACC_STRIPES, 0, ACC_STRIPES * sizeof(double), ctx->stream));
@@ -183,9 +184,6 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   memset(&d, 0, sizeof d);
   d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
   ctx->capacity = p->n_liquid;
-  { const char *e = getenv("WCSPH_TILES"); ctx->use_tiles = e && e[0] == '1'; }
-  { const char *e = getenv("WCSPH_TILE_ABLATE"); ctx->tile_ablate_env = e ? atoi(e) : 0; }
-  ctx->d.tile_ablate = ctx->tile_ablate_env;
   d.faithful = (p->neighbor_mode == WCSPH_MODE_FAITHFUL);
   d.table_size = p->hash_table_size > 0 ? p->hash_table_size : (p->n_liquid + p->n_solid);
   if (d.table_size < 1) d.table_size = 1;
@@ -222,12 +220,11 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.d_vel_pre, nl); DALLOC(d.pos_star, nl); DALLOC(d.vel_star, nl); DALLOC(d.d_ii, nl); DALLOC(d.dij_pj, nl);
   DALLOC(d.a_ii, nl); DALLOC(d.pressure_pre, nl);
   d.nbr_stride = (int)((nl + 63) / 64 * 64);
-  d.nbr_cap = p->list_cap > 0 ? p->list_cap : 128;
+  d.nbr_cap = p->list_cap > 0 ? p->list_cap : 256;
   if (d.nbr_cap > p->max_neighbour) d.nbr_cap = p->max_neighbour;
   d.nbr_cap = (d.nbr_cap + 7) & ~7;
   if (d.nbr_cap < 1) d.nbr_cap = 1;
   DALLOC(d.nbl, (size_t)d.nbr_stride * (d.nbr_cap / 8)); DALLOC(d.nbs, (size_t)d.nbr_stride * (d.nbr_cap / 8));
-  if (ctx->use_tiles) { DALLOC(d.nbr16, (size_t)d.nbr_stride * d.nbr_cap); DALLOC(d.cnt16, nl); }
   DALLOC(d.spos, (size_t)d.ns);
   DALLOC(d.acc, 8 * ACC_STRIPES); DALLOC(d.flags, 4 + ACC_STRIPES);   // [4..]: striped vmax
   size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
@@ -268,8 +265,7 @@ int wcsph_sync(wcsph_ctx *ctx) {
 static int run_scan(wcsph_ctx *ctx, int *in, int n, int *out, const int *bbox, int clear = 0) {
   int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   const int col = ctx->d.ny * ctx->d.nz;
-  // y-row skipping only with the list path: the experimental LDS tiles read whole tile rows of the cell table
-  const int nz = (bbox && !ctx->use_tiles) ? ctx->d.nz : 0;
+  const int nz = bbox ? ctx->d.nz : 0;
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, bbox, col, nz);
   hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->bsum, nb);
   hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out, bbox, col, clear, nz);
@@ -302,14 +298,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   ctx->scan_blocks = (nscan + SCAN_TILE - 1) / SCAN_TILE;
   DALLOC(ctx->cnt, nscan); DALLOC(d.cs_l, nscan); DALLOC(d.cs_s, nscan); DALLOC(ctx->bsum, ctx->scan_blocks + 1);
   DALLOC(d.cell_info, d.ncell);
-  d.ntx = (d.nx + TILE_X - 1) / TILE_X; d.nty = (d.ny + TILE_Y - 1) / TILE_Y; d.ntz = (d.nz + TILE_Z - 1) / TILE_Z;
-  d.ntile = d.ntx * d.nty * d.ntz;
-  DALLOC(d.tile_list, d.ntile); DALLOC(d.tile_qoff, d.ntile); DALLOC(d.tile_meta, 8); DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1)); DALLOC(ctx->tile_p, d.ntile);
-  {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    ctx->tile_blocks1 = ((cus * 4 + 7) / 8) * 8; ctx->tile_blocks2 = ((cus * 2 + 7) / 8) * 8;  // 37 / 74 KB LDS per workgroup
-  }
+  DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1));
   if (d.faithful) {
     DALLOC(ctx->bcount, d.table_size); DALLOC(ctx->bcount_s, d.table_size);
     DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->celltmp, d.ncell);
@@ -385,6 +374,9 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   const int nscan = d.ncell + 2;
   hipStream_t s = ctx->stream;
   // ctx->cnt is all zero here: k_scan_final clears the counters it consumes
+  // overflow / non-finite conditions are re-detected by every update: what the previous one raised has been reported by
+  // the pull_scalars() calls of its step and must not stick to the context (the reference prints and keeps stepping)
+  HIPCHK(hipMemsetAsync(d.flags + FLAG_ERR, 0, sizeof(int), s));
   if (d.faithful) HIPCHK(hipMemcpyAsync(ctx->bcount, ctx->bcount_s, (size_t)d.table_size * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
@@ -417,11 +409,6 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   }
   if (d.nl > 0) {
     hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
-    if (ctx->use_tiles) {
-      hipLaunchKernelGGL(k_tile_count, dim3(nblk(d.ntile)), dim3(BLOCK), 0, s, d, ctx->tile_p);
-      hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, d, (const int *)ctx->tile_p);
-      hipLaunchKernelGGL(kt_build_lists, dim3(ctx->tile_blocks1), dim3(TBLOCK), 0, s, d);
-    }
   }
   LAUNCHCHK();
   ctx->grid_valid = true;
@@ -504,10 +491,9 @@ int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(dst, ctx->stage, (size_t)nl * per * 4, hipMemcpyDeviceToHost, s));
   }
-  HIPCHK(hipMemcpyAsync(ctx->h_flags, d.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (field == WCSPH_F_POS && d.ns > 0) memcpy((float *)dst + (size_t)nl * 3, ctx->solid_host.data(), (size_t)d.ns * 12);
-  return check_flags(ctx);
+  return WCSPH_OK;   // a transfer never fails on the overflow flags: wcsph_sync() and the solver entry points report them
 }
 
 int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes) {
@@ -617,30 +603,14 @@ int wcsph_set_iters(wcsph_ctx *ctx, int32_t vs, int32_t dv, int32_t pr) {
     LAUNCHCHK();                                                                                  \
   } while (0)
 
-#define TPASS1(kern, ...)                                                                         \
-  do {                                                                                            \
-    if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(ctx->tile_blocks1), dim3(TBLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
-    LAUNCHCHK();                                                                                  \
-  } while (0)
-#define TPASS2(kern, ...)                                                                         \
-  do {                                                                                            \
-    if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(ctx->tile_blocks2), dim3(TBLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
-    LAUNCHCHK();                                                                                  \
-  } while (0)
-
-#define HOT_DRHO_DIV(mode, dtv)                                                                   \
-  do { if (ctx->use_tiles) TPASS2((kt_drho<mode, 1>), dtv); else PASS(k_drho_div<mode>, dtv); } while (0)
-#define HOT_DRHO_PRESS(mode, dtv)                                                                 \
-  do { if (ctx->use_tiles) TPASS2((kt_drho<mode, 0>), dtv); else PASS(k_drho_press<mode>, dtv); } while (0)
+#define HOT_DRHO_DIV(mode, dtv) PASS(k_drho_div<mode>, dtv)
+#define HOT_DRHO_PRESS(mode, dtv) PASS(k_drho_press<mode>, dtv)
 /* pack != 0: rebuild the (pos, k) gather records first (k from another array, or ghosts refreshed by a halo
  * exchange since k_make_k wrote them) */
 #define HOT_VEL(cond, kbp, dtv, pack)                                                             \
   do {                                                                                            \
-    if (ctx->use_tiles) TPASS1(kt_vel_from_k<cond>, (const float *)(kbp), dtv);                   \
-    else {                                                                                        \
-      if (pack) ELEM(k_pack_k, (const float *)(kbp));                                             \
-      PASS(k_vel_from_k<cond>, (const float4 *)ctx->d.pk, dtv);                                   \
-    }                                                                                             \
+    if (pack) ELEM(k_pack_k, (const float *)(kbp));                                               \
+    PASS(k_vel_from_k<cond>, (const float4 *)ctx->d.pk, dtv);                                     \
   } while (0)
 
 int wcsph_dfsph_reset_param(wcsph_ctx *ctx) {
@@ -679,13 +649,13 @@ static int pressure_iter_async(wcsph_ctx *ctx) {
 }
 // fused-loop variants: k_i comes from the previous drho launch's epilogue (FUSEK), kappa += k_i in the vel launch
 static int divergence_iter_fused(wcsph_ctx *ctx) {
-  if (ctx->use_tiles || ctx->d.n_owned < ctx->d.nl) return divergence_iter_async(ctx);
+  if (ctx->d.n_owned < ctx->d.nl) return divergence_iter_async(ctx);
   PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v);   // also clears ACC_ERR
   PASS((k_drho_div<DRHO_ITER, true>), ctx->dt);
   return 0;
 }
 static int pressure_iter_fused(wcsph_ctx *ctx) {
-  if (ctx->use_tiles || ctx->d.n_owned < ctx->d.nl) return pressure_iter_async(ctx);
+  if (ctx->d.n_owned < ctx->d.nl) return pressure_iter_async(ctx);
   const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
   if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
   PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);     // also clears ACC_ERR
@@ -866,7 +836,7 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
     HOT_VEL(1, ctx->d.kappa_v, ctx->dt, 0);
   } else if ((rc = wcsph_dfsph_warmstart_divergence(ctx))) return rc;
   double err = -0.1;
-  const bool fusek = !ctx->use_tiles && ctx->d.n_owned == ctx->d.nl;
+  const bool fusek = ctx->d.n_owned == ctx->d.nl;
   if (fusek) PASS((k_drho_div<DRHO_BEGIN, true>), ctx->dt);
   else if ((rc = wcsph_dfsph_begin_divergence(ctx))) return rc;
   const float dt = ctx->dt;
@@ -885,7 +855,7 @@ int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
   if ((rc = wcsph_dfsph_warmstart_pressure(ctx))) return rc;
   ctx->pr_iter = 0;
   double err = 0.0;
-  const bool fusek = !ctx->use_tiles && ctx->d.n_owned == ctx->d.nl;
+  const bool fusek = ctx->d.n_owned == ctx->d.nl;
   if (fusek) PASS((k_drho_press<DRHO_BEGIN, true>), ctx->dt);
   else if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
   while (ctx->fix_pr > 0 ? ctx->pr_iter < ctx->fix_pr : ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100)) {
@@ -904,7 +874,7 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   NEED_SETUP();
   int rc;
   if ((rc = wcsph_grid_update(ctx))) return rc;
-  if (!ctx->use_tiles && ctx->d.n_owned == ctx->d.nl) {
+  if (ctx->d.n_owned == ctx->d.nl) {
     PASS(k_density_coff_warm, ctx->dt);  // compute_density + compute_dfsph_coff + first warm-start pass in one walk
     ctx->warm_fused = true;
   } else PASS(k_density_coff);           // compute_density + compute_dfsph_coff in one walk
@@ -1409,7 +1379,7 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
   const float dt = ctx->dt;
   switch (ph) {
     case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); break;
-    case WCSPH_PH_DENSITY_COFF_WARM: if (ctx->use_tiles) { PASS(k_density_coff); HOT_DRHO_DIV(DRHO_WARM, dt); } else PASS(k_density_coff_warm, dt); break;
+    case WCSPH_PH_DENSITY_COFF_WARM: PASS(k_density_coff_warm, dt); break;
     case WCSPH_PH_VISC_MINV_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual, dt); break;
     case WCSPH_PH_VISC_MINV_RESIDUAL_VORT: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual_vort, dt); break;
     case WCSPH_PH_DRHO_DIV_WARM: HOT_DRHO_DIV(DRHO_WARM, dt); break;
@@ -1580,20 +1550,6 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; PASS(k_visc_minv_residual, ctx->dt); return 0; }
     if (nm == "build_lists") { PASS(k_build_lists, 1); return 0; }
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
-#define ABLATE_CASE(kern, n) if (nm == #kern ":" #n) { PASS(kern<n>, ctx->dt); return 0; }
-    ABLATE_CASE(ablate_drho, 0) ABLATE_CASE(ablate_drho, 1) ABLATE_CASE(ablate_drho, 2) ABLATE_CASE(ablate_drho, 3) ABLATE_CASE(ablate_drho, 4) ABLATE_CASE(ablate_drho, 5) ABLATE_CASE(ablate_drho, 6) ABLATE_CASE(ablate_drho, 7) ABLATE_CASE(ablate_drho, 8) ABLATE_CASE(ablate_drho, 9) ABLATE_CASE(ablate_drho, 10) ABLATE_CASE(ablate_drho, 11) ABLATE_CASE(ablate_drho, 12)
-    ABLATE_CASE(ablate_vel, 0) ABLATE_CASE(ablate_vel, 1) ABLATE_CASE(ablate_vel, 2) ABLATE_CASE(ablate_vel, 3)
-    if (nm.rfind("blocked:", 0) == 0) {   // vel then drho slab by slab: do the second pass's list reads hit the Infinity Cache?
-      const int S = std::max(1, atoi(nm.c_str() + 8)), nl = ctx->d.nl, per = (nl + S - 1) / S;
-      for (int s0 = 0; s0 < S; s0++) {
-        const int i0 = s0 * per, n = std::min(per, nl - i0);
-        if (n <= 0) break;
-        hipLaunchKernelGGL(kx_vel<0>, dim3(nblk8(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->dt, i0, n);
-        hipLaunchKernelGGL(kx_drho<0>, dim3(nblk8(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->dt, i0, n);
-      }
-      LAUNCHCHK();
-      return 0;
-    }
     return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");
   };
   if (nm == "pressure_iter" && (rc = pressure_iter_async(ctx))) return rc;      // primes the (pos, k) records

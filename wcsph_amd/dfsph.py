@@ -58,9 +58,10 @@ def _call(name):
     _lib.check(ctx, getattr(_lib.load(), name)(ctx))
 
 
-def init_particle(filename=None, particleDim=None, neighbor_mode="faithful", boundary=None, maxNeighbour=2048, **attrs):
+def init_particle(filename=None, particleDim=None, neighbor_mode="faithful", boundary=None, maxNeighbour=2048, liquid=None, **attrs):
     """ref: dfsph.py:59-82.  filename: OBJ point cloud of boundary particles (`v x y z` lines) as in the
     reference; None generates the equivalent box shell (scene.box_shell).  particleDim scales the scene.
+    liquid: explicit liquid positions instead of the particleDim^3 lattice (scene.dam_break_with_ball).
     attrs: ParticleData attributes set before the device setup (e.g. tension_coff=0.05; the reference edits them in
     ParticleData.py:61-87)."""
     global particle_data, kernel_c, kernel_adh, kernel_coh, deltaT, alpha_coff, kappa, kappa_v
@@ -79,7 +80,10 @@ def init_particle(filename=None, particleDim=None, neighbor_mode="faithful", bou
         if not hasattr(particle_data, k):
             raise AttributeError("ParticleData has no attribute %r" % k)
         setattr(particle_data, k, v)
-    particle_data.add_liquid_points(scene.dam_break_liquid(particleDimX, particleDimY, particleDimZ, particleRadius))
+    if liquid is None:
+        liquid = scene.dam_break_liquid(particleDimX, particleDimY, particleDimZ, particleRadius)
+    particleLiquidNum = len(liquid)
+    particle_data.add_liquid_points(liquid)
 
     kernel_c = CubicKernel(particle_data.hash_grid.searchR)
     kernel_adh = AdhesionKernel(particle_data.hash_grid.searchR)

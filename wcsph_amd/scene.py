@@ -72,5 +72,27 @@ def sesph_scene(particleRadius=PARTICLE_RADIUS, dim=20, boundary=2.0):
     return liquid, solid
 
 
+ADHESION_CENTRE = (0.0, 0.5, 0.0)   # ref: dfsph.py:300 -- the only boundary particles the adhesion term acts on lie
+ADHESION_GATE = 0.26                #                      within 0.26 of this point ("the box particle are not included")
+
+
+def sphere_shell(centre=ADHESION_CENTRE, radius=0.25, n_points=5447):
+    """Fibonacci lattice on a sphere.  Defaults: the ball of the reference's model/sphere_boundry.obj scene (5447 of its
+    points lie on a sphere of radius 0.25 about (0, 0.5, 0), exactly the set dfsph.py:300-302 gates the adhesion to)."""
+    k = np.arange(n_points, dtype=np.float64) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / n_points)
+    theta = np.pi * (1.0 + 5.0 ** 0.5) * k
+    d = np.stack([np.cos(theta) * np.sin(phi), np.cos(phi), np.sin(theta) * np.sin(phi)], 1)
+    return np.asarray(centre, np.float64) + radius * d
+
+
+def dam_break_with_ball(n, particleRadius=PARTICLE_RADIUS, pitch=BOUNDARY_PITCH, radius=0.25):
+    """The scaled dam break with the adhesion ball of the reference's sphere scene inside the liquid column: lattice
+    particles closer than R to the ball's surface or inside it are left out.  (liquid, solid) float64."""
+    liquid, shell = dam_break_dfsph(n, particleRadius, pitch)
+    d = np.linalg.norm(liquid - np.asarray(ADHESION_CENTRE), axis=1)
+    return liquid[d > radius + particleRadius], np.concatenate([shell, sphere_shell(radius=radius)], 0)
+
+
 # BASELINE.json configs -> particleDim of the DFSPH dam break (SURVEY 8(d) table)
 CONFIGS = {"C2": 46, "C3": 126, "C4": 252, "C5": 100, "default": 20}
