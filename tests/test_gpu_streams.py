@@ -1,5 +1,5 @@
 """The 16-bit delta neighbour streams (csrc/device.h "neighbour streams"): decoded, they are exactly the in-support part
-of the reference's list -- also where the jump to another x-plane does not fit 16 bits and hop slots bridge it."""
+of the reference's list -- also where the jump to the next outer tile plane does not fit 16 bits and hop slots bridge it."""
 import numpy as np
 import pytest
 
@@ -39,15 +39,15 @@ def test_streams_decode_to_in_support_list(mode):
     g.close()
 
 
-def slab_scene(nx=4, n=184, wall_layers=2):
-    """nx x n x n liquid lattice (pitch 2R) against an n x n wall: every x-plane holds n^2 = 33 856 particles, so
-    the step from one plane's entries to the next (and the first step from i to plane x-2) exceeds 32 767."""
-    ax = (np.arange(n, dtype=np.float32) + 0.5) * np.float32(2 * R)
-    xs = (np.arange(nx, dtype=np.float32) + 0.5) * np.float32(2 * R)
-    X, Y, Z = np.meshgrid(xs, ax, ax, indexing="ij")
+def slab_scene(nx=20, ny=20, nz=1000, wall_layers=2):
+    """nx x ny x nz liquid lattice (pitch 2R) against a wall: cells are sorted in tiles of 2 x 4 x 16 with the longer of
+    x / y as the outer axis, so one outer tile plane holds 2 * 20 * 1000 = 40 000 particles and the step from a
+    particle to its neighbours in the next plane exceeds the 32 767 a 16-bit delta can hold."""
+    ax = lambda n: (np.arange(n, dtype=np.float32) + 0.5) * np.float32(2 * R)   # noqa: E731
+    X, Y, Z = np.meshgrid(ax(nx), ax(ny), ax(nz), indexing="ij")
     liquid = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
     xw = -(np.arange(wall_layers, dtype=np.float32) + 0.5) * np.float32(2 * R)
-    X, Y, Z = np.meshgrid(xw, ax, ax, indexing="ij")
+    X, Y, Z = np.meshgrid(xw, ax(ny), ax(nz), indexing="ij")
     solid = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
     return liquid, solid
 

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwcsph_hip.so")
+LIB_PATH = os.environ.get("WCSPH_LIB") or os.path.join(_HERE, "libwcsph_hip.so")   # WCSPH_LIB: development builds (tools/)
 
 MODE_FAITHFUL, MODE_CLEAN = 0, 1
 

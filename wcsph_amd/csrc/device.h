@@ -4,8 +4,9 @@
 // SoA arrays; vec3 fields are float4-padded so that one neighbour gather is a single
 // 16-byte load.  pos.w carries the particle's packed cell (cx | cy<<10 | cz<<20, -1 when the
 // particle is outside the grid box, ref: HashGrid.py:68-69,117-124).  Static solids are
-// sorted once.  Cells are linearised z-fastest so that the 5 cells of one (dx,dy) row of
-// the 5x5x5 walk (ref: HashGrid.py:82-85) are ONE contiguous particle range.
+// sorted once.  Cells are linearised in TILES of 2 x 4 x 16 cells (outer x middle x z, see cell_lin): 64 consecutive
+// particles are a compact brick instead of a 64-cell column segment, and the <= 5 cells of one (dx,dy) row of the
+// 5x5x5 walk (ref: HashGrid.py:82-85) are at most TWO contiguous particle ranges.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,7 +18,10 @@
 struct Dev {
   // counts
   int nl, ns, n_owned;
-  int nx, ny, nz, ncell;
+  int nx, ny, nz, ncell;   // ncell = nx*ny*nz: plain (x,y,z) linearisation, used only by the faithful box filter
+  // tile order (cell_lin): perm = 0: x outer, y middle; 1: y outer, x middle (the longer of the two is outer, so that
+  // the particles between two neighbouring outer tile planes -- the largest delta of a neighbour stream -- are few)
+  int perm, nt0, nt1, nt2, ncell_p;   // tiles per axis, padded cell count (= index of the out-of-box bin)
   int x0;          // first global cell column of this context's window (slab decomposition); 0 otherwise
   // slab halo/compute overlap: 0 = every owned particle; 1 = only those in global cell columns [part_x0, part_x1)
   // (the interior: no ghost within their 5^3 cells); 2 = only the others (see part_ok)
@@ -61,9 +65,9 @@ struct Dev {
   // solids, cell-sorted once
   float4 *spos;
   // cell tables
-  int *cs_l;          // [ncell+2] liquid cell start (ncell = out-of-box bin)
-  int *cs_s;          // [ncell+1] solid cell start
-  int *cell_info;     // [ncell] bit0: solids within the 5^3 walk; bits1..: alias slot + 1
+  int *cs_l;          // [ncell_p+2] liquid cell start in tile order (ncell_p = out-of-box bin)
+  int *cs_s;          // [ncell_p+2] solid cell start
+  int *cell_info;     // [ncell_p] bit0: solids within the 5^3 walk; bits1..: alias slot + 1
   uint16_t *alias;    // [n_alias][ALIAS_STRIDE]
   // reductions
   double *acc;        // [8 slots][ACC_STRIPES]
@@ -106,6 +110,37 @@ __device__ __forceinline__ float cubic_gradW_scale(const Dev &d, float r2) {
   float s = (q <= 0.5f) ? q * (3.0f * q - 2.0f) : -(f * f);
   float g = s * d.ml_h3 * inv_rl * d.inv_h;
   return (rl > 1.0e-5f && q <= 1.0f) ? g : 0.0f;
+}
+
+// ---- tile-ordered cell index ----------------------------------------------------------------------------
+#ifndef T0B      /* -DT0B=0 -DT1B=0 -DT2B=3 gives the plain z-fastest order (tools/state_bench.py compares shapes) */
+#define T0B 1   /* outer axis: 2 cells per tile  */
+#define T1B 2   /* middle axis: 4 cells per tile */
+#define T2B 4   /* z: 16 cells per tile (row_pieces relies on >= 5 cells: a walked row touches at most two tiles) */
+#endif
+#define TILE_SHIFT (T0B + T1B + T2B)
+// index of the first cell (z = 0 of tile row 0) of the z-row through (cx, cy): cell (cx, cy, cz) = row + (cz >> 3) * 64 + (cz & 7)
+__device__ __forceinline__ int cell_row(const Dev &d, int cx, int cy) {
+  const int a0 = d.perm ? cy : cx, a1 = d.perm ? cx : cy;
+  return ((((a0 >> T0B) * d.nt1 + (a1 >> T1B)) * d.nt2) << TILE_SHIFT) | ((a0 & ((1 << T0B) - 1)) << (T1B + T2B)) | ((a1 & ((1 << T1B) - 1)) << T2B);
+}
+__device__ __forceinline__ int cell_lin(const Dev &d, int cx, int cy, int cz) {
+  return cell_row(d, cx, cy) + ((cz >> T2B) << TILE_SHIFT) + (cz & ((1 << T2B) - 1));
+}
+// particle ranges of the cells (x, y, z0 .. z1-1), 0 < z1 - z0 <= 8: a z-run of up to 8 cells touches at most two tiles
+struct RowPieces { int lo0, hi0, lo1, hi1; };
+__device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int x, int y, int z0, int z1) {
+  const int rb = cell_row(d, x, y);
+  const int tA = z0 >> T2B, tB = (z1 - 1) >> T2B;
+  const int bA = rb + (tA << TILE_SHIFT);
+  RowPieces r;
+  r.lo0 = CS[bA + (z0 & ((1 << T2B) - 1))];
+  r.hi0 = CS[bA + min(z1 - (tA << T2B), 1 << T2B)];   // [.. + 8] is the next row of the tile (or the next tile): the end of cell z = 7
+  // branch free: when the run stays in one tile the second piece reads the same entry twice (an empty range)
+  const int bB = rb + (tB << TILE_SHIFT);
+  r.lo1 = CS[bB];
+  r.hi1 = CS[bB + (tB > tA ? z1 - (tB << T2B) : 0)];
+  return r;
 }
 
 // which owned particles a neighbour pass computes in this launch (Dev::part_mode); particles outside the grid box
@@ -183,7 +218,7 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
   if (cw < 0) return;  // outside the grid box: no neighbours (ref: HashGrid.py:80-81, Q4)
   const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
   const float3 xi = xyz(pi);
-  const int info = d.cell_info[(cx * d.ny + cy) * d.nz + cz];
+  const int info = d.cell_info[cell_lin(d, cx, cy, cz)];
   // Row trimming: a row (dx, dy) of the 5x5 columns is walked only over the z-cells the support sphere can reach.
   // Distances in cell units from the particle to the nearest face of the column; rm = list radius + a margin
   // for the rounding of the cell assignment.  Purely a candidate filter: the r2 <= list_r2 test below decides.
@@ -200,28 +235,34 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
     zb = min(min((int)floorf(fz + zr), cz + 2), d.nz - 1) + 1;
     return zb > za;
   };
-  // per x-plane: the five rows' cell-table lookups are issued together, then the rows are scanned
+  // The walk goes plane by plane along the OUTER axis of the tile order (x, or y when perm = 1), then row by row along
+  // the middle axis: indices grow almost monotonically, so the deltas of the neighbour streams stay small.  Per outer
+  // plane the cell-table lookups of its five rows (two pieces each, row_pieces) are issued together, then scanned.
+  const int c0 = d.perm ? cy : cx, c1 = d.perm ? cx : cy, n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
 #define WALK_PLANE(CS, POS, SELF, CALL)                                                            \
-  _Pragma("unroll 1") for (int dx = -2; dx <= 2; dx++) {                                          \
-    const int x = cx + dx;                                                                        \
-    if ((unsigned)x >= (unsigned)d.nx) continue;                                                  \
-    int lo[5], hi[5];                                                                             \
+  _Pragma("unroll 1") for (int e0 = -2; e0 <= 2; e0++) {                                          \
+    const int a0 = c0 + e0;                                                                       \
+    if ((unsigned)a0 >= (unsigned)n0) continue;                                                   \
+    RowPieces rp[5];                                                                              \
     _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
-      const int y = cy + t - 2;                                                                   \
+      const int a1 = c1 + t - 2;                                                                  \
       int z0, z1;                                                                                 \
-      lo[t] = hi[t] = 0;                                                                          \
-      if ((unsigned)y < (unsigned)d.ny && zrange(dx, t - 2, z0, z1)) {                            \
-        const int base = (x * d.ny + y) * d.nz;                                                   \
-        lo[t] = CS[base + z0]; hi[t] = CS[base + z1];                                             \
-      }                                                                                           \
+      rp[t].lo0 = rp[t].hi0 = rp[t].lo1 = rp[t].hi1 = 0;                                          \
+      if ((unsigned)a1 < (unsigned)n1 && zrange(d.perm ? t - 2 : e0, d.perm ? e0 : t - 2, z0, z1)) \
+        rp[t] = row_pieces(d, CS, d.perm ? a1 : a0, d.perm ? a0 : a1, z0, z1);                    \
     }                                                                                             \
-    _Pragma("unroll") for (int t = 0; t < 5; t++)                                                 \
-      for (int j = lo[t]; j < hi[t]; j++) {                                                       \
+    _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
+      int j = rp[t].lo0, end = rp[t].hi0, j2 = rp[t].lo1;                                         \
+      const int end2 = rp[t].hi1;                                                                 \
+      for (;;) {                                                                                  \
+        if (j >= end) { if (j2 >= end2) break; j = j2; end = end2; j2 = end2; }                   \
         const float4 pj = POS[j];                                                                 \
         const float3 r = xi - xyz(pj);                                                            \
         const float r2 = dot3(r, r);                                                              \
         if (r2 <= d.list_r2 && (SELF)) CALL(j, r, r2, 1.0f);                                      \
+        j++;                                                                                      \
       }                                                                                           \
+    }                                                                                             \
   }
   if (liquids) { WALK_PLANE(d.cs_l, d.pos, j != i, fl) }
   if (info & 1) { WALK_PLANE(d.cs_s, d.spos, true, fs) }
@@ -236,7 +277,7 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
       const int k = e[2 + t] & 0xff;
       const float m = (float)(e[2 + t] >> 8);
       const int x = cx + k / 25 - 2, y = cy + (k / 5) % 5 - 2, z = cz + k % 5 - 2;
-      const int c = (x * d.ny + y) * d.nz + z;
+      const int c = cell_lin(d, x, y, z);
       if (liquids)
       for (int j = d.cs_l[c]; j < d.cs_l[c + 1]; j++) {
         const float3 r = xi - xyz(d.pos[j]);
@@ -257,8 +298,8 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
 // included) is stored as a stream of int16 DELTAS: slot k holds j_k - j_{k-1}, the liquid stream starting from
 // j_{-1} = i (neighbours are near i in the cell-sorted order), the solid stream from nhead[i].y.  A sorted index
 // needs 4 bytes, its delta 2: the index stream is what a pass reads most of (tools/ablate.py), so this halves the
-// HBM traffic of every neighbour pass.  Deltas that do not fit (the jump to another x-plane of a large grid) are
-// bridged by HOP slots, +-32767, which move the running index but are not entries.  Eight slots form one
+// HBM traffic of every neighbour pass.  Deltas that do not fit (the jump to the neighbouring outer tile plane of a
+// large grid) are bridged by HOP slots, +-32767, which move the running index but are not entries.  Eight slots form one
 // 16-byte block; block b of particle i sits at [b * nbr_stride + i], so a wave loads 1 KB contiguous per trip.
 #define NB_HOP 32767
 #define NB_IS_ENTRY(dd) ((unsigned)((dd) + (NB_HOP - 1)) <= (unsigned)(2 * NB_HOP - 2))   // |dd| < NB_HOP

@@ -1,4 +1,4 @@
-// grid.h -- HashGrid replacement: dense z-fastest cell table, counting sort of the particles,
+// grid.h -- HashGrid replacement: dense tile-ordered cell table (device.h cell_lin), counting sort of the particles,
 // and (faithful mode) the reference hash table's aliasing reproduced as static per-cell
 // multiplicity tables + a box-filtered bucket-count field for the raw list length.
 // ref: HashGrid.py:44-124.
@@ -20,7 +20,7 @@ __device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin, boo
   if (finite) *finite = (fabsf(fx) <= 3.0e38f) && (fabsf(fy) <= 3.0e38f) && (fabsf(fz) <= 3.0e38f);
   int cx = (int)fx - d.x0, cy = (int)fy, cz = (int)fz;  // truncation toward zero BEFORE the window shift (Q4)
   bool in = fin && (unsigned)cx < (unsigned)d.nx && (unsigned)cy < (unsigned)d.ny && (unsigned)cz < (unsigned)d.nz;
-  *lin = in ? (cx * d.ny + cy) * d.nz + cz : d.ncell;
+  *lin = in ? cell_lin(d, cx, cy, cz) : d.ncell_p;
   return in ? (cx | (cy << 10) | (cz << 20)) : -1;
 }
 
@@ -86,8 +86,10 @@ __global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int npart
 }
 
 __device__ __forceinline__ int lin_of(const Dev &d, int w) {
-  return w < 0 ? d.ncell : ((w & 1023) * d.ny + ((w >> 10) & 1023)) * d.nz + (w >> 20);
+  return w < 0 ? d.ncell_p : cell_lin(d, w & 1023, (w >> 10) & 1023, w >> 20);
 }
+// plain (x, y, z) index: the faithful box filter's scratch arrays
+__device__ __forceinline__ int plain_of(const Dev &d, int w) { return ((w & 1023) * d.ny + ((w >> 10) & 1023)) * d.nz + (w >> 20); }
 
 // phase 3: move every persistent liquid field to its cell-sorted position
 struct SortBuffers {
@@ -149,26 +151,31 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
   *total = tot;
   return off + inc - v;
 }
-// Scan blocks wholly outside the cell columns [xmin-2, xmax+2] of the occupied box hold only zeros: their block sum
-// is written as 0 without reading, their outputs are left alone (nothing reads cells that far from every particle).
-// The last block (out-of-box bin, grand total) is always processed.  bbox == nullptr: everything.
-// nz > 0 additionally skips blocks that lie in one x-plane but wholly outside the rows [ymin-2, ymax+2] of the box
-// (a 2048-cell block spans ~8 rows of a 254-cell column): no particle's 5^3 cells reach them either.
-__device__ __forceinline__ bool scan_block_active(const int *bbox, int n, int col_cells, int nz) {
+// Scan blocks none of whose tiles is within the walk radius (2 cells) of the occupied box hold only zeros: their block
+// sum is written as 0 without reading, their outputs are left alone (nothing reads the table that far from every
+// particle).  A tile is needed if it -- or its predecessor in tile order, whose last cell's END is this tile's first
+// START (row_pieces) -- intersects the grown box.  The last block (out-of-box bin, grand total) is always processed.
+// bbox == nullptr: everything.  Every thread of the block must call this.
+__device__ __forceinline__ bool scan_block_active(const Dev &d, const int *bbox, int n) {
   if (!bbox || (int)blockIdx.x == (n - 1) / SCAN_TILE) return true;
-  const int xmin = bbox[0], xmax = bbox[3];
-  if (xmax < 0) return false;
-  const long lo = (long)max(xmin - 2, 0) * col_cells, hi = (long)(xmax + 3) * col_cells + 1;
-  const long b0 = (long)blockIdx.x * SCAN_TILE, b1 = b0 + SCAN_TILE;
-  if (!(b1 > lo && b0 <= hi)) return false;
-  if (nz > 0 && b0 / col_cells == (b1 - 1) / col_cells) {
-    const int y0 = (int)((b0 % col_cells) / nz), y1 = (int)(((b1 - 1) % col_cells) / nz);
-    if (y1 < bbox[1] - 2 || y0 > bbox[4] + 3) return false;   // +3: a row's end bound is the first cell of the next row
+  if (bbox[3] < 0) return false;
+  const int lx = max(bbox[0] - 2, 0), ly = max(bbox[1] - 2, 0), lz = max(bbox[2] - 2, 0);
+  const int hx = min(bbox[3] + 2, d.nx - 1), hy = min(bbox[4] + 2, d.ny - 1), hz = min(bbox[5] + 2, d.nz - 1);
+  const int l0 = (d.perm ? ly : lx) >> T0B, h0 = (d.perm ? hy : hx) >> T0B, l1 = (d.perm ? lx : ly) >> T1B, h1 = (d.perm ? hx : hy) >> T1B;
+  const int l2 = lz >> T2B, h2 = hz >> T2B;
+  const int tiles_per_block = SCAN_TILE >> TILE_SHIFT;
+  int need = 0;
+  for (int k = threadIdx.x; k <= tiles_per_block; k += BLOCK) {   // the block's tiles and the one before them
+    const int T = blockIdx.x * tiles_per_block - 1 + k;
+    if (T >= 0) {
+      const int t2 = T % d.nt2, q = T / d.nt2, t1 = q % d.nt1, t0 = q / d.nt1;
+      need |= (t0 >= l0 && t0 <= h0 && t1 >= l1 && t1 <= h1 && t2 >= l2 && t2 <= h2);
+    }
   }
-  return true;
+  return __syncthreads_or(need) != 0;
 }
-__global__ void k_scan_reduce(const int *in, int n, int *bsum, const int *bbox, int col_cells, int nz) {
-  if (!scan_block_active(bbox, n, col_cells, nz)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
+__global__ void k_scan_reduce(Dev d, const int *in, int n, int *bsum, const int *bbox) {
+  if (!scan_block_active(d, bbox, n)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int s = 0;
 #pragma unroll
@@ -187,8 +194,8 @@ __global__ void k_scan_bsums(int *bsum, int nb) {  // one block: every thread ow
 }
 // clear != 0: the counters are zeroed as they are consumed, so the next grid update needs no 65 MB memset (only
 // cells of the active blocks can be non-zero: every counted particle lies inside the occupied box or in the last bin)
-__global__ void k_scan_final(int *in, int n, const int *bsum, int *out, const int *bbox, int col_cells, int clear, int nz) {
-  if (!scan_block_active(bbox, n, col_cells, nz)) return;
+__global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, const int *bbox, int clear) {
+  if (!scan_block_active(d, bbox, n)) return;
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int v[SCAN_PER_THREAD], s = 0;
 #pragma unroll
@@ -206,7 +213,7 @@ __global__ void k_scan_final(int *in, int n, const int *bsum, int *out, const in
 // ---- static per-cell info ---------------------------------------------------------------
 // bit0: any solid particle inside the 5x5x5 walk of this cell (lets bulk particles skip the solid walk)
 __global__ void k_cell_solid_near(Dev d, int *cell_info) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  int c = blockIdx.x * blockDim.x + threadIdx.x;   // plain index
   if (c >= d.ncell) return;
   int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
   int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
@@ -217,11 +224,12 @@ __global__ void k_cell_solid_near(Dev d, int *cell_info) {
     for (int dy = -2; dy <= 2; dy++) {
       int y = cy + dy;
       if ((unsigned)y >= (unsigned)d.ny) continue;
-      int base = (x * d.ny + y) * d.nz;
-      any |= (d.cs_s[base + z1] > d.cs_s[base + z0]);
+      const RowPieces rp = row_pieces(d, d.cs_s, x, y, z0, z1);
+      any |= (rp.hi0 > rp.lo0) | (rp.hi1 > rp.lo1);
     }
   }
-  cell_info[c] = (cell_info[c] & ~1) | (any ? 1 : 0);
+  const int l = cell_lin(d, cx, cy, cz);
+  cell_info[l] = (cell_info[l] & ~1) | (any ? 1 : 0);
 }
 
 // Faithful mode (Q1): which cells have two walked cells in one bucket?  64 cells per block, the 125
@@ -248,14 +256,15 @@ __global__ void __launch_bounds__(ALIAS_TB) k_alias_detect(Dev d, int *cell_info
   }
   if (dup) {
     int slot = atomicAdd(n_alias, 1);
-    cell_info[c] = (cell_info[c] & 1) | ((slot + 1) << 1);
+    const int l = cell_lin(d, c / (d.nz * d.ny), (c / d.nz) % d.ny, c % d.nz);
+    cell_info[l] = (cell_info[l] & 1) | ((slot + 1) << 1);
   }
 }
 __global__ void __launch_bounds__(ALIAS_TB) k_alias_fill(Dev d, const int *cell_info, uint16_t *alias) {
   __shared__ int hs[125][ALIAS_TB];
   int c = blockIdx.x * ALIAS_TB + threadIdx.x, t = threadIdx.x;
   if (c >= d.ncell) return;
-  int info = cell_info[c];
+  int info = cell_info[cell_lin(d, c / (d.nz * d.ny), (c / d.nz) % d.ny, c % d.nz)];
   if (!(info >> 1)) return;
   alias_hashes(d, c, hs);
   uint16_t *e = alias + (size_t)((info >> 1) - 1) * ALIAS_STRIDE;
@@ -321,10 +330,9 @@ __global__ void k_ncount_faithful(Dev d, const int *boxsum) {
   int w = __float_as_int(d.pos[i].w);
   int cnt = 0;
   if (w >= 0) {
-    int c = lin_of(d, w);
-    int info = d.cell_info[c];
+    int info = d.cell_info[lin_of(d, w)];
     int self = (info >> 1) ? d.alias[(size_t)((info >> 1) - 1) * ALIAS_STRIDE + 1] : 1;
-    cnt = boxsum[c] - self;
+    cnt = boxsum[plain_of(d, w)] - self;
   }
   if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
   d.ncount[i] = cnt;
@@ -344,12 +352,12 @@ __global__ void k_ncount_clean(Dev d) {
       for (int dy = -2; dy <= 2; dy++) {
         int y = cy + dy;
         if ((unsigned)y >= (unsigned)d.ny) continue;
-        int base = (x * d.ny + y) * d.nz;
-        cnt += d.cs_l[base + z1] - d.cs_l[base + z0] + d.cs_s[base + z1] - d.cs_s[base + z0];
+        const RowPieces rl = row_pieces(d, d.cs_l, x, y, z0, z1), rs = row_pieces(d, d.cs_s, x, y, z0, z1);
+        cnt += (rl.hi0 - rl.lo0) + (rl.hi1 - rl.lo1) + (rs.hi0 - rs.lo0) + (rs.hi1 - rs.lo1);
       }
     }
     cnt -= 1;
-    int c = (cx * d.ny + cy) * d.nz + cz;
+    int c = cell_lin(d, cx, cy, cz);
     if (d.cs_l[c + 1] - d.cs_l[c] + d.cs_s[c + 1] - d.cs_s[c] > d.max_in_grid) atomicOr(&d.flags[FLAG_ERR], ERRBIT_BUCKET);
   }
   if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);
@@ -358,6 +366,9 @@ __global__ void k_ncount_clean(Dev d) {
 
 // Compact per-step neighbour lists: the in-support entries of the reference's neighbour row, with the
 // bucket-multiset multiplicity expanded into repeated entries (ref: HashGrid.py:88-106).
+// (Measured and rejected, r02: parking the plane's 20 cell-table ranges in LDS and testing candidates four at a time
+// from a runtime loop over the pieces -- 375 us against 327 us for this form at C3: the kernel issues ~160 M VALU
+// wave-instructions either way and half-empty 4-wide chunks add more than the shorter dependency chains save.)
 __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   const int i = sorted_index();
   if (i >= d.nl) return;

@@ -118,23 +118,24 @@ __global__ void __launch_bounds__(BLOCK) k_mc_value(Dev d, McDev m) {
   // cell of the node in the solver's grid (may lie outside it: the MC grid reaches searchR beyond the bounding box)
   const int cx = (int)floorf((p.x - d.minx) * d.inv_grid) - d.x0, cy = (int)floorf((p.y - d.miny) * d.inv_grid),
             cz = (int)floorf((p.z - d.minz) * d.inv_grid);
-  // only cells inside the occupied box of this step hold particles -- and only the cell table of its x-planes is
-  // current (the grid update scans nothing else, grid.h scan_block_active)
+  // only cells inside the occupied box of this step hold particles -- and only the cell table of the tiles around it
+  // is current (the grid update scans nothing else, grid.h scan_block_active)
   const int bx0 = d.bbox[0], by0 = d.bbox[1], bz0 = d.bbox[2], bx1 = d.bbox[3], by1 = d.bbox[4], bz1 = d.bbox[5];
   const int z0 = max(cz - 2, bz0), z1 = min(cz + 2, bz1) + 1;
   float s = 0.f;
   if (z1 > z0)
     for (int xx = max(cx - 2, bx0); xx <= min(cx + 2, bx1); xx++)
       for (int yy = max(cy - 2, by0); yy <= min(cy + 2, by1); yy++) {
-        const int base = (xx * d.ny + yy) * d.nz;
-        for (int j = d.cs_l[base + z0]; j < d.cs_l[base + z1]; j++) {
-          const float3 r = p - xyz(d.pos[j]);
-          const float w = mc_cubic_W(m, dot3(r, r));
-          if (w > 0.0f) {
-            const float rho = d.rho[j];
-            if (rho > m.rho_min) s += d.mass / rho * w;
+        const RowPieces rp = row_pieces(d, d.cs_l, xx, yy, z0, z1);
+        for (int piece = 0; piece < 2; piece++)
+          for (int j = piece ? rp.lo1 : rp.lo0; j < (piece ? rp.hi1 : rp.hi0); j++) {
+            const float3 r = p - xyz(d.pos[j]);
+            const float w = mc_cubic_W(m, dot3(r, r));
+            if (w > 0.0f) {
+              const float rho = d.rho[j];
+              if (rho > m.rho_min) s += d.mass / rho * w;
+            }
           }
-        }
       }
   m.value[t] = s;
 }

@@ -264,11 +264,9 @@ int wcsph_sync(wcsph_ctx *ctx) {
 
 static int run_scan(wcsph_ctx *ctx, int *in, int n, int *out, const int *bbox, int clear = 0) {
   int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  const int col = ctx->d.ny * ctx->d.nz;
-  const int nz = bbox ? ctx->d.nz : 0;
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, bbox, col, nz);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, ctx->d, (const int *)in, n, ctx->bsum, bbox);
   hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->bsum, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, in, n, ctx->bsum, out, bbox, col, clear, nz);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, ctx->d, in, n, (const int *)ctx->bsum, out, bbox, clear);
   LAUNCHCHK();
   return 0;
 }
@@ -291,13 +289,19 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
     d.x0 = x0; d.nx = x1 - x0;
     ncell = (long)d.nx * d.ny * d.nz;
   }
-  if (ncell > 0x7fff0000L) return ctx->fail(WCSPH_EARG, "grid has too many cells");
-  d.ncell = (int)ncell;
+  // tile order (device.h cell_lin): the longer of x / y is the outer axis
+  d.perm = d.ny > d.nx ? 1 : 0;
+  d.nt0 = ((d.perm ? d.ny : d.nx) + (1 << T0B) - 1) >> T0B;
+  d.nt1 = ((d.perm ? d.nx : d.ny) + (1 << T1B) - 1) >> T1B;
+  d.nt2 = (d.nz + (1 << T2B) - 1) >> T2B;
+  const long ncell_p = ((long)d.nt0 * d.nt1 * d.nt2) << TILE_SHIFT;
+  if (ncell_p > 0x7fff0000L) return ctx->fail(WCSPH_EARG, "grid has too many cells");
+  d.ncell = (int)ncell; d.ncell_p = (int)ncell_p;
   d.minx = minb[0]; d.miny = minb[1]; d.minz = minb[2];
-  const int nscan = d.ncell + 2;
+  const int nscan = d.ncell_p + 2;
   ctx->scan_blocks = (nscan + SCAN_TILE - 1) / SCAN_TILE;
   DALLOC(ctx->cnt, nscan); DALLOC(d.cs_l, nscan); DALLOC(d.cs_s, nscan); DALLOC(ctx->bsum, ctx->scan_blocks + 1);
-  DALLOC(d.cell_info, d.ncell);
+  DALLOC(d.cell_info, d.ncell_p);
   DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1));
   if (d.faithful) {
     DALLOC(ctx->bcount, d.table_size); DALLOC(ctx->bcount_s, d.table_size);
@@ -371,7 +375,7 @@ int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]) {
 int wcsph_grid_update(wcsph_ctx *ctx) {
   NEED_SETUP();
   Dev &d = ctx->d;
-  const int nscan = d.ncell + 2;
+  const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
   // ctx->cnt is all zero here: k_scan_final clears the counters it consumes
   // overflow / non-finite conditions are re-detected by every update: what the previous one raised has been reported by
@@ -1228,7 +1232,7 @@ __global__ void k_neighbor_lists(Dev d, int i0, int n, int cap, int *counts, int
   const int cw = __float_as_int(pi.w);
   if (cw < 0) return;
   const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
-  const int info = d.cell_info[(cx * d.ny + cy) * d.nz + cz];
+  const int info = d.cell_info[cell_lin(d, cx, cy, cz)];
   const uint16_t *e = (info >> 1) ? d.alias + (size_t)((info >> 1) - 1) * ALIAS_STRIDE : nullptr;
   int w = 0;
   for (int k = 0; k < 125; k++) {
@@ -1236,7 +1240,7 @@ __global__ void k_neighbor_lists(Dev d, int i0, int n, int cap, int *counts, int
     if ((unsigned)x >= (unsigned)d.nx || (unsigned)y >= (unsigned)d.ny || (unsigned)z >= (unsigned)d.nz) continue;
     int mult = 1;
     if (e) for (int q = 0; q < e[0]; q++) if ((e[2 + q] & 0xff) == k) mult += e[2 + q] >> 8;
-    int c = (x * d.ny + y) * d.nz + z;
+    int c = cell_lin(d, x, y, z);
     for (int rep = 0; rep < mult; rep++) {
       for (int j = d.cs_l[c]; j < d.cs_l[c + 1]; j++) if (j != i) { if (w < cap) row[w] = d.oid[j]; w++; }
       for (int j = d.cs_s[c]; j < d.cs_s[c + 1]; j++) { if (w < cap) row[w] = d.nl + __float_as_int(d.spos[j].w); w++; }
