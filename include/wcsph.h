@@ -51,7 +51,8 @@ typedef struct wcsph_params {
   int32_t max_in_grid;       /* 64   (ParticleData.py:27) */
   int32_t max_neighbour;     /* 2048 (ParticleData.py:27) */
   int32_t hash_table_size;   /* 0 => n_liquid + n_solid (HashGrid.py:114); slabs pass the global count */
-  int32_t tension_fixed;     /* 0 literal Q8/Q9 loop is NOT reproducible; only 1 (fixed normals) is implemented */
+  int32_t tension_fixed;     /* 1: n = h * sum, curvature over the support (documented repair of Q8); 0: the loop of
+                              * dfsph.py:264-305 literally over the raw bucket rows (faithful mode, one context = whole domain) */
   int32_t list_cap;          /* entries per particle of the compact lists; 0 => 256 slots.  pcisph needs the reference's 2048 */
   double particle_radius;    /* what the script passes to ParticleData(): radius (dfsph) or diameter (sesph, Q11) */
   double cfl_radius;         /* dfsph.py:27 particleRadius used by optimize_time_step */
@@ -113,6 +114,10 @@ int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]);
 
 int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes);
 int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes);
+/* rows [i0, i0+n) of a liquid field, original order: Python-scope element access `f[i]` / `f[i] = v`
+ * (ref: dfsph.py:98 `particle_data.cg_delta[0]`, :645 `pos.to_numpy()[test_id]`) without moving the whole field */
+int wcsph_field_rows_to_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n, void *dst);
+int wcsph_field_rows_from_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n, const void *src);
 int wcsph_get_scalar(wcsph_ctx *ctx, int id, float *v);
 int wcsph_set_scalar(wcsph_ctx *ctx, int id, float v);
 int wcsph_get_iters(wcsph_ctx *ctx, int32_t *vs_iter, int32_t *dv_iter, int32_t *pr_iter);
@@ -124,6 +129,13 @@ int wcsph_grid_update(wcsph_ctx *ctx);
 /* ref: HashGrid.neighbor / neighborCount (HashGrid.py:24-25,88-106): materialise the explicit list the
  * reference stores, original indices, for particles [i0, i0+n): counts[n], lists[n][cap] (-1 padded) */
 int wcsph_neighbors_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, int32_t *counts, int32_t *lists);
+/* ref: HashGrid.gridCount (HashGrid.py:20,71): occupancy of every bucket of the reference's table, n = table size
+ * (faithful mode).  ref: HashGrid.grid (HashGrid.py:21,76): rows [h0, h0+n) of the table, global particle ids
+ * (liquid: original index; solid: n_liquid + index), ascending inside a bucket, -1 padded to cap.  The table is
+ * materialised on demand (csrc/bucket.h); wcsph_neighbors_to_host() reads its rows from it, so in faithful mode they are
+ * the reference's rows entry for entry, far aliased particles included. */
+int wcsph_hashgrid_count_to_host(wcsph_ctx *ctx, int32_t *dst, int64_t n);
+int wcsph_hashgrid_rows_to_host(wcsph_ctx *ctx, int32_t h0, int32_t n, int32_t cap, int32_t *rows);
 /* diagnostics: the compact per-step lists the neighbour passes actually iterate -- the in-support subset of the row
  * above (`while k < cur_neighbor` loops, e.g. dfsph.py:254-256, weigh everything else by exactly zero), decoded from
  * the 16-bit delta streams; original indices (solids offset by n_liquid), -1 padded.

@@ -28,20 +28,45 @@ def test_neighbor_count_exact(mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_neighbor_multiset_in_walk(mode):
-    """The explicit list (original indices) equals the oracle's list restricted to particles whose cell is
-    one of the 5x5x5 walked cells -- with multiplicity; the rest of the oracle list is far aliased entries."""
+def test_neighbor_rows_are_the_reference_rows(mode):
+    """HashGrid.neighbor (ref: HashGrid.py:88-106).  Faithful: the device's rows equal the oracle's ENTRY FOR ENTRY --
+    walked cells x outermost, bucket slots in ascending id, duplicates from aliased cells and far aliased particles
+    included (they are read from the reference bucket table the library materialises on demand, csrc/bucket.h).
+    Clean: the particles of the 5x5x5 walked cells, as a multiset."""
     g, o = make_pair(6, mode, jitter=0.4)
     g.pd.hash_grid.update_grid()
     o.update_grid()
     counts, lists = g.pd.hash_grid.neighbor.rows(0, g.pd.liquid_count, cap=2048)
     np.testing.assert_array_equal(counts, o.neighborCount)
+    far = 0
     cells = np.array([o.cell_of(i) for i in range(o.count)])
-    for i in range(0, g.pd.liquid_count, 7):
-        mine = np.sort(lists[i][lists[i] >= 0])
+    for i in range(0, g.pd.liquid_count, 3):
         ref = o.neighbor[i, :o.neighborCount[i]]
-        near = np.all(np.abs(cells[ref] - cells[i]) <= 2, axis=1)
-        np.testing.assert_array_equal(mine, np.sort(ref[near]))
+        if mode == "faithful":
+            np.testing.assert_array_equal(lists[i][:counts[i]], ref)
+            far += int((~np.all(np.abs(cells[ref] - cells[i]) <= 2, axis=1)).sum())
+        else:
+            np.testing.assert_array_equal(np.sort(lists[i][lists[i] >= 0]), np.sort(ref))
+    if mode == "faithful":
+        assert far > 0, "the scene must contain far aliased entries for this test to mean anything"
+    g.close()
+
+
+def test_reference_bucket_table():
+    """HashGrid.gridCount / HashGrid.grid (ref: HashGrid.py:20-21,67-76) read back from the device in faithful mode."""
+    g, o = make_pair(6, "faithful", jitter=0.4)
+    g.pd.hash_grid.update_grid()
+    o.update_grid()
+    np.testing.assert_array_equal(g.pd.hash_grid.gridCount, o.gridCount)
+    np.testing.assert_array_equal(g.pd.hash_grid.grid.to_numpy(), o.grid)
+    h = int(np.argmax(o.gridCount))
+    assert g.pd.hash_grid.grid[h, 0] == o.grid[h, 0]
+    # after a step the table follows the particles
+    g.call("dfsph_reset_param"); o.reset_param()
+    g.call("dfsph_step"); o.dfsph_step()
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    np.testing.assert_array_equal(g.pd.hash_grid.gridCount, o.gridCount)
+    np.testing.assert_array_equal(g.pd.hash_grid.grid.to_numpy(), o.grid)
     g.close()
 
 

@@ -35,9 +35,9 @@ class _HostVec:
 
 class _NeighborList:
     """HashGrid.neighbor[i, k] (ref: HashGrid.py:25,88-106): explicit list in ORIGINAL indices, -1 padded.
-    Entries of the reference's multiset that lie in the 5x5x5 walked cells are enumerated (with their
-    multiplicity); far entries that only alias into a walked bucket contribute exactly zero to every sum
-    and are counted in neighborCount but not enumerated."""
+    Faithful mode: the reference's row entry for entry, read from the bucket table the device materialises on demand
+    (walked cells x outermost, bucket slots in ascending id, far aliased particles included).  Clean mode: the
+    particles of the 5x5x5 walked cells."""
 
     def __init__(self, grid):
         self._g = grid
@@ -76,6 +76,32 @@ class _NeighborList:
         return self.rows(int(i), 1)[1][0, k]
 
 
+class _GridTable:
+    """HashGrid.grid[h, k] (ref: HashGrid.py:21,76): the reference's bucket table, materialised on demand from the
+    device (faithful mode): global particle ids, ascending inside a bucket, -1 padded to maxInGrid."""
+
+    def __init__(self, grid):
+        self._g = grid
+
+    @property
+    def shape(self):
+        pd = self._g.particle_data
+        return (pd.hash_table_size or pd.count, self._g.maxInGrid)
+
+    def rows(self, h0, n):
+        ctx = self._g.particle_data._need_ctx()
+        out = np.empty((n, self._g.maxInGrid), np.int32)
+        _lib.check(ctx, _lib.load().wcsph_hashgrid_rows_to_host(ctx, h0, n, self._g.maxInGrid, out.ctypes.data))
+        return out
+
+    def to_numpy(self):
+        return self.rows(0, self.shape[0])
+
+    def __getitem__(self, hk):
+        h, k = hk
+        return self.rows(int(h), 1)[0, k]
+
+
 class HashGrid:
     def __init__(self, gridR, maxInGrid, maxNeighbour, particle_data):
         self.maxInGrid = maxInGrid
@@ -86,6 +112,7 @@ class HashGrid:
         self.searchR = gridR * 2.0
         self.neighborCount = Field(particle_data, "neighborCount", 1, np.int32)
         self.neighbor = _NeighborList(self)
+        self.grid = _GridTable(self)
         self.blockSize = _HostVec(np.int32)
         self.min_boundary = _HostVec(np.float32)
         self.max_boundary = _HostVec(np.float32)
@@ -138,7 +165,16 @@ class HashGrid:
 
     @property
     def gridCount(self):
-        """Reference bucket occupancy (ref: HashGrid.py:20,71), rebuilt on the host for inspection."""
+        """Reference bucket occupancy (ref: HashGrid.py:20,71).  Faithful mode: the device's own table of this step
+        (the counts the raw neighbour counts are built from); clean mode has no bucket table and the counts are
+        rebuilt on the host for inspection."""
+        pd = self.particle_data
+        if pd.neighbor_mode == "faithful":
+            ctx = pd._need_ctx()
+            n = pd.hash_table_size or pd.count
+            out = np.empty(n, np.int32)
+            _lib.check(ctx, _lib.load().wcsph_hashgrid_count_to_host(ctx, out.ctypes.data, n))
+            return out
         pos = self.particle_data.pos.to_numpy()
         cells = self._cells(pos)
         inb = self.check_in_box(cells).astype(bool)

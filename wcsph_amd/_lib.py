@@ -72,7 +72,8 @@ OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_c
          "wcsph_field_gather_rows", "wcsph_field_scatter_rows", "wcsph_set_owned", "wcsph_set_cell_window",
          "wcsph_load_state", "wcsph_load_state_split", "wcsph_store_state", "wcsph_get_acc", "wcsph_set_acc", "wcsph_phase", "wcsph_set_part", "wcsph_set_acc_buffer",
          "wcsph_surface_anisotropic_kernel", "wcsph_dfsph_step_fixed", "wcsph_sample_surface", "wcsph_mc_tables",
-         "wcsph_mc_setup", "wcsph_mc_surface_value", "wcsph_mc_value_to_host", "wcsph_mc_marching_cube", "wcsph_canvas_draw"]
+         "wcsph_mc_setup", "wcsph_mc_surface_value", "wcsph_mc_value_to_host", "wcsph_mc_marching_cube", "wcsph_canvas_draw",
+         "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
 ALL_SYMBOLS = CTX_ONLY + OTHER
 
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
@@ -135,6 +136,10 @@ def load():
     lib.wcsph_mc_setup.argtypes = [vp, C.c_double, C.c_double, vp, vp, vp]
     lib.wcsph_mc_value_to_host.argtypes = [vp, vp, C.c_int64]
     lib.wcsph_mc_marching_cube.argtypes = [vp, C.c_float, vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.wcsph_hashgrid_count_to_host.argtypes = [vp, vp, C.c_int64]
+    lib.wcsph_hashgrid_rows_to_host.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.wcsph_field_rows_to_host.argtypes = [vp, C.c_int, C.c_int32, C.c_int32, vp]
+    lib.wcsph_field_rows_from_host.argtypes = [vp, C.c_int, C.c_int32, C.c_int32, vp]
     lib.wcsph_sample_surface.argtypes = [vp, C.c_int32, C.c_double, C.c_uint32, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
     for name in CTX_ONLY:
         getattr(lib, name).argtypes = [vp]

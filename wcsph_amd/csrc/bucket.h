@@ -1,0 +1,155 @@
+// bucket.h -- the reference's hash table itself (HashGrid.grid / gridCount, ref: HashGrid.py:20-21,67-76), built on
+// demand in faithful mode for the few consumers that need the RAW neighbour row rather than its in-support part:
+//   * HashGrid.neighbor rows exactly as the reference stores them, far aliased entries included (HashGrid.py:88-106);
+//   * the literal compute_tension loop (dfsph.py:264-305): `normal *= searchR` once per raw entry (Q8) and the curvature
+//     term over every raw liquid entry;
+//   * ParticleData.cal_anistropic_kernel in faithful mode (support 0.18 > h: a far aliased entry can weigh in).
+// The solver passes never touch it: every kernel-weighted sum has support h <= the walk radius.
+//
+// Layout: bk_start[T + 1] (exclusive scan of gridCount), bk_item[] = global particle ids (original liquid index, or
+// n_liquid + original solid index), ascending inside a bucket.  The reference's slot order is the arrival order of its
+// atomic_add (Q16: schedule dependent); ascending ids is the order a serial insert produces (one valid reference run).
+#pragma once
+#include "device.h"
+#include "grid.h"
+
+struct BucketTab {
+  int *start;     // [T + 1]
+  int *item;      // [n_liquid + n_solid]
+  int *cursor;    // [T] scatter cursors
+  int *swhere;    // [n_solid] original solid index -> sorted solid index
+};
+
+__global__ void k_bk_swhere(Dev d, BucketTab b) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < d.ns) b.swhere[__float_as_int(d.spos[s].w)] = s;
+}
+__global__ void k_bk_scatter_liquid(Dev d, BucketTab b) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  const int w = __float_as_int(d.pos[i].w);
+  if (w < 0) return;   // outside the box: not inserted (HashGrid.py:68-69)
+  const int h = ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size);
+  b.item[atomicAdd(&b.cursor[h], 1)] = d.oid[i];
+}
+__global__ void k_bk_scatter_solid(Dev d, BucketTab b) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.ns) return;
+  const float4 p = d.spos[s];
+  int lin;
+  const int w = cell_packed(d, xyz(p), &lin);
+  if (w < 0) return;
+  const int h = ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size);
+  b.item[atomicAdd(&b.cursor[h], 1)] = d.nl + __float_as_int(p.w);
+}
+__global__ void k_bk_sort(Dev d, BucketTab b) {   // one thread per bucket: insertion sort (<= maxInGrid items, ~1 on average)
+  int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= d.table_size) return;
+  const int lo = b.start[h], hi = b.start[h + 1];
+  for (int a = lo + 1; a < hi; a++) {
+    const int v = b.item[a];
+    int k = a - 1;
+    while (k >= lo && b.item[k] > v) { b.item[k + 1] = b.item[k]; k--; }
+    b.item[k + 1] = v;
+  }
+}
+
+// position (and kind) of a global id
+__device__ __forceinline__ float4 bk_pos(const Dev &d, const BucketTab &b, int g, int *sorted) {
+  if (g < d.nl) { const int j = d.where[g]; *sorted = j; return d.pos[j]; }
+  const int s = b.swhere[g - d.nl];
+  *sorted = s;
+  return d.spos[s];
+}
+
+// the raw row of liquid particle i (sorted index): f(g) for every entry in the reference's order -- cells (m, n, q) with
+// x outermost (HashGrid.py:82-85), bucket slots in ascending id, the particle itself skipped (HashGrid.py:97)
+template <class F>
+__device__ __forceinline__ void raw_row(const Dev &d, const BucketTab &b, int i, float4 pi, F &&f) {
+  const int cw = __float_as_int(pi.w);
+  if (cw < 0) return;
+  const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
+  const int self = d.oid[i];
+#pragma unroll 1
+  for (int k = 0; k < 125; k++) {
+    const int x = cx + k / 25 - 2, y = cy + (k / 5) % 5 - 2, z = cz + k % 5 - 2;
+    if ((unsigned)x >= (unsigned)d.nx || (unsigned)y >= (unsigned)d.ny || (unsigned)z >= (unsigned)d.nz) continue;
+    const int h = ref_hash(x + d.x0, y, z, d.table_size);
+    for (int s = b.start[h]; s < b.start[h + 1]; s++) {
+      const int g = b.item[s];
+      if (g != self) f(g);
+    }
+  }
+}
+
+// HashGrid.neighbor rows (ref: HashGrid.py:88-106) for original particles [i0, i0 + n): counts = neighborCount, lists -1 padded
+__global__ void k_bk_rows(Dev d, BucketTab b, int i0, int n, int cap, int *counts, int *lists) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = d.where[i0 + t];
+  int *row = lists + (size_t)t * cap;
+  int w = 0;
+  raw_row(d, b, i, d.pos[i], [&](int g) { if (w < cap) row[w] = g; w++; });
+  counts[t] = w;
+  for (int k = w; k < cap; k++) row[k] = -1;
+}
+// HashGrid.grid rows (ref: HashGrid.py:21,76) for buckets [h0, h0 + n)
+__global__ void k_bk_grid_rows(Dev d, BucketTab b, int h0, int n, int cap, int *rows) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int lo = b.start[h0 + t], cnt = b.start[h0 + t + 1] - lo;
+  for (int k = 0; k < cap; k++) rows[(size_t)t * cap + k] = k < cnt ? b.item[lo + k] : -1;
+}
+
+// ---- compute_tension, literally (ref: dfsph.py:264-305) -------------------------------------------------------------
+// ref: kernels/CubicKernel.py:20-32
+__device__ __forceinline__ float3 bk_gradW(const Dev &d, float3 r) {
+  const float r2 = dot3(r, r);
+  return r * cubic_gradW_scale(d, r2);
+}
+// first loop (:266-279): normal_i = sum over the raw row; liquid entries add (m / rho_j) gradW, EVERY entry then scales the
+// running value by searchR (Q8)
+__global__ void __launch_bounds__(BLOCK) k_tension_normal_literal(Dev d, BucketTab b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  const float4 pi = d.pos[i];
+  const float3 xi = xyz(pi);
+  float3 n = f3(0, 0, 0);
+  raw_row(d, b, i, pi, [&](int g) {
+    if (g < d.nl) {
+      const int j = d.where[g];
+      const float3 gw = bk_gradW(d, xi - xyz(d.pos[j]));
+      n = n + gw * (d.mass / d.rho[j]);
+    }
+    n = n * d.h;
+  });
+  d.normal[i] = f4(n, 0);
+}
+// second loop (:281-305): every raw liquid entry adds k_ij * (-gamma (n_i - n_j)) (the cohesion value is overwritten, Q9);
+// solid entries: adhesion inside the scene's 0.26 gate
+__device__ __forceinline__ float adhesion_W(const Dev &d, float r);
+__global__ void __launch_bounds__(BLOCK) k_tension_accel_literal(Dev d, BucketTab b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  const float4 pi = d.pos[i];
+  const float3 xi = xyz(pi), ni = xyz(d.normal[i]);
+  const float rhoi = d.rho[i];
+  float3 dv = xyz(d.d_vel[i]);
+  raw_row(d, b, i, pi, [&](int g) {
+    if (g < d.nl) {
+      const int j = d.where[g];
+      const float kij = 2.0f * d.rho_L0 / (rhoi + d.rho[j]);
+      const float3 accel = (ni - xyz(d.normal[j])) * (-d.tension);
+      dv = dv + accel * kij;
+    } else {
+      const float3 pj = xyz(d.spos[b.swhere[g - d.nl]]);
+      const float3 r = xi - pj, c = pj - f3(0.0f, 0.5f, 0.0f);
+      const float len2 = dot3(r, r), dis = sqrtf(dot3(c, c));
+      if (len2 > d.eps && dis < 0.26f) {
+        const float rl = sqrtf(len2);
+        dv = dv + r * (1.0f / rl) * (-d.tension_b * d.rho_S0 * d.VS0 * adhesion_W(d, rl));
+      }
+    }
+  });
+  d.d_vel[i] = f4(dv, 0);
+}

@@ -20,6 +20,7 @@
 #include "sampler.h"
 #include "mcgrid.h"
 #include "canvas.h"
+#include "bucket.h"
 
 struct wcsph_ctx {
   wcsph_params p;
@@ -36,6 +37,8 @@ struct wcsph_ctx {
   int *bcount = nullptr, *bcount_s = nullptr, *cellval = nullptr, *celltmp = nullptr;
   int *bbox_part = nullptr;
   int n_alias = 0, scan_blocks = 0;
+  BucketTab bk = {nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
+  bool bk_valid = false;
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats
   std::vector<float> solid_host;  // original-order solid positions
@@ -176,8 +179,8 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   ctx->p = *p;
   // gathers use 32-bit byte offsets into 16-byte records (device.h nb_ld): 2^28 particles of one kind is the ceiling
   if (p->n_liquid >= (1 << 28) || p->n_solid >= (1 << 28)) return ctx->fail(WCSPH_EARG, "at most 2^28 - 1 liquid and 2^28 - 1 boundary particles per context");
-  if (p->tension_fixed != 1 && (p->tension_coff != 0.0f))
-    return ctx->fail(WCSPH_EARG, "tension_fixed=0 (literal Q8 normals) is order dependent in the reference and not implemented");
+  if (p->tension_fixed != 1 && p->neighbor_mode != WCSPH_MODE_FAITHFUL)
+    return ctx->fail(WCSPH_EARG, "tension_fixed=0 (the literal loop of dfsph.py:264-305) runs over the reference's raw bucket lists: faithful neighbour mode only");
   HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
   Dev &d = ctx->d;
@@ -299,12 +302,12 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   d.ncell = (int)ncell; d.ncell_p = (int)ncell_p;
   d.minx = minb[0]; d.miny = minb[1]; d.minz = minb[2];
   const int nscan = d.ncell_p + 2;
-  ctx->scan_blocks = (nscan + SCAN_TILE - 1) / SCAN_TILE;
+  ctx->scan_blocks = ((nscan > d.table_size + 2 ? nscan : d.table_size + 2) + SCAN_TILE - 1) / SCAN_TILE;   // also scans the bucket table (bucket.h)
   DALLOC(ctx->cnt, nscan); DALLOC(d.cs_l, nscan); DALLOC(d.cs_s, nscan); DALLOC(ctx->bsum, ctx->scan_blocks + 1);
   DALLOC(d.cell_info, d.ncell_p);
   DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1));
   if (d.faithful) {
-    DALLOC(ctx->bcount, d.table_size); DALLOC(ctx->bcount_s, d.table_size);
+    DALLOC(ctx->bcount, d.table_size + 1); DALLOC(ctx->bcount_s, d.table_size + 1);   // [T] stays 0: the scan's end sentinel
     DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->celltmp, d.ncell);
   }
   // liquids: identity order until the first grid update
@@ -416,6 +419,54 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   }
   LAUNCHCHK();
   ctx->grid_valid = true;
+  ctx->bk_valid = false;
+  return WCSPH_OK;
+}
+
+// ---- the reference's bucket table, on demand (bucket.h) ----------------------------------------------------
+static int bucket_build(wcsph_ctx *ctx) {
+  Dev &d = ctx->d;
+  if (!d.faithful) return ctx->fail(WCSPH_EARG, "the reference bucket table (HashGrid.grid) exists in faithful neighbour mode only");
+  if (ctx->win_x1 >= 0) return ctx->fail(WCSPH_EARG, "the reference bucket table is not available on a slab window (it spans all ranks)");
+  if (ctx->bk_valid) return 0;
+  const int T = d.table_size;
+  hipStream_t s = ctx->stream;
+  if (!ctx->bk.start) {
+    DALLOC(ctx->bk.start, (size_t)T + 2); DALLOC(ctx->bk.cursor, (size_t)T + 1);
+    DALLOC(ctx->bk.item, (size_t)ctx->capacity + d.ns + 1); DALLOC(ctx->bk.swhere, (size_t)d.ns + 1);
+    if (d.ns > 0) hipLaunchKernelGGL(k_bk_swhere, dim3(nblk(d.ns)), dim3(BLOCK), 0, s, d, ctx->bk);
+  }
+  int rc = run_scan(ctx, ctx->bcount, T + 1, ctx->bk.start, nullptr, 0);   // bcount = gridCount of this step (grid update)
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->bk.cursor, ctx->bk.start, (size_t)T * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (d.nl > 0) hipLaunchKernelGGL(k_bk_scatter_liquid, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, ctx->bk);
+  if (d.ns > 0) hipLaunchKernelGGL(k_bk_scatter_solid, dim3(nblk(d.ns)), dim3(BLOCK), 0, s, d, ctx->bk);
+  hipLaunchKernelGGL(k_bk_sort, dim3(nblk(T)), dim3(BLOCK), 0, s, d, ctx->bk);
+  LAUNCHCHK();
+  ctx->bk_valid = true;
+  return 0;
+}
+int wcsph_hashgrid_count_to_host(wcsph_ctx *ctx, int32_t *dst, int64_t n) {   // HashGrid.gridCount
+  NEED_GRID();
+  if (!dst || n != ctx->d.table_size) return ctx->fail(WCSPH_EARG, "wcsph_hashgrid_count_to_host: n must be the hash table size");
+  if (!ctx->d.faithful) return ctx->fail(WCSPH_EARG, "HashGrid.gridCount is the reference table: faithful neighbour mode only");
+  HIPCHK(hipMemcpyAsync(dst, ctx->bcount, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return WCSPH_OK;
+}
+int wcsph_hashgrid_rows_to_host(wcsph_ctx *ctx, int32_t h0, int32_t n, int32_t cap, int32_t *rows) {   // HashGrid.grid[h0 : h0+n, :cap]
+  NEED_GRID();
+  if (h0 < 0 || n < 0 || (long)h0 + n > ctx->d.table_size || cap < 1 || !rows) return WCSPH_EARG;
+  int rc = bucket_build(ctx);
+  if (rc) return rc;
+  if (n == 0) return WCSPH_OK;
+  int *dr = nullptr;
+  HIPCHK(hipMalloc((void **)&dr, (size_t)n * cap * 4));
+  hipLaunchKernelGGL(k_bk_grid_rows, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->bk, h0, n, cap, dr);
+  hipError_t e1 = hipMemcpyAsync(rows, dr, (size_t)n * cap * 4, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  hipFree(dr);
+  if (e1 != hipSuccess || e2 != hipSuccess) return ctx->fail(WCSPH_EHIP, "hashgrid_rows_to_host copy");
   return WCSPH_OK;
 }
 
@@ -518,6 +569,46 @@ int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t byt
   LAUNCHCHK();
   HIPCHK(hipStreamSynchronize(s));
   if (field == WCSPH_F_POS) ctx->grid_valid = false;  // cells are stale until the next grid update
+  return WCSPH_OK;
+}
+
+// rows [i0, i0 + n) of a field in the caller's original order (Field.__getitem__ / __setitem__: one element, not the field)
+__global__ void k_rows_out(const float *f, int stride, int per, const int *where, int i0, int n, float *out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * per) return;
+  out[t] = f[(size_t)where[i0 + t / per] * stride + t % per];
+}
+__global__ void k_rows_in(float *f, int stride, int per, const int *where, int i0, int n, const float *in) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * per) return;
+  f[(size_t)where[i0 + t / per] * stride + t % per] = in[t];
+}
+int wcsph_field_rows_to_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n, void *dst) {
+  NEED_SETUP();
+  FieldDesc fd = field_desc(ctx, field);
+  if (fd.kind != 3 && fd.kind != 1 && fd.kind != -1) return ctx->fail(WCSPH_EARG, "field_rows: vec3 / scalar fields only");
+  if (i0 < 0 || n < 0 || i0 + n > ctx->d.nl || !dst) return WCSPH_EARG;
+  if (n == 0) return WCSPH_OK;
+  const int per = fd.kind == 3 ? 3 : 1, stride = fd.kind == 3 ? 4 : 1;
+  if ((size_t)n * per > ((size_t)ctx->capacity + ctx->d.ns) * 3) return WCSPH_EARG;
+  hipLaunchKernelGGL(k_rows_out, dim3(nblk(n * per)), dim3(BLOCK), 0, ctx->stream, (const float *)fd.ptr, stride, per, (const int *)ctx->d.where, i0, n, ctx->stage);
+  LAUNCHCHK();
+  HIPCHK(hipMemcpyAsync(dst, ctx->stage, (size_t)n * per * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return WCSPH_OK;
+}
+int wcsph_field_rows_from_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n, const void *src) {
+  NEED_SETUP();
+  FieldDesc fd = field_desc(ctx, field);
+  if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "field_rows: writable vec3 / scalar fields only");
+  if (i0 < 0 || n < 0 || i0 + n > ctx->d.nl || !src) return WCSPH_EARG;
+  if (n == 0) return WCSPH_OK;
+  const int per = fd.kind == 3 ? 3 : 1, stride = fd.kind == 3 ? 4 : 1;
+  HIPCHK(hipMemcpyAsync(ctx->stage, src, (size_t)n * per * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rows_in, dim3(nblk(n * per)), dim3(BLOCK), 0, ctx->stream, (float *)fd.ptr, stride, per, (const int *)ctx->d.where, i0, n, (const float *)ctx->stage);
+  LAUNCHCHK();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (field == WCSPH_F_POS) ctx->grid_valid = false;
   return WCSPH_OK;
 }
 
@@ -709,6 +800,13 @@ int wcsph_dfsph_tension(wcsph_ctx *ctx) {
   // gamma = gamma_b = 0 (the reference default): both loops add exactly +-0 to d_vel; `normal` (order
   // dependent garbage in the reference, Q8) is then left untouched.
   if (ctx->d.tension == 0.0f && ctx->d.tension_b == 0.0f) return WCSPH_OK;
+  if (ctx->p.tension_fixed == 0) {   // the reference loop literally, over the raw bucket rows (bucket.h)
+    int rc = bucket_build(ctx);
+    if (rc) return rc;
+    ELEM(k_tension_normal_literal, ctx->bk);
+    ELEM(k_tension_accel_literal, ctx->bk);
+    return WCSPH_OK;
+  }
   PASS(k_tension_normal);
   PASS(k_tension_accel);
   return WCSPH_OK;
@@ -1251,10 +1349,13 @@ int wcsph_neighbors_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, 
   NEED_GRID();
   if (i0 < 0 || n < 0 || i0 + n > ctx->d.nl || cap < 1 || !counts || !lists) return WCSPH_EARG;
   if (n == 0) return WCSPH_OK;
+  const bool exact = ctx->d.faithful && ctx->win_x1 < 0;   // the reference row itself, far aliased entries included (bucket.h)
+  if (exact) { int rc = bucket_build(ctx); if (rc) return rc; }
   int *dc = nullptr, *dl = nullptr;
   HIPCHK(hipMalloc((void **)&dc, (size_t)n * 4));
   HIPCHK(hipMalloc((void **)&dl, (size_t)n * cap * 4));
-  hipLaunchKernelGGL(k_neighbor_lists, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, i0, n, cap, dc, dl);
+  if (exact) hipLaunchKernelGGL(k_bk_rows, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->bk, i0, n, cap, dc, dl);
+  else hipLaunchKernelGGL(k_neighbor_lists, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, i0, n, cap, dc, dl);
   hipError_t e1 = hipMemcpyAsync(counts, dc, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e2 = hipMemcpyAsync(lists, dl, (size_t)n * cap * 4, hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e3 = hipStreamSynchronize(ctx->stream);
@@ -1400,8 +1501,8 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_DRHO_PRESS_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_PRESS(DRHO_ITER, dt); break;
     case WCSPH_PH_END_PRESS: ELEM(k_end_press, dt); break;
     case WCSPH_PH_CLEAR: ELEM(k_clear_nonpressure); break;
-    case WCSPH_PH_TENSION_NORMAL: PASS(k_tension_normal); break;
-    case WCSPH_PH_TENSION_ACCEL: PASS(k_tension_accel); break;
+    case WCSPH_PH_TENSION_NORMAL: if (ctx->p.tension_fixed == 0) return ctx->fail(WCSPH_EARG, "literal tension is not available phase by phase"); PASS(k_tension_normal); break;
+    case WCSPH_PH_TENSION_ACCEL: if (ctx->p.tension_fixed == 0) return ctx->fail(WCSPH_EARG, "literal tension is not available phase by phase"); PASS(k_tension_accel); break;
     case WCSPH_PH_VISC_GUESS: ELEM(k_visc_guess); break;
     case WCSPH_PH_VISC_MINV: PASS(k_visc_minv, dt); break;
     case WCSPH_PH_VISC_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_residual, dt); break;

@@ -36,13 +36,26 @@ class Field:
             raise ValueError("%s.from_numpy: expected shape %s, got %s" % (self.name, self._np_shape(), a.shape))
         _lib.check(ctx, _lib.load().wcsph_field_from_host(ctx, _lib.FIELD_ID[self.name], a.ctypes.data, a.nbytes))
 
+    def _row_ok(self, i):
+        return isinstance(i, (int, np.integer)) and self._ncomp in (1, 3) and 0 <= int(i) < self._owner.liquid_count
+
     def __getitem__(self, i):
-        return self.to_numpy()[i]
+        if not self._row_ok(i):          # slices, negative indices, solid rows of pos, matrices: whole-field path
+            return self.to_numpy()[i]
+        ctx = self._owner._need_ctx()
+        out = np.empty(self._ncomp, dtype=np.float32 if self.dtype != np.int32 else np.int32)
+        _lib.check(ctx, _lib.load().wcsph_field_rows_to_host(ctx, _lib.FIELD_ID[self.name], int(i), 1, out.ctypes.data))
+        return out if self._ncomp == 3 else out[0]
 
     def __setitem__(self, i, v):
-        a = self.to_numpy()
-        a[i] = v
-        self.from_numpy(a)
+        if not self._row_ok(i) or self.dtype == np.int32:
+            a = self.to_numpy()
+            a[i] = v
+            self.from_numpy(a)
+            return
+        ctx = self._owner._need_ctx()
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32), (self._ncomp,)))
+        _lib.check(ctx, _lib.load().wcsph_field_rows_from_host(ctx, _lib.FIELD_ID[self.name], int(i), 1, a.ctypes.data))
 
 
 class ScalarField:
