@@ -11,12 +11,16 @@ Rank 0 prints ONE JSON line: M particle-steps/s for the whole job, plus
   "roofline":     the north-star kernel pair `pressure_iter` (ref: dfsph.py:518-547) timed live with
                   HIP events on the context's stream, algorithmic bytes (84 + 24 s) B per liquid particle
                    over the 8 TB/s HBM peak,
-  "cpu_baseline": the reference-algorithm CPU restatement (oracle/, faithful mode, OpenMP) timed on this
-                  box's host cores on a bounded C2-size sample.
+  "cpu_baseline": the reference-algorithm CPU restatement (oracle/, faithful mode, OpenMP, gcc -O3
+                  -march=native) timed on this box's host cores on the SAME configuration (C3), 2 steps.
+`value` is the configuration's first steps (the column still at rest: the cheapest state of a dam break);
+config.developed_flow reports the same measurement after 1200 steps (collapsed, splashing).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,8 +41,16 @@ def build_sim(n, mode, **attrs):
     return dfsph, pd, time.time() - t0
 
 
-def cpu_baseline(n, steps):
-    """Reference-algorithm CPU restatement (oracle/wcsph_ref.c, faithful mode) on the host cores: all cores, and 1 thread."""
+def kernel_source_sha16():
+    """hash of the sources that define the pressure_iter kernels: a recorded PMC traffic figure is only quoted for them"""
+    h = hashlib.sha256()
+    for f in ("device.h", "dfsph_kernels.h", "grid.h"):
+        h.update(open(os.path.join(ROOT, "wcsph_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---- CPU baseline (child process: the baseline build of the oracle, its own 17 GB of tables) -------------------------
+def _cpu_child(n, steps, sweep, single):
     import oracle
     from oracle import Oracle
     from wcsph_amd import scene
@@ -48,32 +60,89 @@ def cpu_baseline(n, steps):
     o.reset_param()
     o.dfsph_step()  # first step pays the page faults of the 8 KiB/particle neighbour table
     maxt = oracle.get_max_threads()
-    # the loops of a C2-size scene are short: try a few team sizes, report the best one (and which)
-    sweep = {}
-    for th in sorted({maxt, 64, 32, 16} & set(range(1, maxt + 1)), reverse=True):
+    times = {}
+    for th in sorted({t for t in sweep if 1 <= t <= maxt} | {maxt}, reverse=True):
         oracle.set_num_threads(th)
         t0 = time.perf_counter()
         o.dfsph_step()
-        sweep[th] = time.perf_counter() - t0
-    cores = min(sweep, key=sweep.get)
+        times[th] = time.perf_counter() - t0
+    cores = min(times, key=times.get)
     oracle.set_num_threads(cores)
     t0 = time.perf_counter()
     for _ in range(steps):
         o.dfsph_step()
     dt = time.perf_counter() - t0
-    oracle.set_num_threads(1)
-    t1 = time.perf_counter()
-    o.dfsph_step()
-    dt1 = time.perf_counter() - t1
-    oracle.set_num_threads(maxt)
-    val = len(liquid) * steps / dt / 1e6
+    out = {"value": round(len(liquid) * steps / dt / 1e6, 4), "ms_per_step": round(dt / steps * 1e3, 1), "cores": cores,
+           "n_liquid": len(liquid), "n_solid": len(solid), "steps": steps, "host_threads_available": maxt,
+           "thread_sweep_ms": {str(k): round(v * 1e3, 1) for k, v in times.items()},
+           "iters_last_step": [o.vs_iter, o.dv_iter, o.pr_iter]}
+    if single:
+        oracle.set_num_threads(1)
+        t1 = time.perf_counter()
+        o.dfsph_step()
+        d1 = time.perf_counter() - t1
+        out["single_thread"] = {"value": round(len(liquid) / d1 / 1e6, 4), "ms_per_step": round(d1 * 1e3, 1), "steps": 1}
     o.close()
-    return {"value": round(val, 4), "unit": "M particle-steps/s", "cores": cores, "kind": "port",
-            "sample": "DFSPH dam break %d^3 = %d liquid + %d boundary particles (config C2 size), %d steps after 1 "
-                      "warm-up step, faithful neighbour mode, gcc -O2 -fopenmp" % (n, len(liquid), len(solid), steps),
-            "ms_per_step": round(dt / steps * 1e3, 2), "host_threads_available": maxt,
-            "thread_sweep_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
-            "single_thread": {"value": round(len(liquid) / dt1 / 1e6, 4), "ms_per_step": round(dt1 * 1e3, 1), "steps": 1}}
+    print("CPU_BASELINE_JSON " + json.dumps(out), flush=True)
+
+
+def _run_cpu_child(n, steps, sweep, single, timeout):
+    env = dict(os.environ, WCSPH_ORACLE_BASELINE="1")
+    code = "import bench; bench._cpu_child(%d, %d, %r, %r)" % (n, steps, list(sweep), bool(single))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % timeout}
+    for line in r.stdout.splitlines():
+        if line.startswith("CPU_BASELINE_JSON "):
+            return json.loads(line[len("CPU_BASELINE_JSON "):])
+    return {"error": (r.stderr or r.stdout)[-400:]}
+
+
+def cpu_baseline(n_main, n_small):
+    """Reference-algorithm CPU restatement (oracle/wcsph_ref.c, faithful mode, gcc -O3 -march=native -fopenmp, built on
+    this host) on the headline configuration; the C2-size sample of round 1 and a 1-thread figure ride along."""
+    nthreads = os.cpu_count() or 1
+    main = _run_cpu_child(n_main, 2, [nthreads, nthreads // 2, nthreads // 4], False, 900)
+    small = _run_cpu_child(n_small, 10, [nthreads, 64, 32, 16], True, 300)
+    if "error" in main:
+        return {"value": None, "unit": "M particle-steps/s", "cores": 0, "kind": "port", "sample": "failed: " + main["error"], "c2_sample": small}
+    return {"value": main["value"], "unit": "M particle-steps/s", "cores": main["cores"], "kind": "port",
+            "sample": "the headline workload itself: DFSPH dam break %d^3 = %d liquid + %d boundary particles (config C3), %d steps after 1 "
+                      "warm-up step and a %d-step thread sweep, faithful neighbour mode, gcc -O3 -march=native -fopenmp built on this host"
+                      % (n_main, main["n_liquid"], main["n_solid"], main["steps"], len(main["thread_sweep_ms"])),
+            "ms_per_step": main["ms_per_step"], "host_threads_available": main["host_threads_available"],
+            "thread_sweep_ms": main["thread_sweep_ms"], "iters_last_step": main["iters_last_step"], "c2_sample": small}
+
+
+# ---- timed legs ---------------------------------------------------------------------------------------------------
+def timed_steps(dfsph, pd, warmup, steps, tsync, fixed=None, profile=False):
+    from wcsph_amd import _lib
+    import ctypes as C
+    ctx, lib = pd._need_ctx(), _lib.load()
+    step = (lambda: dfsph.step_fixed(*fixed)) if fixed else dfsph.step
+    for _ in range(warmup):
+        step()
+    pd.sync(); tsync()
+    if profile:   # every pressure_iter launch group of the timed region is bracketed by HIP events on the context's stream
+        _lib.check(ctx, lib.wcsph_profile_begin(ctx, 16 * steps + 16))
+    iters = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        iters.append((dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter))
+    pd.sync(); tsync()
+    elapsed = time.perf_counter() - t0
+    out = {"elapsed": elapsed, "iters": np.array(iters, dtype=np.float64)}
+    if profile:
+        ms, n_launch = C.c_float(), C.c_int32()
+        _lib.check(ctx, lib.wcsph_profile_end(ctx, C.byref(ms), C.byref(n_launch)))
+        out["launch_ms"], out["launches"] = ms.value, n_launch.value
+    return out
+
+
+def leg(value_n, r, steps):
+    return {"value": round(value_n * steps / r["elapsed"] / 1e6, 3), "ms_per_step": round(r["elapsed"] / steps * 1e3, 3)}
 
 
 def main():
@@ -92,10 +161,11 @@ def _main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3", help="C2 | C3 | default | an integer particleDim")
     ap.add_argument("--mode", default="faithful", choices=["faithful", "clean"])
-    ap.add_argument("--cpu-steps", type=int, default=10)
-    ap.add_argument("--cpu-n", type=int, default=46)
+    ap.add_argument("--cpu-n", type=int, default=46, help="particleDim of the small CPU sample that rides along")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-clean", action="store_true", help="skip the clean-mode companion run")
+    ap.add_argument("--no-clean", action="store_true", help="skip the companion legs (clean mode, fixed iterations, C2, C5)")
+    ap.add_argument("--no-developed", action="store_true", help="skip the developed-flow leg (1200 untimed steps)")
+    ap.add_argument("--developed-after", type=int, default=1200)
     ap.add_argument("--kernel-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -121,21 +191,9 @@ def _main():
     except Exception:
         tsync = lambda: None  # noqa: E731
 
-    iters = []
-    for _ in range(args.warmup):
-        dfsph.step()
-    pd.sync(); tsync()
-    # every pressure_iter launch group of the timed region is bracketed by HIP events on the context's stream
-    _lib.check(ctx, lib.wcsph_profile_begin(ctx, 16 * args.steps + 16))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dfsph.step()
-        iters.append((dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter))
-    pd.sync(); tsync()
-    elapsed = time.perf_counter() - t0
-    ms, n_launch = C.c_float(), C.c_int32()
-    _lib.check(ctx, lib.wcsph_profile_end(ctx, C.byref(ms), C.byref(n_launch)))
+    r = timed_steps(dfsph, pd, args.warmup, args.steps, tsync, profile=True)
     nl, ns = pd.liquid_count, pd.solid_count
+    elapsed = r["elapsed"]
     value = nl * args.steps / elapsed / 1e6
 
     # the same kernel pair replayed back to back after the run (a replay finds more of its stream in the Infinity Cache)
@@ -143,97 +201,85 @@ def _main():
     _lib.check(ctx, lib.wcsph_time_kernel(ctx, b"pressure_iter", args.kernel_reps, C.byref(ms_replay)))
     s = ns / nl
     alg_bytes = (84.0 + 24.0 * s) * nl
-    achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+    achieved = alg_bytes / (r["launch_ms"] * 1e-3) / 1e9
     extra = {}
-    for name in ("pressure_vel_loop", "pressure_drho_loop", "divergence_iter", "density_coff", "grid_update", "visc_iter"):
+    for name in ("pressure_vel_loop", "pressure_drho_loop", "divergence_iter", "density_coff", "grid_update", "build_lists", "visc_iter"):
         m2 = C.c_float()
         _lib.check(ctx, lib.wcsph_time_kernel(ctx, name.encode(), max(args.kernel_reps // 2, 2), C.byref(m2)))
         extra[name + "_us"] = round(m2.value * 1e3, 1)
-    traffic = None
+    # HBM traffic of the pair from the PMC counters: recorded by tools/pmc_traffic.sh (rocprofv3 cannot run inside this
+    # process); quoted only if it was taken on THIS kernel source and THIS workload, otherwise null
+    traffic, traffic_note = None, "no PMC record for this kernel source (tools/pmc_traffic.sh)"
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tf):
         try:
             t = json.load(open(tf))
-            if t.get("n_liquid") == nl:
-                traffic = t.get("pressure_iter_bytes_per_launch")
+            if t.get("n_liquid") == nl and t.get("kernel_source_sha16") == kernel_source_sha16():
+                traffic, traffic_note = t.get("pressure_iter_bytes_per_launch"), t.get("source")
         except Exception:
             pass
-    it = np.array(iters, dtype=np.float64)
+    it = r["iters"]
     out = {
         "metric": "M particle-steps/sec, DFSPH dam-break", "value": round(value, 3), "unit": "M particle-steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "DFSPH 3D dam-break %s: %d^3 = %d liquid + %d boundary particles, CubicKernel, CFL dt, "
                                "viscosity PCG + vorticity on (reference defaults)" % (args.config, n, nl, ns),
+                   "state": "steps %d..%d from rest (column not yet collapsed: minimum iteration counts)" % (args.warmup + 1, args.warmup + args.steps),
                    "neighbor_mode": args.mode, "n_liquid": nl, "n_solid": ns,
                    "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)},
                    "dt_end": float(dfsph.deltaT[0]), "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "kernel": "pressure_iter as the fused solver launches it: k_vel_from_k (kappa += k) + k_drho_press<ITER> (k epilogue), ref dfsph.py:518-547",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "avg_launch_us": round(ms.value * 1e3, 1), "launches_timed": n_launch.value,
+                     "frac_is": "ALGORITHMIC bytes (84 + 24 s) B x n_liquid per launch / measured launch time / 8 TB/s",
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "traffic_frac": (round(traffic / (r["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                     "avg_launch_us": round(r["launch_ms"] * 1e3, 1), "launches_timed": r["launches"],
                      "timing": "HIP events around every launch group inside the timed steps", "replay_us": round(ms_replay.value * 1e3, 1),
-                     "algorithmic_bytes_per_launch": int(alg_bytes), "other_kernels": extra},
+                     "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_source_sha16": kernel_source_sha16(), "other_kernels": extra},
     }
     pd.close()
+    if not args.no_developed:
+        # the same workload after the column has collapsed (t ~ 1.1 s): longer lists, disordered neighbourhoods, a grid
+        # box that spans the whole domain -- what a production run spends its time in
+        dfd, pdd, _ = build_sim(n, args.mode)
+        for _ in range(args.developed_after):
+            dfd.step()
+        rd = timed_steps(dfd, pdd, 0, 20, tsync, profile=True)
+        out["config"]["developed_flow"] = dict(
+            leg(nl, rd, 20), after_steps=args.developed_after, t_sim=round(float(dfd.current_time), 3),
+            ratio_to_rest=round((rd["elapsed"] / 20) / (elapsed / args.steps), 2),
+            mean_iters={"vs": round(rd["iters"][:, 0].mean(), 2), "dv": round(rd["iters"][:, 1].mean(), 2), "pr": round(rd["iters"][:, 2].mean(), 2)},
+            pressure_iter_us=round(rd["launch_ms"] * 1e3, 1),
+            pressure_iter_frac=round(alg_bytes / (rd["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        pdd.close()
     if args.mode == "faithful" and not args.no_clean:
-        # the N > 1 slab runs use clean neighbour semantics: same workload, same step count, for a
-        # like-for-like reading of the multi-GPU numbers
+        # the N > 1 slab runs can use either neighbour semantics; clean mode for a like-for-like reading
         dfsph2, pd2, _ = build_sim(n, "clean")
-        for _ in range(args.warmup):
-            dfsph2.step()
-        pd2.sync(); tsync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            dfsph2.step()
-        pd2.sync(); tsync()
-        el2 = time.perf_counter() - t0
-        out["config"]["clean_mode"] = {"value": round(nl * args.steps / el2 / 1e6, 3), "ms_per_step": round(el2 / args.steps * 1e3, 3)}
+        out["config"]["clean_mode"] = leg(nl, timed_steps(dfsph2, pd2, args.warmup, args.steps, tsync), args.steps)
         pd2.close()
     if not args.no_clean:
         # equal-work micro-benchmark: fixed dv = 2, pr = 4, vs = 4 iterations per step
         d4, p4, _ = build_sim(n, args.mode)
-        for _ in range(max(args.warmup // 2, 2)):
-            d4.step_fixed(2, 4, 4)
-        p4.sync(); tsync()
-        t0 = time.perf_counter()
         nfix = max(args.steps // 2, 5)
-        for _ in range(nfix):
-            d4.step_fixed(2, 4, 4)
-        p4.sync(); tsync()
-        el4 = time.perf_counter() - t0
-        out["config"]["fixed_iters_dv2_pr4_vs4"] = {"value": round(nl * nfix / el4 / 1e6, 3), "ms_per_step": round(el4 / nfix * 1e3, 3), "steps": nfix}
+        out["config"]["fixed_iters_dv2_pr4_vs4"] = dict(leg(nl, timed_steps(d4, p4, max(args.warmup // 2, 2), nfix, tsync, fixed=(2, 4, 4)), nfix), steps=nfix)
         p4.close()
     if args.config == "C3" and not args.no_clean:
         # BASELINE.json configs[1] (C2, ~100 k particles) for reference: too small to fill 256 CUs, launch-bound
         d3, p3, _ = build_sim(scene.CONFIGS["C2"], args.mode)
-        for _ in range(args.warmup):
-            d3.step()
-        p3.sync(); tsync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            d3.step()
-        p3.sync(); tsync()
-        el3 = time.perf_counter() - t0
-        out["config"]["C2_100k"] = {"value": round(p3.liquid_count * args.steps / el3 / 1e6, 3), "ms_per_step": round(el3 / args.steps * 1e3, 3),
-                                    "n_liquid": p3.liquid_count}
+        out["config"]["C2_100k"] = dict(leg(p3.liquid_count, timed_steps(d3, p3, args.warmup, args.steps, tsync), args.steps), n_liquid=p3.liquid_count)
         p3.close()
-    if args.config == "C3" and not args.no_clean:
-        # BASELINE.json configs[4] (C5): 1 M particles with the Akinci surface tension switched on as well (the reference's
-        # default coefficients are 0, which skips both tension passes)
-        d5, p5, _ = build_sim(scene.CONFIGS["C5"], args.mode, tension_coff=0.05, tension_coff_b=0.05)
-        for _ in range(args.warmup):
-            d5.step()
-        p5.sync(); tsync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            d5.step()
-        p5.sync(); tsync()
-        el5 = time.perf_counter() - t0
-        out["config"]["C5_1M_tension"] = {"value": round(p5.liquid_count * args.steps / el5 / 1e6, 3), "ms_per_step": round(el5 / args.steps * 1e3, 3),
-                                          "n_liquid": p5.liquid_count, "tension_coff": 0.05, "tension_coff_b": 0.05}
+        # BASELINE.json configs[4] (C5): 1 M particles with the Akinci surface tension on (the reference ships 0.0 for both
+        # coefficients, which skips the passes) and the adhesion ball of the reference's sphere scene inside the liquid,
+        # so that the boundary term (dfsph.py:297-304, gated to that ball) does work; repaired normals (tension_fixed = 1)
+        liq5, sol5 = scene.dam_break_with_ball(scene.CONFIGS["C5"])
+        d5, p5, _ = build_sim(scene.CONFIGS["C5"], args.mode, liquid=liq5, boundary=sol5, tension_coff=0.05, tension_coff_b=0.05)
+        out["config"]["C5_1M_tension"] = dict(leg(p5.liquid_count, timed_steps(d5, p5, args.warmup, args.steps, tsync), args.steps),
+                                              n_liquid=p5.liquid_count, n_solid=p5.solid_count, tension_coff=0.05, tension_coff_b=0.05,
+                                              tension_semantics="fixed normals (tension_fixed=1); parity-tested against the oracle in both semantics")
         p5.close()
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(n, args.cpu_n)
     return out
 
 

@@ -254,8 +254,32 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms_per_
 /* Restrict the dense cell table to global cell columns [x0, x1) along x; call BEFORE wcsph_setup().  Cell
  * coordinates (and the reference hash) stay global, so every rank sees the same cells (HashGrid.py:68). */
 int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1);
-/* Replace the liquid set: d_rows is a DEVICE array [n_total][14] f32 = pos3 vel3 omega3 vel_guess3 kappa kappa_v
- * (the fields the reference carries across steps).  Rows [0,n_owned) are this rank's particles, the rest are
+/* Communication boundary of the decomposition (SURVEY 8(b) lists wcsph_comm_init / wcsph_halo_exchange): the library
+ * owns everything device-side of an exchange -- which rows travel, packing, unpacking, the bucket histogram -- and the
+ * driver owns the communicator (torch.distributed process group == RCCL, created by whoever launched the ranks, as
+ * bench.py's contract prescribes): between wcsph_halo_pack() and wcsph_halo_unpack() it moves ONE contiguous device
+ * buffer per neighbour with ncclSend/ncclRecv (INTEGRATION.md "Multi-GPU").
+ * Faithful neighbour mode on slabs: the reference hash table is global (HashGrid.py:108-114, `count` buckets), so
+ *  - params.hash_table_size = global particle count, wcsph_set_global_liquid() = global liquid count (CFL prefix, Q5),
+ *  - wcsph_set_owned_columns(): the global cell columns whose boundary particles THIS rank counts (each exactly once),
+ *  - wcsph_bucket_hist(which = 1): static boundary histogram, summed over ranks ONCE after wcsph_setup();
+ *    (which = 0): liquid histogram of the step, int32[n] on the device, summed over ranks between
+ *    wcsph_grid_update_begin() and wcsph_grid_update_end() (wcsph_grid_update() = both, for a single context). */
+int wcsph_set_owned_columns(wcsph_ctx *ctx, int32_t lo, int32_t hi);
+int wcsph_set_global_liquid(wcsph_ctx *ctx, int64_t n_liquid_global);
+int wcsph_grid_update_begin(wcsph_ctx *ctx);
+int wcsph_grid_update_end(wcsph_ctx *ctx);
+int wcsph_bucket_hist(wcsph_ctx *ctx, int which, void **d_ptr, int64_t *n);
+/* the per-step liquid histogram packed for the wire: two 16-bit counts per int32 word (an int32 SUM all-reduce adds the
+ * halves independently; half the bytes of the plain histogram); _unpack() after the all-reduce, before _grid_update_end() */
+int wcsph_bucket_hist_pack(wcsph_ctx *ctx, void **d_ptr, int64_t *n_words);
+int wcsph_bucket_hist_unpack(wcsph_ctx *ctx);
+/* rows d_idx[0..n) (original indices, device array) of n_fields fields (enum wcsph_field, vec3 / scalar) side by side:
+ * d_out / d_in is a device buffer [n][sum of widths] f32; one launch each */
+int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, void *d_out);
+int wcsph_halo_unpack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, const void *d_in);
+/* Replace the liquid set: d_rows is a DEVICE array [n_total][15] f32 = pos3 vel3 omega3 vel_guess3 kappa kappa_v gid
+ * (the fields the reference carries across steps + the particle's global id as int32 bits).  Rows [0,n_owned) are this rank's particles, the rest are
  * ghost copies: read as neighbours, never updated, excluded from reductions.  n_total <= params.n_liquid. */
 int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows);
 /* the same from two row blocks (owned rows, then ghost rows): saves the driver a concatenation of the whole state */

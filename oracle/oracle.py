@@ -13,6 +13,25 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "libwcsph_oracle.so")
 
+
+def _cpu_tag():
+    import hashlib
+    try:
+        txt = "".join(sorted(set(l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags")))))
+    except OSError:
+        txt = "unknown"
+    return hashlib.sha1(txt.encode()).hexdigest()[:10]
+
+
+def build_baseline():
+    """gcc -O3 -march=native -fopenmp build of the same restatement for bench.py's cpu_baseline leg, compiled on (and
+    named after) the CPU it runs on.  WCSPH_ORACLE_BASELINE=1 makes this process load it instead of the checker build."""
+    out = os.path.join(_HERE, "_build", "libwcsph_oracle_baseline_%s.so" % _cpu_tag())
+    srcs = [os.path.join(_HERE, f) for f in ("wcsph_ref.c", "poisson_ref.c", "mc_ref.c", "Makefile")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "baseline", "BASE_OUT=" + os.path.relpath(out, _HERE)])
+    return out
+
 _SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
             "tension_coff", "tension_coff_b", "VL0", "VS0", "liqiudMass", "searchR", "gridR", "invGridR", "rho_L0",
             "viscosity_err", "vorticity_coff", "viscosity_omega", "vorticity_init", "rho_err", "pci_coff"]
@@ -58,7 +77,7 @@ _lib = None
 def _load():
     global _lib
     if _lib is None:
-        lib = C.CDLL(build_oracle())
+        lib = C.CDLL(build_baseline() if os.environ.get("WCSPH_ORACLE_BASELINE") == "1" else build_oracle())
         lib.orc_create.restype = C.c_void_p
         lib.orc_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
         lib.orc_destroy.argtypes = [C.c_void_p]

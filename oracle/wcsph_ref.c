@@ -192,8 +192,8 @@ static inline void cell_of(const orc_ctx *c, v3 p, int *x, int *y, int *z) {
 }
 void orc_cell_of(const orc_ctx *c, int i, int *xyz) { cell_of(c, c->pos[i], xyz, xyz + 1, xyz + 2); }
 
-/* ref: HashGrid.py:56-106.  The bucket insert is done serially in index order (the
- * reference's slot order is atomic-schedule dependent, Q16; any order is "a" reference run). */
+/* ref: HashGrid.py:56-106.  Bucket slots end up in index order (the reference's slot order is
+ * atomic-schedule dependent, Q16; any order is "a" reference run). */
 void orc_update_grid(orc_ctx *c) {
   const int MIG = c->maxInGrid, MN = c->maxNeighbour;
   /* :58-64 full-table clears */
@@ -207,14 +207,37 @@ void orc_update_grid(orc_ctx *c) {
     c->neighborCount[i] = 0;
     for (int j = 0; j < MN; j++) c->neighbor[i * MN + j] = -1;
   }
-  /* :67-76 insert */
+  /* :67-76 insert.  Parallel: slots are claimed with an atomic add (as the reference's ti.atomic_add does), then every
+   * bucket is sorted by particle id, which is exactly what a serial insert in index order leaves behind.  Only when a
+   * bucket overflows does the order of arrival decide who is dropped: that case is redone serially. */
+  int ovf_grid = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ovf_grid)
   for (int i = 0; i < c->count; i++) {
     int x, y, z; cell_of(c, c->pos[i], &x, &y, &z);
     if (in_box(c, x, y, z)) {
       int h = cell_hash(c, x, y, z);
-      int old = c->gridCount[h]++;
-      if (old > MIG - 1) { c->gridCount[h] = MIG; c->overflow_grid++; }
+      int old = __atomic_fetch_add(&c->gridCount[h], 1, __ATOMIC_RELAXED);
+      if (old > MIG - 1) ovf_grid++;
       else c->grid[(long)h * MIG + old] = i;
+    }
+  }
+  if (ovf_grid) {   /* serial redo, index order (the first MIG particles of a bucket survive) */
+    for (long i = 0; i < (long)c->table_size; i++) { c->gridCount[i] = 0; for (int j = 0; j < MIG; j++) c->grid[i * MIG + j] = -1; }
+    for (int i = 0; i < c->count; i++) {
+      int x, y, z; cell_of(c, c->pos[i], &x, &y, &z);
+      if (in_box(c, x, y, z)) {
+        int h = cell_hash(c, x, y, z);
+        int old = c->gridCount[h]++;
+        if (old > MIG - 1) { c->gridCount[h] = MIG; c->overflow_grid++; }
+        else c->grid[(long)h * MIG + old] = i;
+      }
+    }
+  } else {
+#pragma omp parallel for schedule(static)
+    for (long h = 0; h < (long)c->table_size; h++) {
+      int n = c->gridCount[h];
+      int *g = c->grid + h * MIG;
+      for (int a = 1; a < n; a++) { int v = g[a], k = a - 1; while (k >= 0 && g[k] > v) { g[k + 1] = g[k]; k--; } g[k + 1] = v; }
     }
   }
   /* :79-106 neighbour lists, liquid particles only */

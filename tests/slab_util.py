@@ -25,7 +25,7 @@ _PH = {
 
 
 class OracleBackend:
-    def __init__(self, capacity, solid_local, bounds, window, particleR=0.025, device=None):
+    def __init__(self, capacity, solid_local, bounds, window, particleR=0.025, device=None, **_):
         self.solid = np.asarray(solid_local, np.float64).astype(np.float32)
         self.bounds, self.particleR = bounds, particleR
         self.device = torch.device("cpu")
@@ -42,6 +42,7 @@ class OracleBackend:
         o = Oracle(pos, len(r), self.particleR, mode="clean", maxNeighbour=640, bounds=(self.bounds[1], self.bounds[0]))
         o.vel[:] = r[:, 3:6]; o.omega[:] = r[:, 6:9]; o.vel_guess[:] = r[:, 9:12]
         o.kappa[:] = r[:, 12]; o.kappa_v[:] = r[:, 13]
+        self.gid = r[:n_owned, 14].copy()
         o.n_reduce = int(n_owned)
         o.deltaT = self.scal["deltaT"]
         o.avg_density_err = self.avg_density_err
@@ -49,7 +50,7 @@ class OracleBackend:
 
     def store_state(self):
         o, n = self.o, self.n_owned
-        r = np.concatenate([o.pos[:n], o.vel[:n], o.omega[:n], o.vel_guess[:n], o.kappa[:n, None], o.kappa_v[:n, None]], 1)
+        r = np.concatenate([o.pos[:n], o.vel[:n], o.omega[:n], o.vel_guess[:n], o.kappa[:n, None], o.kappa_v[:n, None], self.gid[:, None]], 1)
         return torch.from_numpy(np.ascontiguousarray(r, np.float32))
 
     def grid_update(self):
@@ -120,15 +121,17 @@ def split_scene(liquid, bounds, world, particleR=0.025):
     inv = np.float32(1.0 / (2 * particleR))
     cx = np.trunc((liquid[:, 0].astype(np.float32) - bounds[0][0]) * inv).astype(np.int64)
     nx = int(float(bounds[1][0] - bounds[0][0]) / (2 * particleR) + 1.0)
-    cuts = balanced_cuts(np.bincount(cx, minlength=nx), world)
-    parts = [liquid[(cx >= cuts[r]) & (cx < cuts[r + 1])] for r in range(world)]
-    return cuts, parts
+    from wcsph_amd.slab import MIN_SLAB
+    cuts = balanced_cuts(np.bincount(cx, minlength=nx), world, MIN_SLAB)
+    sel = [np.nonzero((cx >= cuts[r]) & (cx < cuts[r + 1]))[0] for r in range(world)]
+    split_scene.gids = sel                      # global id = index in the scene's liquid array
+    return cuts, [liquid[s] for s in sel]
 
 
 def match_rows(a, b):
-    """max position / velocity mismatch between two row sets after nearest-position matching"""
-    from scipy.spatial import cKDTree
+    """max position / velocity mismatch between two row sets, matched by the global particle id in column 14"""
     assert len(a) == len(b)
-    d, j = cKDTree(b[:, :3]).query(a[:, :3])
-    assert len(np.unique(j)) == len(a), "particles do not match one-to-one"
-    return float(d.max()), float(np.abs(a[:, 3:6] - b[j, 3:6]).max()), j
+    ia, ib = a[:, 14].copy().view(np.int32), b[:, 14].copy().view(np.int32)
+    assert len(np.unique(ia)) == len(a) and np.array_equal(np.sort(ia), np.sort(ib)), "particle ids do not match one-to-one"
+    a, b = a[np.argsort(ia)], b[np.argsort(ib)]
+    return float(np.abs(a[:, :3] - b[:, :3]).max()), float(np.abs(a[:, 3:6] - b[:, 3:6]).max()), np.argsort(ib)

@@ -27,11 +27,14 @@ def _hip_run(rank, world, port, outdir, n):
     liquid, solid, bounds = slab_util.test_scene(n)
     cuts, parts = slab_util.split_scene(liquid, bounds, world)
     sim = SlabSim(lambda **kw: HipBackend(**kw), parts[rank], solid, bounds, cuts, len(liquid), rank, world,
-                  device=dev, comm_device=torch.device("cpu"))
+                  device=dev, comm_device=torch.device("cpu"), gid_local=slab_util.split_scene.gids[rank],
+                  neighbor_mode=os.environ.get("SLAB_TEST_MODE", "clean"))
     sim.rows[:, 3] = VX
     torch.cuda.synchronize()
     log = []
-    for _ in range(STEPS):
+    for k in range(STEPS):
+        if world > 1 and k == int(os.environ.get("SLAB_TEST_REBALANCE_AT", "-1")):
+            assert sim.rebalance(force=True)
         sim.step()
         log.append((sim.vs_iter, sim.dv_iter, sim.pr_iter, float(sim.dt), sim.n_owned))
     torch.cuda.synchronize()
@@ -81,6 +84,46 @@ def test_hip_slab_two_ranks_match_one_rank(tmp_path):
     np.testing.assert_array_equal(l2[0][:, :3], l2[1][:, :3])
     assert (l2[0][:, 4] + l2[1][:, 4] == n ** 3).all()
     assert l2[0][0, 4] != l2[0][-1, 4]
+
+
+def test_faithful_slabs_reproduce_the_single_context(tmp_path):
+    """Faithful neighbour semantics across ranks: the reference's hash table is global (`count` buckets, HashGrid.py:114),
+    so every rank counts its owned liquid particles per bucket and the histogram is all-reduced each step (two 16-bit
+    counts per word), the static boundary histogram once; the CFL prefix (Q5) runs on global particle ids.  Two ranks
+    (with a forced rebalance on the way) must reproduce one rank, and one rank must reproduce the plain library step --
+    density to the north-star 1e-4."""
+    import slab_util
+    from test_slab_gloo import _free_port
+    from util import GpuSim
+    n, out = 10, str(tmp_path)
+    os.environ.update(SLAB_TEST_MODE="faithful", SLAB_TEST_REBALANCE_AT="3")
+    try:
+        _hip_run(0, 1, 0, out, n)
+        mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+    finally:
+        os.environ.pop("SLAB_TEST_MODE", None); os.environ.pop("SLAB_TEST_REBALANCE_AT", None)
+    one = np.load(os.path.join(out, "hrows_w1_r0.npy"))
+    two = np.concatenate([np.load(os.path.join(out, "hrows_w2_r%d.npy" % r)) for r in range(2)])
+    dpos, dvel, _ = slab_util.match_rows(one, two)
+    assert dpos < 5e-6 and dvel < 1e-3
+    l1 = np.load(os.path.join(out, "hlog_w1_r0.npy"))
+    l2 = np.load(os.path.join(out, "hlog_w2_r0.npy"))
+    np.testing.assert_array_equal(l1[:, :3], l2[:, :3])
+    np.testing.assert_allclose(l1[:, 3], l2[:, 3], rtol=1e-6)            # same dt history: the CFL prefix saw the same particles
+    # the plain library step on the same scene
+    liquid, solid, bounds = slab_util.test_scene(n)
+    g = GpuSim(liquid, solid, mode="faithful")
+    g.call("dfsph_reset_param")
+    v = np.zeros((len(liquid), 3), np.float32); v[:, 0] = VX
+    g.pd.vel.from_numpy(v)
+    for _ in range(STEPS):
+        g.call("dfsph_step")
+    pos = g.pd.pos.to_numpy()[:len(liquid)]
+    order = np.argsort(one[:, 14].copy().view(np.int32))
+    assert np.abs(one[order, :3] - pos).max() < 5e-6
+    assert np.abs(one[order, 3:6] - g.pd.vel.to_numpy()).max() < 1e-3
+    assert g.iters() == tuple(int(x) for x in l1[-1, :3])
+    g.close()
 
 
 def test_overlapped_halo_exchange_changes_nothing(tmp_path):

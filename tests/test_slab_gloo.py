@@ -35,10 +35,13 @@ def _run(rank, world, port, outdir, n):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     liquid, solid, bounds = slab_util.test_scene(n)
     cuts, parts = slab_util.split_scene(liquid, bounds, world)
-    sim = SlabSim(lambda **kw: slab_util.OracleBackend(**kw), parts[rank], solid, bounds, cuts, len(liquid), rank, world)
+    sim = SlabSim(lambda **kw: slab_util.OracleBackend(**kw), parts[rank], solid, bounds, cuts, len(liquid), rank, world,
+                  gid_local=slab_util.split_scene.gids[rank])
     sim.rows[:, 3] = VX
     log = []
-    for _ in range(STEPS):
+    for k in range(STEPS):
+        if world > 1 and k == int(os.environ.get("SLAB_TEST_REBALANCE_AT", "-1")):
+            assert sim.rebalance(force=True)
         sim.step()
         log.append((sim.vs_iter, sim.dv_iter, sim.pr_iter, float(sim.dt), sim.n_owned))
     np.save(os.path.join(outdir, "rows_w%d_r%d.npy" % (world, rank)), sim.rows.numpy())
@@ -69,6 +72,31 @@ def test_two_ranks_match_one_rank(tmp_path):
     assert l2[0][0, 4] != l2[0][-1, 4]                              # and ownership really migrated
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_rebalanced_cuts_change_nothing(tmp_path, world):
+    """SlabSim.rebalance(): new cuts from the all-reduced column histogram, rows routed to their new owners, backends
+    rebuilt -- mid-run, after the block has started to move; the trajectory is the 1-rank one."""
+    import slab_util
+    n = 10
+    out = str(tmp_path)
+    _run(0, 1, 0, out, n)
+    os.environ["SLAB_TEST_REBALANCE_AT"] = "3"
+    try:
+        mp.spawn(_run, args=(world, _free_port(), out, n), nprocs=world, join=True)
+    finally:
+        os.environ.pop("SLAB_TEST_REBALANCE_AT", None)
+    one = np.load(os.path.join(out, "rows_w1_r0.npy"))
+    many = np.concatenate([np.load(os.path.join(out, "rows_w%d_r%d.npy" % (world, r))) for r in range(world)])
+    assert len(one) == len(many) == n ** 3
+    dpos, dvel, _ = slab_util.match_rows(one, many)
+    assert dpos < 2e-6 and dvel < 2e-4
+    l1 = np.load(os.path.join(out, "log_w1_r0.npy"))
+    lw = [np.load(os.path.join(out, "log_w%d_r%d.npy" % (world, r))) for r in range(world)]
+    for l in lw:
+        np.testing.assert_array_equal(l1[:, :3], l[:, :3])
+    assert (sum(l[:, 4] for l in lw) == n ** 3).all()
+
+
 def test_single_rank_slab_equals_plain_oracle_step(tmp_path):
     """world = 1: the phase-by-phase choreography is the reference main-loop body."""
     import slab_util
@@ -95,4 +123,6 @@ def test_balanced_cuts():
     assert balanced_cuts(hist, 2) == [0, 6, 12]
     assert balanced_cuts(hist, 4) == [0, 4, 6, 8, 12]
     c = balanced_cuts(np.array([100, 0, 0, 0, 0, 0]), 3)
-    assert c[0] == 0 and c[-1] == 6 and all(b - a >= 2 for a, b in zip(c[:-1], c[1:-1]))
+    assert c[0] == 0 and c[-1] == 6 and all(b - a >= 2 for a, b in zip(c[:-1], c[1:]))
+    c = balanced_cuts(np.r_[np.zeros(30), 50 * np.ones(4), np.zeros(30)].astype(int), 4, 6)    # SlabSim's minimum slab width
+    assert c[0] == 0 and c[-1] == 64 and all(b - a >= 6 for a, b in zip(c[:-1], c[1:]))

@@ -7,7 +7,7 @@ import torch
 from wcsph_amd.slab import SlabSim, HipBackend, dam_break_slab
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 126
-liquid, solid, bounds, cuts, ng = dam_break_slab(n, 0, 1)
+liquid, solid, bounds, cuts, ng, gid = dam_break_slab(n, 0, 1)
 dev = torch.device("cuda", 0)
 sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, cuts, ng, 0, 1, device=dev)
 for _ in range(10):

@@ -73,7 +73,8 @@ OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_c
          "wcsph_load_state", "wcsph_load_state_split", "wcsph_store_state", "wcsph_get_acc", "wcsph_set_acc", "wcsph_phase", "wcsph_set_part", "wcsph_set_acc_buffer",
          "wcsph_surface_anisotropic_kernel", "wcsph_dfsph_step_fixed", "wcsph_sample_surface", "wcsph_mc_tables",
          "wcsph_mc_setup", "wcsph_mc_surface_value", "wcsph_mc_value_to_host", "wcsph_mc_marching_cube", "wcsph_canvas_draw",
-         "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
+         "wcsph_set_owned_columns", "wcsph_set_global_liquid", "wcsph_grid_update_begin", "wcsph_grid_update_end", "wcsph_bucket_hist", "wcsph_bucket_hist_pack", "wcsph_bucket_hist_unpack",
+         "wcsph_halo_pack", "wcsph_halo_unpack", "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
 ALL_SYMBOLS = CTX_ONLY + OTHER
 
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
@@ -136,6 +137,15 @@ def load():
     lib.wcsph_mc_setup.argtypes = [vp, C.c_double, C.c_double, vp, vp, vp]
     lib.wcsph_mc_value_to_host.argtypes = [vp, vp, C.c_int64]
     lib.wcsph_mc_marching_cube.argtypes = [vp, C.c_float, vp, C.c_int32, C.POINTER(C.c_int32)]
+    lib.wcsph_set_owned_columns.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.wcsph_set_global_liquid.argtypes = [vp, C.c_int64]
+    lib.wcsph_grid_update_begin.argtypes = [vp]
+    lib.wcsph_grid_update_end.argtypes = [vp]
+    lib.wcsph_bucket_hist.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.wcsph_bucket_hist_pack.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.wcsph_bucket_hist_unpack.argtypes = [vp]
+    lib.wcsph_halo_pack.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
+    lib.wcsph_halo_unpack.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
     lib.wcsph_hashgrid_count_to_host.argtypes = [vp, vp, C.c_int64]
     lib.wcsph_hashgrid_rows_to_host.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.wcsph_field_rows_to_host.argtypes = [vp, C.c_int, C.c_int32, C.c_int32, vp]

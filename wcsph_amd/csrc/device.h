@@ -23,6 +23,7 @@ struct Dev {
   // the particles between two neighbouring outer tile planes -- the largest delta of a neighbour stream -- are few)
   int perm, nt0, nt1, nt2, ncell_p;   // tiles per axis, padded cell count (= index of the out-of-box bin)
   int x0;          // first global cell column of this context's window (slab decomposition); 0 otherwise
+  int own_lo, own_hi;   // global cell columns this context OWNS (bucket histogram); [0, inf) without a decomposition
   // slab halo/compute overlap: 0 = every owned particle; 1 = only those in global cell columns [part_x0, part_x1)
   // (the interior: no ghost within their 5^3 cells); 2 = only the others (see part_ok)
   int part_mode, part_x0, part_x1;
@@ -47,6 +48,7 @@ struct Dev {
   float *kappa, *kappa_v;                 // persistent
   int *oid;                               // sorted -> original index
   int *where;                             // original -> sorted index
+  int *gid;                               // slab decomposition: GLOBAL particle id of row o (nullptr: the row index is the id)
   float4 *d_vel, *d_omega, *normal, *cg_r, *cg_dir, *cg_Ad, *cg_s;
   float4 *minv0, *minv1, *minv2;          // rows of cg_Minv
   float *rho, *adv_rho, *pressure, *vel_max, *alpha, *kbuf;

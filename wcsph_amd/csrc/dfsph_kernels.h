@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(BLOCK) k_cfl(Dev d, float dt) {
     float m = fmaxf(dot3(v, v), 0.1f);
     d.vel_max[i] = m;
     int o = d.oid[i];
-    if (o < d.cfl_prefix && o < d.n_owned) vm = m;
+    if (o < d.n_owned && (d.gid ? d.gid[o] : o) < d.cfl_prefix) vm = m;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_down(vm, o, WAVE));
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(BLOCK) k_finish_nonpressure(Dev d, float dt) {
     const float3 vn = v + a * dt;
     const float m = fmaxf(dot3(vn, vn), 0.1f);
     d.vel_max[i] = m;
-    if (o < d.cfl_prefix && o < d.n_owned) vm = m;
+    if (o < d.n_owned && (d.gid ? d.gid[o] : o) < d.cfl_prefix) vm = m;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_down(vm, o, WAVE));

@@ -27,7 +27,7 @@ __device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin, boo
 // phase 1 of the counting sort (ref: HashGrid.py:67-76 "insert pos"): cell of every particle, slot in cell.
 // bbox != nullptr: also this block's bounding box of the occupied cells -> bbox[6 * blockIdx.x ..] (no atomics: the
 // particles are x-sorted, so a shared max would be raised by nearly every block); k_bbox_final reduces them.
-__global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox) {
+__global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox, int count_limit) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
   if (i < n) {
@@ -40,7 +40,12 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
     pw[i] = w;
     slot[i] = atomicAdd(&cnt[lin], 1);
     if (w >= 0) {
-      if (bcount) atomicAdd(&bcount[ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+      // reference bucket occupancy: every particle is counted ONCE across the ranks of a slab decomposition -- liquid
+      // particles by their owner (ghost rows sit behind the owned ones before the sort), boundary particles by the rank
+      // whose owned columns hold them (own_lo <= global cell x < own_hi)
+      const int gx = (w & 1023) + d.x0;
+      if (bcount && i < count_limit && gx >= d.own_lo && gx < d.own_hi)
+        atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
       lo[0] = hi[0] = w & 1023; lo[1] = hi[1] = (w >> 10) & 1023; lo[2] = hi[2] = w >> 20;
     }
   }
@@ -210,6 +215,22 @@ __global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, c
   for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
 }
 
+// slab decomposition, faithful mode: the per-step liquid histogram travels as two 16-bit counts per int32 word (an int32
+// SUM all-reduce adds both halves independently while every global count stays below 65536; RCCL has no 16-bit integer)
+__global__ void k_hist_pack16(const int *l, int T, int *packed) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * w >= T) return;
+  const int a = min(l[2 * w], 0xffff), b = (2 * w + 1 < T) ? min(l[2 * w + 1], 0xffff) : 0;
+  packed[w] = a | (b << 16);
+}
+__global__ void k_hist_unpack16(const int *packed, int T, int *l) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * w >= T) return;
+  const unsigned v = (unsigned)packed[w];
+  l[2 * w] = (int)(v & 0xffffu);
+  if (2 * w + 1 < T) l[2 * w + 1] = (int)(v >> 16);
+}
+
 // ---- static per-cell info ---------------------------------------------------------------
 // bit0: any solid particle inside the 5x5x5 walk of this cell (lets bulk particles skip the solid walk)
 __global__ void k_cell_solid_near(Dev d, int *cell_info) {
@@ -304,10 +325,14 @@ __global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags, co
     cellval[c] = bcount[ref_hash(cx + d.x0, cy, cz, d.table_size)];
   }
 }
-// bucket occupancy over ALL buckets (the cap applies to every bucket, not only walked ones)
-__global__ void k_bucket_cap(Dev d, const int *bcount, int *flags) {
+// gridCount = static boundary particles + this step's liquid particles (both global sums on a slab decomposition);
+// the cap applies to every bucket, not only walked ones
+__global__ void k_bucket_sum(Dev d, const int *bs, const int *bl, int *bcount, int *flags) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < d.table_size && bcount[b] > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
+  if (b >= d.table_size) return;
+  const int v = bs[b] + bl[b];
+  bcount[b] = v;
+  if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
 }
 __global__ void k_boxsum(Dev d, const int *in, int *out, int len, int stride, const int *bb, int mx, int my) {
   // 5-tap sum along one axis; len = cells along the axis, stride = element stride of the axis
@@ -393,9 +418,9 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
 }
 
 // ---- slab decomposition: whole-state load / store in original (row) order -----------------------
-#define STATE_W 14
-// A row is 14 floats = 56 bytes: read or written straight from a lane it is a 56-byte-stride access (1.5 TB/s); the
-// 256 rows of a block are one contiguous 14 KB piece, so they go through LDS with fully coalesced global accesses.
+#define STATE_W 15   /* pos3 vel3 omega3 vel_guess3 kappa kappa_v + the global particle id (int bits) */
+// A row is 15 floats = 60 bytes: read or written straight from a lane it is a 60-byte-stride access (1.5 TB/s); the
+// 256 rows of a block are one contiguous 15 KB piece, so they go through LDS with fully coalesced global accesses.
 __global__ void __launch_bounds__(BLOCK) k_load_state(Dev d, const float *rows, int n, int first) {   // rows[t] -> particle first + t
   __shared__ float sh[BLOCK * STATE_W];
   const int t0 = blockIdx.x * BLOCK, cnt = min(BLOCK, n - t0);
@@ -411,6 +436,7 @@ __global__ void __launch_bounds__(BLOCK) k_load_state(Dev d, const float *rows, 
   d.vel_guess[i] = make_float4(r[9], r[10], r[11], 0);
   d.kappa[i] = r[12];
   d.kappa_v[i] = r[13];
+  if (d.gid) d.gid[i] = __float_as_int(r[14]);
   d.oid[i] = i;
   d.where[i] = i;
 }
@@ -424,6 +450,7 @@ __global__ void __launch_bounds__(BLOCK) k_store_state(Dev d, float *rows) {   /
     const float4 p = d.pos[i], v = d.vel[i], w = d.omega[i], g = d.vel_guess[i];
     r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = v.x; r[4] = v.y; r[5] = v.z; r[6] = w.x; r[7] = w.y; r[8] = w.z;
     r[9] = g.x; r[10] = g.y; r[11] = g.z; r[12] = d.kappa[i]; r[13] = d.kappa_v[i];
+    r[14] = __int_as_float(d.gid ? d.gid[o0 + threadIdx.x] : o0 + (int)threadIdx.x);
   }
   __syncthreads();
   float *dst = rows + (size_t)o0 * STATE_W;
@@ -456,7 +483,25 @@ __global__ void k_permute1(float *f, const int *where, int n, const float *in) {
   if (o >= n) return;
   f[where[o]] = in[o];
 }
-// rows by explicit ORIGINAL index list (halo pack / unpack)
+// halo pack / unpack of SEVERAL fields in one launch: out[k][W] = the listed fields of original row idx[k], side by side
+struct HaloFields { int n; const float *ptr[8]; int width[8], stride[8]; int W; };
+__global__ void k_halo_pack(HaloFields h, const int *where, const int *idx, int n, float *out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * h.W) return;
+  const int k = t / h.W;
+  int c = t % h.W, f = 0;
+  while (c >= h.width[f]) { c -= h.width[f]; f++; }
+  out[t] = h.ptr[f][(size_t)where[idx[k]] * h.stride[f] + c];
+}
+__global__ void k_halo_unpack(HaloFields h, const int *where, const int *idx, int n, const float *in) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * h.W) return;
+  const int k = t / h.W;
+  int c = t % h.W, f = 0;
+  while (c >= h.width[f]) { c -= h.width[f]; f++; }
+  const_cast<float *>(h.ptr[f])[(size_t)where[idx[k]] * h.stride[f] + c] = in[t];
+}
+// rows by explicit ORIGINAL index list (single field)
 __global__ void k_gather_rows3(const float4 *f, const int *where, const int *idx, int n, float *out) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;

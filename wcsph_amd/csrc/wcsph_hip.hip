@@ -34,7 +34,7 @@ struct wcsph_ctx {
   int *oid_b = nullptr;
   // grid scratch
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
-  int *bcount = nullptr, *bcount_s = nullptr, *cellval = nullptr, *celltmp = nullptr;
+  int *bcount = nullptr, *bcount_s = nullptr, *bcount_l = nullptr, *cellval = nullptr, *celltmp = nullptr;   // gridCount = _s (static solids) + _l (liquid, per step)
   int *bbox_part = nullptr;
   int n_alias = 0, scan_blocks = 0;
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
@@ -186,6 +186,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   Dev &d = ctx->d;
   memset(&d, 0, sizeof d);
   d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
+  d.own_lo = 0; d.own_hi = 0x7fffffff;
   ctx->capacity = p->n_liquid;
   d.faithful = (p->neighbor_mode == WCSPH_MODE_FAITHFUL);
   d.table_size = p->hash_table_size > 0 ? p->hash_table_size : (p->n_liquid + p->n_solid);
@@ -300,6 +301,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   const long ncell_p = ((long)d.nt0 * d.nt1 * d.nt2) << TILE_SHIFT;
   if (ncell_p > 0x7fff0000L) return ctx->fail(WCSPH_EARG, "grid has too many cells");
   d.ncell = (int)ncell; d.ncell_p = (int)ncell_p;
+  if (ctx->win_x1 >= 0) DALLOC(d.gid, (size_t)ctx->capacity + 1);   // slab rows carry their global particle id
   d.minx = minb[0]; d.miny = minb[1]; d.minz = minb[2];
   const int nscan = d.ncell_p + 2;
   ctx->scan_blocks = ((nscan > d.table_size + 2 ? nscan : d.table_size + 2) + SCAN_TILE - 1) / SCAN_TILE;   // also scans the bucket table (bucket.h)
@@ -307,7 +309,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   DALLOC(d.cell_info, d.ncell_p);
   DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1));
   if (d.faithful) {
-    DALLOC(ctx->bcount, d.table_size + 1); DALLOC(ctx->bcount_s, d.table_size + 1);   // [T] stays 0: the scan's end sentinel
+    DALLOC(ctx->bcount, d.table_size + 1); DALLOC(ctx->bcount_s, d.table_size + 1); DALLOC(ctx->bcount_l, d.table_size + 1);   // [T] stays 0: the scan's end sentinel
     DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->celltmp, d.ncell);
   }
   // liquids: identity order until the first grid update
@@ -334,7 +336,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
     HIPCHK(hipMemcpyAsync(spos_in, tmp.data(), (size_t)d.ns * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->cnt, 0, (size_t)nscan * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.ns)), dim3(BLOCK), 0, ctx->stream, d, (const float4 *)spos_in, d.ns, ctx->cnt,
-                       ctx->pw, ctx->slot, d.faithful ? ctx->bcount_s : (int *)nullptr, (int *)nullptr);
+                       ctx->pw, ctx->slot, d.faithful ? ctx->bcount_s : (int *)nullptr, (int *)nullptr, d.ns);
     LAUNCHCHK();
     int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_s, nullptr, 1);   // leaves the counters zeroed for the liquid updates
     if (rc) return rc;
@@ -375,8 +377,8 @@ int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]) {
 }
 
 // ---- HashGrid.update_grid -------------------------------------------------------------------
-int wcsph_grid_update(wcsph_ctx *ctx) {
-  NEED_SETUP();
+// first half: cells, counting sort, this context's share of the reference bucket histogram (owned liquid particles)
+static int grid_begin(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
@@ -384,10 +386,10 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   // overflow / non-finite conditions are re-detected by every update: what the previous one raised has been reported by
   // the pull_scalars() calls of its step and must not stick to the context (the reference prints and keeps stepping)
   HIPCHK(hipMemsetAsync(d.flags + FLAG_ERR, 0, sizeof(int), s));
-  if (d.faithful) HIPCHK(hipMemcpyAsync(ctx->bcount, ctx->bcount_s, (size_t)d.table_size * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (d.faithful) HIPCHK(hipMemsetAsync(ctx->bcount_l, 0, (size_t)d.table_size * sizeof(int), s));
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
-                       d.faithful ? ctx->bcount : (int *)nullptr, ctx->bbox_part);
+                       d.faithful ? ctx->bcount_l : (int *)nullptr, ctx->bbox_part, d.n_owned);
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
@@ -400,10 +402,16 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
     std::swap(d.omega, ctx->omega_b); std::swap(d.kappa, ctx->kappa_b); std::swap(d.kappa_v, ctx->kappa_v_b);
     std::swap(d.oid, ctx->oid_b); std::swap(d.pressure, ctx->pressure_b);
   }
-  // raw neighbour-list length (HashGrid.neighborCount)
+  LAUNCHCHK();
+  return 0;
+}
+// second half: raw neighbour-list length (HashGrid.neighborCount) from the GLOBAL bucket occupancy, compact lists
+static int grid_end(wcsph_ctx *ctx) {
+  Dev &d = ctx->d;
+  hipStream_t s = ctx->stream;
   if (d.faithful) {
     const int *bb = d.bbox;
-    hipLaunchKernelGGL(k_bucket_cap, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, d.flags);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, (const int *)ctx->bcount_l, ctx->bcount, d.flags);
     // separable 5x5x5 box sum of gridCount[hash(cell)] on the occupied box: values on box +-2 in every axis, the z pass
     // on box +-2 in x and y, the y pass on box +-2 in x, the x pass on the box itself
     hipLaunchKernelGGL(k_cellval, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags, bb);
@@ -414,12 +422,46 @@ int wcsph_grid_update(wcsph_ctx *ctx) {
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
   }
-  if (d.nl > 0) {
-    hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
-  }
+  if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
   LAUNCHCHK();
   ctx->grid_valid = true;
   ctx->bk_valid = false;
+  return WCSPH_OK;
+}
+int wcsph_grid_update(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  int rc = grid_begin(ctx);
+  if (rc) return rc;
+  return grid_end(ctx);
+}
+// slab decomposition, faithful neighbour mode: the drivers all-reduce the liquid bucket histogram between the halves
+int wcsph_grid_update_begin(wcsph_ctx *ctx) { NEED_SETUP(); ctx->grid_valid = false; return grid_begin(ctx); }
+int wcsph_grid_update_end(wcsph_ctx *ctx) { NEED_SETUP(); return grid_end(ctx); }
+int wcsph_bucket_hist_pack(wcsph_ctx *ctx, void **d_ptr, int64_t *n_words) {   // liquid histogram, two 16-bit counts per word
+  NEED_SETUP();
+  if (!d_ptr || !n_words) return WCSPH_EARG;
+  if (!ctx->d.faithful) return ctx->fail(WCSPH_EARG, "the bucket histogram exists in faithful neighbour mode only");
+  const int T = ctx->d.table_size, W = (T + 1) / 2;
+  hipLaunchKernelGGL(k_hist_pack16, dim3(nblk(W)), dim3(BLOCK), 0, ctx->stream, (const int *)ctx->bcount_l, T, ctx->bcount);   // bcount is rebuilt by grid_end
+  LAUNCHCHK();
+  *d_ptr = ctx->bcount; *n_words = W;
+  return WCSPH_OK;
+}
+int wcsph_bucket_hist_unpack(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  if (!ctx->d.faithful) return ctx->fail(WCSPH_EARG, "the bucket histogram exists in faithful neighbour mode only");
+  const int T = ctx->d.table_size, W = (T + 1) / 2;
+  // unpack through celltmp-free path: bcount holds the summed words, bcount_l receives the global counts
+  hipLaunchKernelGGL(k_hist_unpack16, dim3(nblk(W)), dim3(BLOCK), 0, ctx->stream, (const int *)ctx->bcount, T, ctx->bcount_l);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_bucket_hist(wcsph_ctx *ctx, int which, void **d_ptr, int64_t *n) {
+  NEED_SETUP();
+  if (!d_ptr || !n || which < 0 || which > 1) return WCSPH_EARG;
+  if (!ctx->d.faithful) return ctx->fail(WCSPH_EARG, "the bucket histogram exists in faithful neighbour mode only");
+  *d_ptr = which ? ctx->bcount_s : ctx->bcount_l;
+  *n = ctx->d.table_size;
   return WCSPH_OK;
 }
 
@@ -1416,6 +1458,51 @@ int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1) {
   if (!ctx || x1 <= x0) return WCSPH_EARG;
   if (ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_set_cell_window() must precede wcsph_setup()");
   ctx->win_x0 = x0; ctx->win_x1 = x1;
+  return WCSPH_OK;
+}
+int wcsph_set_owned_columns(wcsph_ctx *ctx, int32_t lo, int32_t hi) {
+  if (!ctx || hi <= lo) return WCSPH_EARG;
+  if (ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_set_owned_columns() must precede wcsph_setup()");
+  ctx->d.own_lo = lo; ctx->d.own_hi = hi;
+  return WCSPH_OK;
+}
+int wcsph_set_global_liquid(wcsph_ctx *ctx, int64_t n_liquid_global) {   // Q5: the CFL prefix is defined on GLOBAL particle ids
+  if (!ctx || n_liquid_global < 0) return WCSPH_EARG;
+  ctx->d.cfl_prefix = 0x7fffffff;
+  if (ctx->d.faithful && n_liquid_global > 1) { long s = 1; while (s * 2 < n_liquid_global) s *= 2; ctx->d.cfl_prefix = (int)(s > 0x7fffffffL ? 0x7fffffffL : s); }
+  return WCSPH_OK;
+}
+// halo pack / unpack: several fields of the rows idx[0..n) side by side in one buffer, one launch each way
+static int halo_fields(wcsph_ctx *ctx, int nf, const int32_t *fields, HaloFields *h) {
+  if (nf < 1 || nf > 8 || !fields) return ctx->fail(WCSPH_EARG, "halo: 1..8 fields");
+  h->n = nf; h->W = 0;
+  for (int k = 0; k < nf; k++) {
+    FieldDesc fd = field_desc(ctx, fields[k]);
+    if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "halo: vec3 / scalar fields only");
+    h->ptr[k] = (const float *)fd.ptr; h->width[k] = fd.kind == 3 ? 3 : 1; h->stride[k] = fd.kind == 3 ? 4 : 1;
+    h->W += h->width[k];
+  }
+  return 0;
+}
+int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, void *d_out) {
+  NEED_SETUP();
+  HaloFields h;
+  int rc = halo_fields(ctx, n_fields, fields, &h);
+  if (rc) return rc;
+  if (n <= 0) return WCSPH_OK;
+  hipLaunchKernelGGL(k_halo_pack, dim3(nblk(n * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, d_idx, n, (float *)d_out);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_halo_unpack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, const void *d_in) {
+  NEED_SETUP();
+  HaloFields h;
+  int rc = halo_fields(ctx, n_fields, fields, &h);
+  if (rc) return rc;
+  if (n <= 0) return WCSPH_OK;
+  hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(n * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, d_idx, n, (const float *)d_in);
+  LAUNCHCHK();
+  for (int k = 0; k < n_fields; k++) if (fields[k] == WCSPH_F_POS) ctx->grid_valid = false;
   return WCSPH_OK;
 }
 int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows) {

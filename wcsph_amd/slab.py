@@ -27,21 +27,34 @@ import torch.distributed as dist
 
 from . import _lib, scene
 
-STATE_W = 14  # pos3 vel3 omega3 vel_guess3 kappa kappa_v  (the fields the reference carries across steps)
+STATE_W = 15  # pos3 vel3 omega3 vel_guess3 kappa kappa_v (the fields the reference carries across steps) + global id (int bits)
 GHOST_CELLS = 2  # support h = 2 hash cells (HashGrid.py:18: searchR = 2 * gridR)
+MIN_SLAB = 2 * GHOST_CELLS + 2  # cell columns: a particle that has just crossed one cut is never within reach of the other
+FIELD_W = {"vel": 3, "vel_guess": 3, "cg_dir": 3, "omega": 3, "normal": 3}   # everything else is a scalar
+
+
+class _DevArray:
+    """device memory owned by the library, presented to torch (zero copy) through the CUDA array interface"""
+
+    def __init__(self, ptr, n, typestr="<i4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 # ---------------------------------------------------------------------------------------------------------
 class HipBackend:
     """Compute backend of one rank: a libwcsph_hip.so context with a slab-local cell window."""
 
-    def __init__(self, capacity, solid_local, bounds, window, particleR=0.025, device=None, **attrs):
+    def __init__(self, capacity, solid_local, bounds, window, particleR=0.025, device=None, neighbor_mode="clean",
+                 owned=None, n_global=(0, 0), **attrs):
         from .ParticleData import ParticleData
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.load()
-        pd = ParticleData(particleR, neighbor_mode="clean")
+        self.faithful = neighbor_mode == "faithful"
+        pd = ParticleData(particleR, neighbor_mode=neighbor_mode)
         for k, v in attrs.items():
             setattr(pd, k, v)
+        if self.faithful:   # the reference hash table has `count` buckets: the GLOBAL particle count (HashGrid.py:114)
+            pd.hash_table_size = int(n_global[0]) + int(n_global[1])
         # capacity rows of liquid; positions are loaded per step (load_state)
         pd.liquid_count = pd.count = int(capacity)
         pd._chunks = [np.zeros((int(capacity), 3))]
@@ -51,6 +64,10 @@ class HipBackend:
         pd.setup_data_gpu()
         self.ctx = pd._need_ctx()
         _lib.check(self.ctx, self.lib.wcsph_set_cell_window(self.ctx, int(window[0]), int(window[1])))
+        if owned is not None:
+            _lib.check(self.ctx, self.lib.wcsph_set_owned_columns(self.ctx, int(owned[0]), int(owned[1])))
+        if self.faithful:
+            _lib.check(self.ctx, self.lib.wcsph_set_global_liquid(self.ctx, int(n_global[0])))
         # one HIP stream for everything this rank does: the library's kernels, torch's row shuffling and the
         # RCCL calls torch.distributed enqueues are ordered by it (SlabSim.step runs under torch.cuda.stream)
         self.stream = torch.cuda.Stream(self.device)
@@ -93,6 +110,37 @@ class HipBackend:
 
     def grid_update(self):
         self._chk(self.lib.wcsph_grid_update(self.ctx))
+
+    def grid_update_begin(self):
+        self._chk(self.lib.wcsph_grid_update_begin(self.ctx))
+
+    def grid_update_end(self):
+        self._chk(self.lib.wcsph_grid_update_end(self.ctx))
+
+    def bucket_hist(self, which):
+        """the library's bucket histogram (0: liquid of this step, 1: static boundary) as a torch int32 view"""
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.wcsph_bucket_hist(self.ctx, int(which), C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DevArray(p.value, n.value), device=self.device)
+
+    def bucket_hist_packed(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.wcsph_bucket_hist_pack(self.ctx, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DevArray(p.value, n.value), device=self.device)
+
+    def bucket_hist_unpack(self):
+        self._chk(self.lib.wcsph_bucket_hist_unpack(self.ctx))
+
+    def pack_rows(self, fields, idx, out):
+        """rows idx of several fields side by side into `out` ([n, sum of widths]); one launch"""
+        ids = (C.c_int32 * len(fields))(*[_lib.FIELD_ID[f] for f in fields])
+        if idx.numel():
+            self._chk(self.lib.wcsph_halo_pack(self.ctx, len(fields), ids, C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(out.data_ptr())))
+
+    def unpack_rows(self, fields, idx, inp):
+        ids = (C.c_int32 * len(fields))(*[_lib.FIELD_ID[f] for f in fields])
+        if idx.numel():
+            self._chk(self.lib.wcsph_halo_unpack(self.ctx, len(fields), ids, C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(inp.data_ptr())))
 
     def phase(self, name):
         self._chk(self.lib.wcsph_phase(self.ctx, _lib.PHASE_ID[name]))
@@ -141,16 +189,18 @@ class HipBackend:
 
 
 # ---------------------------------------------------------------------------------------------------------
-def balanced_cuts(cellx_hist, world):
-    """Cell-column cuts [world+1] giving ~equal particle counts per slab; cut[0] = 0, cut[-1] = nx."""
+def balanced_cuts(cellx_hist, world, min_width=GHOST_CELLS):
+    """Cell-column cuts [world+1] giving ~equal particle counts per slab; cut[0] = 0, cut[-1] = nx; every slab at least
+    min_width columns wide (SlabSim uses MIN_SLAB)."""
     nx = len(cellx_hist)
     cum = np.concatenate([[0], np.cumsum(cellx_hist)])
     total = cum[-1]
     cuts = [0]
     for r in range(1, world):
         c = int(np.searchsorted(cum, total * r / world, side="left"))
-        c = max(c, cuts[-1] + GHOST_CELLS)   # a slab is at least one ghost layer wide
-        cuts.append(min(c, nx))
+        c = max(c, cuts[-1] + min_width)
+        c = min(c, nx - (world - r) * min_width)   # leave room for the slabs to the right
+        cuts.append(max(min(c, nx), cuts[-1]))
     cuts.append(nx)
     return cuts
 
@@ -159,7 +209,8 @@ class SlabSim:
     """The DFSPH step of dfsph.py:606-617 on one slab, with halo exchanges between phases."""
 
     def __init__(self, backend_factory, liquid_local, solid_all, bounds, cuts, n_global, rank, world,
-                 particleR=0.025, device=None, capacity_factor=1.6, group=None, comm_device=None):
+                 particleR=0.025, device=None, capacity_factor=1.6, group=None, comm_device=None,
+                 neighbor_mode="clean", gid_local=None, rebalance_every=0):
         self.rank, self.world, self.group = rank, world, group
         self.device = device if device is not None else torch.device("cpu")
         # tensors handed to torch.distributed live here: the compute device for nccl (RCCL moves them over
@@ -171,21 +222,26 @@ class SlabSim:
         grid_r = particleR * 2.0
         self.inv_grid = np.float32(1.0 / grid_r)
         self.nx = int(float(self.maxb[0] - self.minb[0]) / grid_r + 1.0)   # HashGrid.py:46-48
-        self.cuts = list(cuts)
-        self.lo, self.hi = self.cuts[rank], self.cuts[rank + 1]
         self.n_global = int(n_global)
-        # static boundary particles of the cell window
-        w0, w1 = max(self.lo - GHOST_CELLS, 0), min(self.hi + GHOST_CELLS, self.nx)
-        self.window = (w0, w1)
-        scx = self._cellx_np(np.asarray(solid_all, np.float64).astype(np.float32)[:, 0])
-        solid_local = np.asarray(solid_all)[(scx >= w0) & (scx < w1)]
+        self.neighbor_mode = neighbor_mode
+        self.solid_all = np.asarray(solid_all)
+        self._factory, self._cap_factor = backend_factory, capacity_factor
+        self.rebalance_every, self.steps_done, self.n_rebalanced = int(rebalance_every), 0, 0
         n_local = len(liquid_local)
-        capacity = int(max(n_local, n_global // world) * capacity_factor) + 4096
-        self.B = backend_factory(capacity=capacity, solid_local=solid_local, bounds=(self.minb, self.maxb),
-                                 window=self.window, particleR=particleR, device=self.device)
         rows = np.zeros((n_local, STATE_W), np.float32)
         rows[:, 0:3] = np.asarray(liquid_local, np.float64).astype(np.float32)
+        if gid_local is None:   # global ids: rank-major numbering (callers that care -- CFL prefix, Q5 -- pass the scene's own)
+            counts = [n_local]
+            if world > 1:
+                t = torch.tensor([n_local], dtype=torch.int64, device=self.comm_device)
+                allc = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(allc, t, group=group)
+                counts = [int(c.item()) for c in allc]
+            gid_local = sum(counts[:rank]) + np.arange(n_local, dtype=np.int64)
+        rows[:, 14] = np.asarray(gid_local, np.int32).view(np.float32)
         self.rows = torch.from_numpy(rows).to(self.device)
+        self.B = None
+        self._set_cuts(list(cuts))
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         # reference module globals (dfsph.py:36-41,178)
@@ -196,13 +252,39 @@ class SlabSim:
         self.eps, self.viscosity_err = 1e-5, 0.05
         self.user_max_t, self.user_min_t = 0.005, 0.0001
         self.tension = False
-        self.n_exchanges = 0
+        self.n_exchanges = self.n_host_waits = 0
+
+    def _set_cuts(self, cuts):
+        """(re)build this rank's backend for the slab [cuts[rank], cuts[rank+1]): cell window, static boundary particles
+        of the window, and in faithful mode the global static bucket histogram"""
+        rank, world = self.rank, self.world
+        self.cuts = list(cuts)
+        self.lo, self.hi = self.cuts[rank], self.cuts[rank + 1]
+        w0, w1 = max(self.lo - GHOST_CELLS, 0), min(self.hi + GHOST_CELLS, self.nx)
+        self.window = (w0, w1)
+        sol32 = np.asarray(self.solid_all, np.float64).astype(np.float32)
+        scx = self._cellx_np(sol32[:, 0]) if len(sol32) else np.zeros(0, np.int64)
+        solid_local = self.solid_all[(scx >= w0) & (scx < w1)]
+        capacity = int(max(self.rows.shape[0], self.n_global // world) * self._cap_factor) + 4096
+        if self.B is not None:
+            self.B.close()
+        kw = dict(capacity=capacity, solid_local=solid_local, bounds=(self.minb, self.maxb), window=self.window,
+                  particleR=self.particleR, device=self.device)
+        if self.neighbor_mode == "faithful":
+            big = 1 << 30
+            kw.update(neighbor_mode="faithful", owned=(self.lo if rank > 0 else -big, self.hi if rank < world - 1 else big),
+                      n_global=(self.n_global, len(self.solid_all)))
+        self.B = self._factory(**kw)
+        if self.neighbor_mode == "faithful" and world > 1:
+            self._allreduce_tensor(self.B.bucket_hist(1))      # static boundary particles: once per backend
         # halo/compute overlap: a neighbour pass that needs a halo refresh runs on the slab interior (columns at least
         # GHOST_CELLS away from a cut with a neighbour: no ghost within reach) while the exchange is in flight, then on
         # the rest.  WCSPH_SLAB_OVERLAP=0 switches it off.
         self.overlap = world > 1 and os.environ.get("WCSPH_SLAB_OVERLAP", "1") != "0"
         big = 1 << 20
         self.interior = (self.lo + GHOST_CELLS if rank > 0 else -big, self.hi - GHOST_CELLS if rank < world - 1 else big)
+        # preallocated halo buffers (sized for the widest exchange: two vec3 fields), grown on demand
+        self._hb = {}
 
     # ---- geometry -------------------------------------------------------------------------------------
     def _cellx_np(self, x):
@@ -217,44 +299,68 @@ class SlabSim:
     def _neighbours(self):
         return (self.rank - 1 if self.rank > 0 else None, self.rank + 1 if self.rank < self.world - 1 else None)
 
-    def _exchange_var(self, to_left, to_right):
-        """Variable-size row exchange with the two slab neighbours; returns (from_left, from_right)."""
+    def _host(self, t):
+        """device values the host needs to decide something: one wait"""
+        self.n_host_waits += 1
+        return t.tolist()
+
+    def _allreduce_tensor(self, t, op=None):
+        op = op if op is not None else dist.ReduceOp.SUM
+        if self.comm_device != self.device:        # gloo dry run: stage through the host
+            h = t.to(self.comm_device)
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=self.group)
+
+    def _exchange_var(self, to_left, to_right, head_l=(), head_r=()):
+        """Variable-size row exchange with the two slab neighbours ONLY (no world-wide collective): a fixed-size header
+        (the row count and the caller's integers) travels first, point to point, then the rows.
+        Returns (from_left, from_right, head_from_left, head_from_right)."""
         left, right = self._neighbours()
         w = to_left.shape[1]
-        sizes = torch.tensor([to_left.shape[0], to_right.shape[0]], dtype=torch.int64, device=self.comm_device)
-        allsz = [torch.zeros(2, dtype=torch.int64, device=self.comm_device) for _ in range(self.world)]
-        dist.all_gather(allsz, sizes, group=self.group)
-        n_from_left = int(allsz[left][1]) if left is not None else 0
-        n_from_right = int(allsz[right][0]) if right is not None else 0
-        from_left = torch.empty((n_from_left, w), dtype=torch.float32, device=self.device)
-        from_right = torch.empty((n_from_right, w), dtype=torch.float32, device=self.device)
+        nh = 1 + max(len(head_l), len(head_r))
+        hs_l = torch.tensor([to_left.shape[0]] + list(head_l) + [0] * (nh - 1 - len(head_l)), dtype=torch.int64, device=self.comm_device)
+        hs_r = torch.tensor([to_right.shape[0]] + list(head_r) + [0] * (nh - 1 - len(head_r)), dtype=torch.int64, device=self.comm_device)
+        hr_l, hr_r = torch.zeros_like(hs_l), torch.zeros_like(hs_r)
+        ops = []
+        if left is not None:
+            ops += [dist.P2POp(dist.isend, hs_l, left, group=self.group), dist.P2POp(dist.irecv, hr_l, left, group=self.group)]
+        if right is not None:
+            ops += [dist.P2POp(dist.isend, hs_r, right, group=self.group), dist.P2POp(dist.irecv, hr_r, right, group=self.group)]
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        hl, hr = self._host(torch.stack([hr_l, hr_r]))
+        from_left = torch.empty((int(hl[0]), w), dtype=torch.float32, device=self.device)
+        from_right = torch.empty((int(hr[0]), w), dtype=torch.float32, device=self.device)
         self._sendrecv(to_left, to_right, from_left, from_right)
-        return from_left, from_right
+        return from_left, from_right, hl[1:], hr[1:]
 
     def _sendrecv(self, to_left, to_right, from_left, from_right):
         self._complete(self._post(to_left, to_right, from_left, from_right))
 
     def _post(self, to_left, to_right, from_left, from_right):
-        """tensors or equally long lists of tensors per direction; everything goes out as one batch.  Returns what
-        _complete needs.  With nccl the transfers run on the process group's own stream: work queued on the current
-        stream after this call overlaps with them until _complete makes the stream wait."""
-        as_list = lambda t: list(t) if isinstance(t, (list, tuple)) else [t]   # noqa: E731
-        to_left, to_right, from_left, from_right = as_list(to_left), as_list(to_right), as_list(from_left), as_list(from_right)
+        """one tensor per direction; everything goes out as one batch.  Returns what _complete needs.  With nccl the
+        transfers run on the process group's own stream: work queued on the current stream after this call overlaps with
+        them until _complete makes the stream wait."""
         left, right = self._neighbours()
         staged = self.comm_device != self.device
         dst = None
         if staged:
             dst = (from_left, from_right)
-            to_left = [t.to(self.comm_device) for t in to_left]; to_right = [t.to(self.comm_device) for t in to_right]
-            from_left = [torch.empty_like(t, device=self.comm_device) for t in from_left]
-            from_right = [torch.empty_like(t, device=self.comm_device) for t in from_right]
+            to_left, to_right = to_left.to(self.comm_device), to_right.to(self.comm_device)
+            from_left, from_right = torch.empty_like(from_left, device=self.comm_device), torch.empty_like(from_right, device=self.comm_device)
         ops = []
         if left is not None:
-            ops += [dist.P2POp(dist.isend, t.contiguous(), left, group=self.group) for t in to_left if t.numel()]
-            ops += [dist.P2POp(dist.irecv, t, left, group=self.group) for t in from_left if t.numel()]
+            if to_left.numel():
+                ops.append(dist.P2POp(dist.isend, to_left.contiguous(), left, group=self.group))
+            if from_left.numel():
+                ops.append(dist.P2POp(dist.irecv, from_left, left, group=self.group))
         if right is not None:
-            ops += [dist.P2POp(dist.isend, t.contiguous(), right, group=self.group) for t in to_right if t.numel()]
-            ops += [dist.P2POp(dist.irecv, t, right, group=self.group) for t in from_right if t.numel()]
+            if to_right.numel():
+                ops.append(dist.P2POp(dist.isend, to_right.contiguous(), right, group=self.group))
+            if from_right.numel():
+                ops.append(dist.P2POp(dist.irecv, from_right, right, group=self.group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
         self.n_exchanges += 1
         return reqs, dst, (from_left, from_right), (to_left, to_right)      # the send buffers stay referenced until done
@@ -264,14 +370,21 @@ class SlabSim:
         for req in reqs:
             req.wait()
         if dst is not None:
-            for d, s_ in zip(dst[0], src[0]):
-                d.copy_(s_)
-            for d, s_ in zip(dst[1], src[1]):
-                d.copy_(s_)
+            dst[0].copy_(src[0]); dst[1].copy_(src[1])
+
+    def _halo_buffers(self, W):
+        """send / receive buffers of a halo refresh of total row width W, allocated once per (W, ghost layout)"""
+        key = (W, self.send_all.numel(), self.ghost_all.numel())
+        b = self._hb.get(W)
+        if b is None or b[0] != key:
+            b = (key, torch.empty((self.send_all.numel(), W), dtype=torch.float32, device=self.device),
+                 torch.empty((self.ghost_all.numel(), W), dtype=torch.float32, device=self.device))
+            self._hb[W] = b
+        return b[1], b[2]
 
     def xchg(self, *fields):
-        """Refresh the ghost rows of the given fields from their owners: ONE grouped send/recv with each slab neighbour
-        however many fields travel (the cost of an exchange is its latency, not its bytes)."""
+        """Refresh the ghost rows of the given fields from their owners: ONE packed buffer per slab neighbour however many
+        fields travel (the cost of an exchange is its latency, not its bytes)."""
         self.xchg_end(self.xchg_begin(*fields))
 
     def xchg_begin(self, *fields):
@@ -279,19 +392,32 @@ class SlabSim:
         if self.world == 1:
             return None
         B = self.B
+        W = sum(FIELD_W.get(f, 1) for f in fields)
+        out, inc = self._halo_buffers(W)
         nl, ngl = self.send_l.numel(), self.ghost_l.numel()
-        outs = [B.gather_rows(f, self.send_all) for f in fields]            # one pack kernel per field, both neighbours
-        incs = [torch.empty((self.ghost_all.numel(), o.shape[1]), dtype=torch.float32, device=self.device) for o in outs]
-        pending = self._post([o[:nl] for o in outs], [o[nl:] for o in outs], [i[:ngl] for i in incs], [i[ngl:] for i in incs])
-        return fields, incs, outs, pending
+        if hasattr(B, "pack_rows"):
+            B.pack_rows(fields, self.send_all, out)                        # ONE pack kernel for all fields, both neighbours
+        else:
+            c = 0
+            for f in fields:
+                w = FIELD_W.get(f, 1)
+                out[:, c:c + w] = B.gather_rows(f, self.send_all); c += w
+        pending = self._post(out[:nl], out[nl:], inc[:ngl], inc[ngl:])
+        return fields, inc, pending
 
     def xchg_end(self, h):
         if h is None:
             return
-        fields, incs, outs, pending = h
+        fields, inc, pending = h
         self._complete(pending)
-        for f, inc in zip(fields, incs):
-            self.B.scatter_rows(f, self.ghost_all, inc)                    # one unpack kernel per field
+        B = self.B
+        if hasattr(B, "unpack_rows"):
+            B.unpack_rows(fields, self.ghost_all, inc)                     # ONE unpack kernel
+        else:
+            c = 0
+            for f in fields:
+                w = FIELD_W.get(f, 1)
+                B.scatter_rows(f, self.ghost_all, inc[:, c:c + w].contiguous()); c += w
 
     def xp(self, fields, phase):
         """halo refresh of `fields`, then the neighbour phase that reads them from the ghosts -- overlapped: the phase runs
@@ -310,9 +436,11 @@ class SlabSim:
 
     def _allreduce(self, v, op):
         if self.world == 1:
+            self.n_host_waits += 1
             return float(v)
         t = torch.tensor([float(v)], dtype=torch.float64, device=self.comm_device)
         dist.all_reduce(t, op=op, group=self.group)
+        self.n_host_waits += 1
         return float(t.item())
 
     def reduce_acc(self, slot, fetch=True):
@@ -322,17 +450,16 @@ class SlabSim:
         B = self.B
         acc = getattr(B, "acc", None)
         if acc is None or self.world == 1:
+            if fetch or self.world > 1:
+                self.n_host_waits += 1
             v = self.allsum(B.get_acc(slot)) if self.world > 1 else B.get_acc(slot)
             if self.world > 1:
                 B.set_acc(slot, v)
             return v
         sl = acc[slot * _lib.ACC_STRIPES:(slot + 1) * _lib.ACC_STRIPES]
-        if self.comm_device != self.device:        # gloo dry run: stage through the host
-            t = sl.to(self.comm_device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            sl.copy_(t)
-        else:
-            dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
+        self._allreduce_tensor(sl)
+        if fetch:
+            self.n_host_waits += 1
         return B.get_acc(slot) if fetch else None
 
     def allsum(self, v): return self._allreduce(v, dist.ReduceOp.SUM)   # noqa: E704
@@ -340,43 +467,106 @@ class SlabSim:
 
     # ---- ownership ----------------------------------------------------------------------------------------
     def redistribute(self):
-        """Migrate particles that crossed a cut, then rebuild the ghost layers and load the backend."""
+        """Migration and ghost rebuild in ONE neighbour-only exchange, then the backend is loaded.
+
+        To the left neighbour go [my particles that crossed the left cut | my remaining particles within GHOST_CELLS of
+        it]; the first block becomes the neighbour's property, the second its ghosts.  What I handed over I keep as a
+        ghost myself (it sits just beyond the cut), so nothing travels twice.  The index lists of the per-phase halo
+        refreshes follow from the same bookkeeping on both sides:
+            my send list to L  = my near-cut rows (in sent order) ++ the rows L just handed to me (in received order)
+            L's ghost rows of me = what it received as ghosts       ++ what it handed to me."""
         rows = self.rows
         i32 = torch.int32
-        gl = gr = None
-        if self.world > 1:
-            cx = self._cellx(rows)
-            go_l = (cx < self.lo) if self.rank > 0 else torch.zeros_like(cx, dtype=torch.bool)
-            go_r = (cx >= self.hi) if self.rank < self.world - 1 else torch.zeros_like(cx, dtype=torch.bool)
-            n_l, n_r = torch.stack([go_l.sum(), go_r.sum()]).tolist()        # one host wait; both are 0 on most steps
-            empty = rows[:0]
-            out_l = rows.index_select(0, torch.nonzero(go_l).flatten()) if n_l else empty
-            out_r = rows.index_select(0, torch.nonzero(go_r).flatten()) if n_r else empty
-            in_l, in_r = self._exchange_var(out_l, out_r)
-            if n_l or n_r or in_l.shape[0] or in_r.shape[0]:                 # otherwise the owned rows stay where they are
-                rows = torch.cat([rows[~(go_l | go_r)], in_l, in_r], 0)
-                cx = self._cellx(rows)
-            near_l = (cx < self.lo + GHOST_CELLS) if self.rank > 0 else torch.zeros_like(cx, dtype=torch.bool)
-            near_r = (cx >= self.hi - GHOST_CELLS) if self.rank < self.world - 1 else torch.zeros_like(cx, dtype=torch.bool)
-            self.send_l = torch.nonzero(near_l).flatten()
-            self.send_r = torch.nonzero(near_r).flatten()
-            gl, gr = self._exchange_var(rows.index_select(0, self.send_l), rows.index_select(0, self.send_r))
-            self.send_l, self.send_r = self.send_l.to(i32), self.send_r.to(i32)
-            n = rows.shape[0]
-            self.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=self.device)
-            self.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=self.device)
-        else:
-            n = rows.shape[0]
+        if self.world == 1:
             empty = torch.zeros(0, dtype=i32, device=self.device)
-            self.send_l = self.send_r = self.ghost_l = self.ghost_r = empty
+            self.send_l = self.send_r = self.ghost_l = self.ghost_r = self.send_all = self.ghost_all = empty
+            self.n_owned = rows.shape[0]
+            self.B.load_state(self.n_owned, rows)
+            return
+        G = GHOST_CELLS
+        cx = self._cellx(rows)
+        has_l, has_r = self.rank > 0, self.rank < self.world - 1
+        false = torch.zeros_like(cx, dtype=torch.bool)
+        go_l = (cx < self.lo) if has_l else false
+        go_r = (cx >= self.hi) if has_r else false
+        stay = ~(go_l | go_r)
+        near_l = (stay & (cx < self.lo + G)) if has_l else false
+        near_r = (stay & (cx >= self.hi - G)) if has_r else false
+        lost = ((cx < self.lo - G) & has_l) | ((cx >= self.hi + G) & has_r)     # more than a ghost layer per step: CFL broken
+        n_ml, n_mr, n_lost = self._host(torch.stack([go_l.sum(), go_r.sum(), lost.sum()]))
+        if n_lost:
+            raise RuntimeError("rank %d: %d particles moved more than %d cell columns past a cut in one step (CFL violated); "
+                               "they would land outside the neighbour's cell window" % (self.rank, n_lost, G))
+        new_index = torch.cumsum(stay.to(torch.int64), 0) - 1                    # row index after the leavers are removed
+        idx_nl, idx_nr = torch.nonzero(near_l).flatten(), torch.nonzero(near_r).flatten()
+        mig_l = rows.index_select(0, torch.nonzero(go_l).flatten()) if n_ml else rows[:0]
+        mig_r = rows.index_select(0, torch.nonzero(go_r).flatten()) if n_mr else rows[:0]
+        to_l = torch.cat([mig_l, rows.index_select(0, idx_nl)], 0)
+        to_r = torch.cat([mig_r, rows.index_select(0, idx_nr)], 0)
+        in_l, in_r, hl, hr = self._exchange_var(to_l, to_r, (n_ml,), (n_mr,))
+        a_l, a_r = int(hl[0]), int(hr[0])                                        # rows that became mine
+        owned = rows if not (n_ml or n_mr) else rows[stay]
+        n_stay = owned.shape[0]
+        if a_l or a_r:
+            owned = torch.cat([owned, in_l[:a_l], in_r[:a_r]], 0)
+        n = owned.shape[0]
+        ar = lambda a, b: torch.arange(a, b, dtype=torch.int64, device=self.device)   # noqa: E731
+        self.send_l = torch.cat([new_index[idx_nl], ar(n_stay, n_stay + a_l)]).to(i32)
+        self.send_r = torch.cat([new_index[idx_nr], ar(n_stay + a_l, n)]).to(i32)
+        gl = torch.cat([in_l[a_l:], mig_l], 0)
+        gr = torch.cat([in_r[a_r:], mig_r], 0)
+        self.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=self.device)
+        self.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=self.device)
         self.send_all = torch.cat([self.send_l, self.send_r])
         self.ghost_all = torch.cat([self.ghost_l, self.ghost_r])
-        self.rows = rows
-        self.n_owned = rows.shape[0]
-        if gl is not None and hasattr(self.B, "load_state_split"):
-            self.B.load_state_split(rows, (gl, gr))
+        self.rows = owned
+        self.n_owned = n
+        if hasattr(self.B, "load_state_split"):
+            self.B.load_state_split(owned, (gl, gr))
         else:
-            self.B.load_state(self.n_owned, rows if gl is None else torch.cat([rows, gl, gr], 0))
+            self.B.load_state(n, torch.cat([owned, gl, gr], 0))
+
+    def rebalance(self, force=False):
+        """New cuts from the all-reduced cell-column histogram ("rebalance cuts every K steps"): as the dam
+        breaks along x the liquid leaves the initial columns, and static cuts would pile it onto the edge ranks.  Rows
+        move to their new owners point to point, and every rank rebuilds its backend for the new cell window."""
+        if self.world == 1:
+            return False
+        cx = self._cellx(self.rows).clamp_(0, self.nx - 1)
+        hist = torch.bincount(cx, minlength=self.nx).to(torch.int64)
+        self._allreduce_tensor(hist)
+        h = np.asarray(self._host(hist), np.int64)
+        cuts = balanced_cuts(h, self.world, MIN_SLAB)
+        cum = np.concatenate([[0], np.cumsum(h)])
+        load = lambda c: max(cum[c[r + 1]] - cum[c[r]] for r in range(self.world))   # noqa: E731
+        if not force and load(self.cuts) <= 1.1 * load(cuts):
+            return False                                    # the present cuts are within 10 % of the best ones
+        inner = torch.tensor(cuts[1:-1], dtype=torch.int64, device=self.device)
+        owner = torch.bucketize(cx, inner, right=True)       # cut[r] <= cx < cut[r+1]  ->  r
+        parts = [self.rows.index_select(0, torch.nonzero(owner == r).flatten()) for r in range(self.world)]
+        counts = torch.tensor([p.shape[0] for p in parts], dtype=torch.int64, device=self.comm_device)
+        allc = [torch.zeros_like(counts) for _ in range(self.world)]
+        dist.all_gather(allc, counts, group=self.group)
+        incoming = [int(allc[r][self.rank]) for r in range(self.world)]
+        self.n_host_waits += 1
+        staged = self.comm_device != self.device
+        recv = [torch.empty((incoming[r], STATE_W), dtype=torch.float32, device=self.comm_device) for r in range(self.world)]
+        send = [p.to(self.comm_device).contiguous() if staged else p.contiguous() for p in parts]
+        ops = []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            if send[r].numel():
+                ops.append(dist.P2POp(dist.isend, send[r], r, group=self.group))
+            if recv[r].numel():
+                ops.append(dist.P2POp(dist.irecv, recv[r], r, group=self.group))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        recv[self.rank] = send[self.rank]
+        self.rows = torch.cat([t.to(self.device) for t in recv], 0)
+        self._set_cuts(cuts)
+        self.n_rebalanced += 1
+        return True
 
     # ---- the step -------------------------------------------------------------------------------------------
     def step(self):
@@ -390,9 +580,21 @@ class SlabSim:
         B, ph, x = self.B, self.B.phase, self.xchg
         ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = _lib.ACC_ERR, _lib.ACC_DAD, _lib.ACC_DNEW, _lib.ACC_DZERO
         N = float(self.n_global)
+        if self.rebalance_every and self.steps_done and self.steps_done % self.rebalance_every == 0:
+            self.rebalance()
+            B, ph = self.B, self.B.phase
+        self.steps_done += 1
         self.redistribute()
         B.set_scalar("deltaT", self.dt)
-        B.grid_update()                                   # particle_data.hash_grid.update_grid()
+        if self.neighbor_mode == "faithful" and self.world > 1:
+            # particle_data.hash_grid.update_grid() with the reference's GLOBAL bucket table (HashGrid.py:108-114): every
+            # rank counts its own liquid particles per bucket, the histogram is summed over the ranks on the device
+            B.grid_update_begin()
+            self._allreduce_tensor(B.bucket_hist_packed())     # two 16-bit counts per int32 word: count/2 words on the wire
+            B.bucket_hist_unpack()
+            B.grid_update_end()
+        else:
+            B.grid_update()                               # particle_data.hash_grid.update_grid()
         # compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146), which
         # reads pos_j / vel_j only, in one walk; rho_j then travels with kappa_v
         self.dv_iter = 0
@@ -472,7 +674,8 @@ class SlabSim:
 # ---------------------------------------------------------------------------------------------------------
 def dam_break_slab(n, rank, world, particleRadius=scene.PARTICLE_RADIUS):
     """This rank's share of the n^3 dam break (dfsph.py:59-82 recipe) without building the whole scene:
-    returns (liquid_local, solid_all, bounds, cuts, n_global)."""
+    returns (liquid_local, solid_all, bounds, cuts, n_global, gid_local); gid = the particle's index in the reference's
+    own creation order (dfsph.py:69-73: i = (x * ny + y) * nz + z), which the faithful CFL prefix (Q5) is defined on."""
     dis = particleRadius * 2.0
     L = n * dis
     solid = scene.box_shell(L)
@@ -483,16 +686,18 @@ def dam_break_slab(n, rank, world, particleRadius=scene.PARTICLE_RADIUS):
     cellx = np.trunc((xs.astype(np.float32) - minb[0]) * inv).astype(np.int64)
     nx = int(float(maxb[0] - minb[0]) / dis + 1.0)
     hist = np.bincount(cellx, minlength=nx) * (n * n)
-    cuts = balanced_cuts(hist, world)
+    cuts = balanced_cuts(hist, world, MIN_SLAB)
     mine = np.nonzero((cellx >= cuts[rank]) & (cellx < cuts[rank + 1]))[0]
     j = np.arange(n * n)
     y = (j // n).astype(np.float64) * dis + 0.2
     z = (j % n - n / 2).astype(np.float64) * dis + dis * 0.5
     liquid = np.empty((len(mine) * n * n, 3))
+    gid = np.empty(len(mine) * n * n, np.int64)
     for k, ix in enumerate(mine):
         blk = liquid[k * n * n:(k + 1) * n * n]
         blk[:, 0] = xs[ix]; blk[:, 1] = y; blk[:, 2] = z
-    return liquid, solid, (minb, maxb), cuts, n ** 3
+        gid[k * n * n:(k + 1) * n * n] = ix * n * n + j
+    return liquid, solid, (minb, maxb), cuts, n ** 3, gid
 
 
 def bench_main(args):
@@ -520,9 +725,10 @@ def bench_main(args):
     # weak scaling: n^3 ~ world * 126^3  (C3 per GPU; world = 8 gives the 252^3 of config C4)
     n_base = scene.CONFIGS.get(args.config) or int(args.config)
     n = int(round(n_base * world ** (1.0 / 3.0)))
-    liquid, solid, bounds, cuts, n_global = dam_break_slab(n, rank, world)
+    liquid, solid, bounds, cuts, n_global, gid = dam_break_slab(n, rank, world)
     sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, cuts, n_global, rank, world, device=dev,
-                  comm_device=torch.device("cpu") if comm == "gloo" else dev)
+                  comm_device=torch.device("cpu") if comm == "gloo" else dev, neighbor_mode=args.mode, gid_local=gid,
+                  rebalance_every=int(os.environ.get("WCSPH_REBALANCE_EVERY", "200")))
     cdev = sim.comm_device
     iters = []
     for _ in range(args.warmup):
@@ -557,7 +763,9 @@ def bench_main(args):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DFSPH 3D dam-break %d^3 = %d liquid particles over %d x-slabs (C3 load per GPU; C4 at 8 "
                                    "GPUs), ghost halos over RCCL send/recv, viscosity PCG + vorticity on" % (n, n_global, world),
-                       "neighbor_mode": "clean", "n_liquid": n_global, "cuts": cuts, "comm": comm,
+                       "neighbor_mode": args.mode, "n_liquid": n_global, "cuts": sim.cuts, "comm": comm,
+                       "host_waits_per_step": round(sim.n_host_waits / float(args.steps + args.warmup), 1),
+                       "rebalance_every": sim.rebalance_every, "rebalanced": sim.n_rebalanced,
                        "owned_per_rank": [int(c.item()) for c in allc],
                        "halo_exchanges_per_step": round(sim.n_exchanges / float(args.steps + args.warmup), 1),
                        "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)}},
