@@ -64,3 +64,44 @@ long orc_mc_crossings(const float *value, const int *dims, const float *minb, do
     }
   return n;
 }
+
+/* marching_cube, MarchingCubeGrid.py:252-328, with the case tables passed in (edge_table[256], tri_table[256][16]):
+ * out[cap][3] vertices, three per triangle, cubes in index order (the reference appends through an atomic counter, so its
+ * triangle ORDER is schedule dependent; the set is not).  Returns the vertex count. */
+static void mc_interp(const float *p1, const float *p2, float v1, float v2, float iso, float *p) {   /* :373-409 */
+  int swap = 1;   /* check_pos(p2, p1): the LAST differing coordinate decides */
+  for (int a = 0; a < 3; a++) { if (p2[a] < p1[a]) swap = 1; else if (p2[a] > p1[a]) swap = 0; }
+  if (swap) { const float *tp = p1; p1 = p2; p2 = tp; float tv = v1; v1 = v2; v2 = tv; }
+  for (int a = 0; a < 3; a++) p[a] = p1[a];
+  if (fabsf(v1 - v2) > 0.00001f) for (int a = 0; a < 3; a++) p[a] = p1[a] + (p2[a] - p1[a]) / (v2 - v1) * (iso - v1);
+}
+long orc_mc_triangles(const float *value, const int *dims, const float *minb, double grid_r, float iso,
+                      const int *edge_table, const int *tri_table, float *out, long cap) {
+  static const int CO[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};   /* :257-264 */
+  static const int ED[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+  const int nx = dims[0], ny = dims[1], nz = dims[2];
+  const float gr = (float)grid_r;
+  long n = 0;
+  for (int x = 0; x + 1 < nx; x++) for (int y = 0; y + 1 < ny; y++) for (int z = 0; z + 1 < nz; z++) {
+    float v[8], p[8][3];
+    int ci = 0;
+    for (int c = 0; c < 8; c++) {
+      const int cx = x + CO[c][0], cy = y + CO[c][1], cz = z + CO[c][2];
+      v[c] = value[((long)cx * ny + cy) * nz + cz];
+      p[c][0] = minb[0] + (float)cx * gr; p[c][1] = minb[1] + (float)cy * gr; p[c][2] = minb[2] + (float)cz * gr;
+      if (v[c] < iso) ci |= 1 << c;
+    }
+    if (edge_table[ci] == 0) continue;
+    float vl[12][3];
+    for (int e = 0; e < 12; e++) {
+      for (int a = 0; a < 3; a++) vl[e][a] = p[0][a];
+      if (edge_table[ci] & (1 << e)) mc_interp(p[ED[e][0]], p[ED[e][1]], v[ED[e][0]], v[ED[e][1]], iso, vl[e]);
+    }
+    for (int k = 0; k + 2 < 16 && tri_table[ci * 16 + k] != -1; k += 3)
+      for (int q = 0; q < 3; q++) {
+        if (n < cap) for (int a = 0; a < 3; a++) out[3 * n + a] = vl[tri_table[ci * 16 + k + q]][a];
+        n++;
+      }
+  }
+  return n;
+}

@@ -121,6 +121,8 @@ def _load():
         lib.orc_mc_value.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_mc_crossings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_float, C.c_void_p, C.c_long]
         lib.orc_mc_crossings.restype = C.c_long
+        lib.orc_mc_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        lib.orc_mc_triangles.restype = C.c_long
         lib.orc_poisson_sample.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_uint32, C.c_int, C.c_void_p, C.c_int]
         lib.orc_poisson_sample.restype = C.c_int
         lib.orc_ps_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -149,6 +151,19 @@ def mc_crossings(value, dims, minb, grid_r, iso):
     out = np.empty((n, 3), np.float32)
     lib.orc_mc_crossings(value.ctypes.data, dims.ctypes.data, minb.ctypes.data, float(grid_r), float(iso), out.ctypes.data, n)
     return out
+
+
+def mc_triangles(value, dims, minb, grid_r, iso, edge_table, tri_table):
+    """MCGrid.marching_cube restated (oracle/mc_ref.c) with explicit case tables -> [n_tri, 3, 3] vertices"""
+    value = np.ascontiguousarray(value, np.float32)
+    minb = np.ascontiguousarray(minb, np.float32).ravel(); dims = np.ascontiguousarray(dims, np.int32).ravel()
+    et = np.ascontiguousarray(edge_table, np.int32).ravel(); tt = np.ascontiguousarray(tri_table, np.int32).reshape(256, 16)
+    lib = _load()
+    a = (value.ctypes.data, dims.ctypes.data, minb.ctypes.data, float(grid_r), float(iso), et.ctypes.data, tt.ctypes.data)
+    n = lib.orc_mc_triangles(*a, None, 0)
+    out = np.empty((n, 3), np.float32)
+    lib.orc_mc_triangles(*a, out.ctypes.data, n)
+    return out.reshape(-1, 3, 3)
 
 
 def poisson_sample(tri, radius=0.025, seed=20240901, trials=10, cap=None):

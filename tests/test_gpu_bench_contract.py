@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "12", "--steps", "3", "--warmup", "1",
-                        "--cpu-n", "8", "--cpu-steps", "1", "--kernel-reps", "2"], capture_output=True, text=True, timeout=600)
+                        "--cpu-n", "8", "--developed-after", "30", "--kernel-reps", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -29,4 +29,6 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert rf["launches_timed"] >= 2 * d["steps"] and rf["avg_launch_us"] > 0       # in-situ events: >= 2 pressure iterations per step
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert "developed_flow" in d["config"] and d["config"]["developed_flow"]["value"] > 0
+    assert rf["traffic"] is None or rf["traffic"] > 0
     assert d["value"] > 0 and abs(d["ms_per_step"] - d["config"]["n_liquid"] / d["value"] / 1e3) / d["ms_per_step"] < 0.02

@@ -48,6 +48,25 @@ def test_mesh_vertices_are_the_grid_edge_crossings():
     g.close()
 
 
+def test_mesh_triangles_equal_the_restatement():
+    """marching_cube on the GPU against oracle/mc_ref.c's restatement of MarchingCubeGrid.py:252-328 driven by the same
+    case tables, on the GPU's own node field: the same triangles (as a multiset; the reference's append order is an
+    atomic counter's)."""
+    from wcsph_amd import _lib
+    g, o = make_pair(8, "clean", jitter=0.4)
+    g.pd.hash_grid.update_grid()
+    g.call("dfsph_compute_density")
+    mc, tri = mesh_of(g)
+    edge = np.empty(256, np.int32); tt = np.empty(256 * 16, np.int32)
+    assert _lib.load().wcsph_mc_tables(edge.ctypes.data, tt.ctypes.data) == 0
+    want = oracle.mc_triangles(mc.surface_value.to_numpy(), mc.blocknp, mc.minboundarynp, mc.gridR, mc.isolevel, edge, tt)
+    assert tri.shape == want.shape
+    key = lambda m: np.sort(np.round(m.reshape(len(m), 9).astype(np.float64), 6).view([("", np.float64)] * 9), axis=0)   # noqa: E731
+    a, b = key(tri).view(np.float64).reshape(-1, 9), key(want).view(np.float64).reshape(-1, 9)
+    assert np.abs(a - b).max() < 2e-6
+    g.close()
+
+
 def test_mesh_is_closed_oriented_and_encloses_the_block(tmp_path):
     g, o = make_pair(8, "clean", jitter=0.2)
     g.pd.hash_grid.update_grid()

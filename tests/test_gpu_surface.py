@@ -17,19 +17,18 @@ def test_color_map_and_anisotropic_kernel(mode):
     g.pd.compute_color_map(); o.compute_color_map()
     assert rel_err(g.pd.color.to_numpy(), o.color) < 1e-5
     assert rel_err(g.pd.color_grad.to_numpy(), o.color_grad) < 1e-4
-    if mode == "faithful":
-        # weight_func has support 2 * mc_grid.searchR = 0.18 > h: in the reference, bucket entries from cells 3-4 away
-        # that alias into a walked bucket contribute too.  The library counts such far entries (neighborCount) but
-        # does not enumerate them, so the anisotropic kernel is checked under clean semantics only.
-        g.close()
-        return
+    # weight_func has support 2 * mc_grid.searchR = 0.18 > h: in the reference, bucket entries from cells 3-4 away that
+    # alias into a walked bucket contribute too -- in faithful mode the library runs these sums over the reference's raw
+    # rows (csrc/bucket.h), in clean mode over the walked cells
     g.pd.cal_anistropic_kernel(); o.cal_anistropic_kernel()
     assert g.pd.mc_grid.searchR == pytest.approx(0.025 * 0.9 * 4.0)
     assert np.abs(g.pd.pos_avr.to_numpy() - o.pos_avr).max() < 1e-6
     G, Go = g.pd.G.to_numpy(), o.G
     assert G.shape == (g.pd.liquid_count, 3, 3)
     aniso = np.abs(Go - 0.5 * np.eye(3)).reshape(len(Go), -1).max(1) > 1e-6
-    assert aniso.sum() > 100 and (~aniso).sum() > 0      # both branches (enough / too few neighbours) occur
+    assert aniso.sum() > 100
+    if mode == "clean":
+        assert (~aniso).sum() > 0      # both branches (enough / too few neighbours) occur; the raw faithful counts all exceed 25
     assert rel_err(G, Go) < 2e-4
     np.testing.assert_allclose(G, np.transpose(G, (0, 2, 1)), atol=1e-6)   # symmetric
     g.close()

@@ -12,6 +12,7 @@
 #pragma once
 #include "device.h"
 #include "grid.h"
+#include "surface.h"
 
 struct BucketTab {
   int *start;     // [T + 1]
@@ -152,4 +153,47 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel_literal(Dev d, BucketTa
     }
   });
   d.d_vel[i] = f4(dv, 0);
+}
+
+// ---- cal_anistropic_kernel over the raw rows (ref: ParticleData.py:220-289) ----------------------------------------------
+// weight_func's support is 2 * mc_grid.searchR = 0.18 > h: a far aliased list entry from a cell three or four away can
+// carry weight, so in faithful mode the sums run over the reference's own rows instead of the walked cells.
+__global__ void __launch_bounds__(BLOCK) k_surf_pos_avr_raw(Dev d, BucketTab b, SurfDev s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  const float4 pi = d.pos[i];
+  const float3 xi = xyz(pi);
+  float sw = 0.f;
+  float3 sx = f3(0, 0, 0);
+  raw_row(d, b, i, pi, [&](int g) {
+    if (g >= d.nl) return;
+    const float3 xj = xyz(d.pos[d.where[g]]);
+    const float3 r = xi - xj;
+    const float w = aniso_w(dot3(r, r), s.R2);
+    sw += w; sx = sx + xj * w;
+  });
+  s.pos_avr[i] = (sw > 0.0f) ? f4(sx * (1.0f / sw), 0) : make_float4(pi.x, pi.y, pi.z, 0);
+}
+__global__ void __launch_bounds__(BLOCK) k_surf_aniso_raw(Dev d, BucketTab b, SurfDev s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  const float kn = 0.5f, ne = 25.0f;
+  float4 r0 = make_float4(kn, 0, 0, 0), r1 = make_float4(0, kn, 0, 0), r2v = make_float4(0, 0, kn, 0);
+  if ((float)d.ncount[i] > ne) {
+    const float4 pi = d.pos[i];
+    const float3 xi = xyz(pi), pa = xyz(s.pos_avr[i]);
+    float sw = 0.f, c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    raw_row(d, b, i, pi, [&](int g) {
+      if (g >= d.nl) return;
+      const float3 xj = xyz(d.pos[d.where[g]]);
+      const float3 dx = xi - xj;
+      const float w = aniso_w(dot3(dx, dx), s.R2);
+      const float3 r = xj - pa;
+      sw += w;
+      c00 += w * r.x * r.x; c01 += w * r.x * r.y; c02 += w * r.x * r.z;
+      c11 += w * r.y * r.y; c12 += w * r.y * r.z; c22 += w * r.z * r.z;
+    });
+    aniso_G(sw, c00, c01, c02, c11, c12, c22, r0, r1, r2v);
+  }
+  s.g0[i] = r0; s.g1[i] = r1; s.g2[i] = r2v;
 }

@@ -75,11 +75,24 @@ __device__ __forceinline__ void jacobi3(float a00, float a01, float a02, float a
   w[0] = e0; w[1] = e1; w[2] = e2;
   for (int k = 0; k < 3; k++) { Q[k][0] = v0[k]; Q[k][1] = v1[k]; Q[k][2] = v2[k]; }
 }
+// ref: ParticleData.py:268-280: C = sum_ci / sum_wij -> eigen-decomposition -> G = R inv(sigmas) R^T
+__device__ __forceinline__ void aniso_G(float sw, float c00, float c01, float c02, float c11, float c12, float c22, float4 &r0, float4 &r1, float4 &r2v) {
+  const float kr = 4.0f, ks = 1400.0f;
+  const float is = 1.0f / sw;
+  float w[3], Q[3][3];
+  jacobi3(c00 * is, c01 * is, c02 * is, c11 * is, c12 * is, c22 * is, w, Q);
+  if (w[0] > 0.0f) {
+    const float i0 = 1.0f / (ks * w[0]), i1 = 1.0f / (ks * fmaxf(w[1], w[0] / kr)), i2 = 1.0f / (ks * fmaxf(w[2], w[0] / kr));
+    float G[3][3];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) G[a][b] = Q[a][0] * i0 * Q[b][0] + Q[a][1] * i1 * Q[b][1] + Q[a][2] * i2 * Q[b][2];
+    r0 = make_float4(G[0][0], G[0][1], G[0][2], 0); r1 = make_float4(G[1][0], G[1][1], G[1][2], 0); r2v = make_float4(G[2][0], G[2][1], G[2][2], 0);
+  }
+}
 // ref: ParticleData.py:244-280
 __global__ void __launch_bounds__(BLOCK) k_surf_aniso(Dev d, SurfDev s) {
   const int i = sorted_index();
   if (i >= d.nl) return;
-  const float kr = 4.0f, ks = 1400.0f, kn = 0.5f, ne = 25.0f;
+  const float kn = 0.5f, ne = 25.0f;
   float4 r0 = make_float4(kn, 0, 0, 0), r1 = make_float4(0, kn, 0, 0), r2v = make_float4(0, 0, kn, 0);
   if ((float)d.ncount[i] > ne) {
     const float4 pi = d.pos[i];
@@ -94,15 +107,7 @@ __global__ void __launch_bounds__(BLOCK) k_surf_aniso(Dev d, SurfDev s) {
                  c11 += w * r.y * r.y; c12 += w * r.y * r.z; c22 += w * r.z * r.z;
                },
                [&](int, float3, float, float) {});
-    const float is = 1.0f / sw;
-    float w[3], Q[3][3];
-    jacobi3(c00 * is, c01 * is, c02 * is, c11 * is, c12 * is, c22 * is, w, Q);
-    if (w[0] > 0.0f) {
-      const float i0 = 1.0f / (ks * w[0]), i1 = 1.0f / (ks * fmaxf(w[1], w[0] / kr)), i2 = 1.0f / (ks * fmaxf(w[2], w[0] / kr));
-      float G[3][3];
-      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) G[a][b] = Q[a][0] * i0 * Q[b][0] + Q[a][1] * i1 * Q[b][1] + Q[a][2] * i2 * Q[b][2];
-      r0 = make_float4(G[0][0], G[0][1], G[0][2], 0); r1 = make_float4(G[1][0], G[1][1], G[1][2], 0); r2v = make_float4(G[2][0], G[2][1], G[2][2], 0);
-    }
+    aniso_G(sw, c00, c01, c02, c11, c12, c22, r0, r1, r2v);
   }
   s.g0[i] = r0; s.g1[i] = r1; s.g2[i] = r2v;
 }

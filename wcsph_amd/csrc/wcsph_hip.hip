@@ -1248,7 +1248,12 @@ int wcsph_surface_anisotropic_kernel(wcsph_ctx *ctx, float mc_searchR) {
   Dev v = ctx->d;
   ctx->surf.R2 = mc_searchR * 2.0f;                 // ParticleData.py:295 support of weight_func
   v.list_r2 = ctx->surf.R2 * ctx->surf.R2;          // entries of the walked cells beyond it weigh exactly zero
-  if (v.nl > 0) {
+  if (v.nl > 0 && v.faithful && ctx->win_x1 < 0) {
+    // weight_func's support (0.18) exceeds the walk radius: over the reference's raw rows (csrc/bucket.h)
+    if ((rc = bucket_build(ctx))) return rc;
+    hipLaunchKernelGGL(k_surf_pos_avr_raw, dim3(nblk(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->bk, ctx->surf);
+    hipLaunchKernelGGL(k_surf_aniso_raw, dim3(nblk(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->bk, ctx->surf);
+  } else if (v.nl > 0) {
     hipLaunchKernelGGL(k_surf_pos_avr, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
     hipLaunchKernelGGL(k_surf_aniso, dim3(nblk8(v.nl)), dim3(BLOCK), 0, ctx->stream, v, ctx->surf);
   }

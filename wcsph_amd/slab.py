@@ -527,6 +527,13 @@ class SlabSim:
             self.B.load_state(n, torch.cat([owned, gl, gr], 0))
 
     def rebalance(self, force=False):
+        stream = getattr(self.B, "stream", None)
+        if stream is None:
+            return self._rebalance(force)
+        with torch.cuda.stream(stream):      # the rows were written on the backend's stream
+            return self._rebalance(force)
+
+    def _rebalance(self, force=False):
         """New cuts from the all-reduced cell-column histogram ("rebalance cuts every K steps"): as the dam
         breaks along x the liquid leaves the initial columns, and static cuts would pile it onto the edge ranks.  Rows
         move to their new owners point to point, and every rank rebuilds its backend for the new cell window."""
@@ -581,8 +588,8 @@ class SlabSim:
         ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = _lib.ACC_ERR, _lib.ACC_DAD, _lib.ACC_DNEW, _lib.ACC_DZERO
         N = float(self.n_global)
         if self.rebalance_every and self.steps_done and self.steps_done % self.rebalance_every == 0:
-            self.rebalance()
-            B, ph = self.B, self.B.phase
+            self._rebalance()
+            B, ph, x = self.B, self.B.phase, self.xchg
         self.steps_done += 1
         self.redistribute()
         B.set_scalar("deltaT", self.dt)
