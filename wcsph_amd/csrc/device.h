@@ -4,8 +4,9 @@
 // SoA arrays; vec3 fields are float4-padded so that one neighbour gather is a single
 // 16-byte load.  pos.w carries the particle's packed cell (cx | cy<<10 | cz<<20, -1 when the
 // particle is outside the grid box, ref: HashGrid.py:68-69,117-124).  Static solids are
-// sorted once.  Cells are linearised in 2 x 2 columns along z (see cell_lin): 64 consecutive particles are a compact
-// 2 x 2 x 16 bar and the 5x5x5 walk (ref: HashGrid.py:82-85) reads nine contiguous particle ranges.
+// sorted once.  Cells are linearised in TILES of 2 x 4 x 16 cells (outer x middle x z, see cell_lin): 64 consecutive
+// particles are a compact brick instead of a 64-cell column segment, and the <= 5 cells of one (dx,dy) row of the
+// 5x5x5 walk (ref: HashGrid.py:82-85) are at most TWO contiguous particle ranges.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,8 +19,9 @@ struct Dev {
   // counts
   int nl, ns, n_owned;
   int nx, ny, nz, ncell;   // ncell = nx*ny*nz: plain (x,y,z) linearisation, used only by the faithful box filter
-  // column order (cell_lin): perm = 0: x outer, y middle; 1: y outer, x middle (the longer of the two is outer)
-  int perm, nt0, nt1, ncell_p;   // columns per axis, padded cell count (= index of the out-of-box bin)
+  // tile order (cell_lin): perm = 0: x outer, y middle; 1: y outer, x middle (the longer of the two is outer, so that
+  // the particles between two neighbouring outer tile planes -- the largest delta of a neighbour stream -- are few)
+  int perm, nt0, nt1, nt2, ncell_p;   // tiles per axis, padded cell count (= index of the out-of-box bin)
   int x0;          // first global cell column of this context's window (slab decomposition); 0 otherwise
   int own_lo, own_hi;   // global cell columns this context OWNS (bucket histogram); [0, inf) without a decomposition
   // slab halo/compute overlap: 0 = every owned particle; 1 = only those in global cell columns [part_x0, part_x1)
@@ -112,33 +114,35 @@ __device__ __forceinline__ float cubic_gradW_scale(const Dev &d, float r2) {
   return (rl > 1.0e-5f && q <= 1.0f) ? g : 0.0f;
 }
 
-// ---- column-ordered cell index ---------------------------------------------------------------------------
-// Cells are linearised in COLUMNS of 2 x 2 cells (outer x middle axis) running along z: column-major, then the z layer,
-// then the four cells of the layer.  Every z-range of a column is ONE contiguous particle range, so the 5x5x5 cells a
-// particle walks (ref: HashGrid.py:82-85) lie in 3 x 3 columns = nine contiguous ranges (cells three away in x or y
-// ride along and are dropped by the cell test), and 64 consecutive particles are a 2 x 2 x 16 bar whose neighbourhood
-// is nine contiguous pieces (brick.h stages them in LDS).
-__device__ __forceinline__ int cell_lin(const Dev &d, int cx, int cy, int cz) {
+// ---- tile-ordered cell index ----------------------------------------------------------------------------
+#ifndef T0B      /* -DT0B=0 -DT1B=0 -DT2B=3 gives the plain z-fastest order (tools/state_bench.py compares shapes) */
+#define T0B 1   /* outer axis: 2 cells per tile  */
+#define T1B 2   /* middle axis: 4 cells per tile */
+#define T2B 4   /* z: 16 cells per tile (row_pieces relies on >= 5 cells: a walked row touches at most two tiles) */
+#endif
+#define TILE_SHIFT (T0B + T1B + T2B)
+// index of the first cell (z = 0 of tile row 0) of the z-row through (cx, cy): cell (cx, cy, cz) = row + (cz >> 3) * 64 + (cz & 7)
+__device__ __forceinline__ int cell_row(const Dev &d, int cx, int cy) {
   const int a0 = d.perm ? cy : cx, a1 = d.perm ? cx : cy;
-  return ((((a0 >> 1) * d.nt1 + (a1 >> 1)) * d.nz + cz) << 2) | ((a0 & 1) << 1) | (a1 & 1);
+  return ((((a0 >> T0B) * d.nt1 + (a1 >> T1B)) * d.nt2) << TILE_SHIFT) | ((a0 & ((1 << T0B) - 1)) << (T1B + T2B)) | ((a1 & ((1 << T1B) - 1)) << T2B);
 }
-// first cell of layer z of column (T0, T1); z = nz is the first cell of the next column
-__device__ __forceinline__ int layer_lin(const Dev &d, int T0, int T1, int z) { return ((T0 * d.nt1 + T1) * d.nz + z) << 2; }
-// packed cell (cx | cy << 10 | cz << 20) of a position: ref HashGrid.py:68 -- ti.cast((pos - min) * invGridR, i32): f32 sub,
-// f32 mul (no fma), trunc to zero; -1 outside the box
-__device__ __forceinline__ int cell_of_pos(const Dev &d, float3 p, bool *finite = nullptr) {
-  const float fx = __fmul_rn(__fsub_rn(p.x, d.minx), d.inv_grid);
-  const float fy = __fmul_rn(__fsub_rn(p.y, d.miny), d.inv_grid);
-  const float fz = __fmul_rn(__fsub_rn(p.z, d.minz), d.inv_grid);
-  const bool fin = (fabsf(fx) < 1e9f) && (fabsf(fy) < 1e9f) && (fabsf(fz) < 1e9f);  // NaN/inf => outside
-  if (finite) *finite = (fabsf(fx) <= 3.0e38f) && (fabsf(fy) <= 3.0e38f) && (fabsf(fz) <= 3.0e38f);
-  const int cx = (int)fx - d.x0, cy = (int)fy, cz = (int)fz;  // truncation toward zero BEFORE the window shift (Q4)
-  const bool in = fin && (unsigned)cx < (unsigned)d.nx && (unsigned)cy < (unsigned)d.ny && (unsigned)cz < (unsigned)d.nz;
-  return in ? (cx | (cy << 10) | (cz << 20)) : -1;
+__device__ __forceinline__ int cell_lin(const Dev &d, int cx, int cy, int cz) {
+  return cell_row(d, cx, cy) + ((cz >> T2B) << TILE_SHIFT) + (cz & ((1 << T2B) - 1));
 }
-// is the cell with packed word w one of the 5 x 5 (x, y) columns around cell (cx, cy)?  (z is the caller's range)
-__device__ __forceinline__ bool cell_near(int w, int cx, int cy) {
-  return (unsigned)((w & 1023) - cx + 2) <= 4u && (unsigned)(((w >> 10) & 1023) - cy + 2) <= 4u;
+// particle ranges of the cells (x, y, z0 .. z1-1), 0 < z1 - z0 <= 8: a z-run of up to 8 cells touches at most two tiles
+struct RowPieces { int lo0, hi0, lo1, hi1; };
+__device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int x, int y, int z0, int z1) {
+  const int rb = cell_row(d, x, y);
+  const int tA = z0 >> T2B, tB = (z1 - 1) >> T2B;
+  const int bA = rb + (tA << TILE_SHIFT);
+  RowPieces r;
+  r.lo0 = CS[bA + (z0 & ((1 << T2B) - 1))];
+  r.hi0 = CS[bA + min(z1 - (tA << T2B), 1 << T2B)];   // [.. + 8] is the next row of the tile (or the next tile): the end of cell z = 7
+  // branch free: when the run stays in one tile the second piece reads the same entry twice (an empty range)
+  const int bB = rb + (tB << TILE_SHIFT);
+  r.lo1 = CS[bB];
+  r.hi1 = CS[bB + (tB > tA ? z1 - (tB << T2B) : 0)];
+  return r;
 }
 
 // which owned particles a neighbour pass computes in this launch (Dev::part_mode); particles outside the grid box
@@ -205,52 +209,66 @@ __device__ __forceinline__ double acc_total(const double *slot) {
   return tot;
 }
 
-// The cell walk (grid update and post-processing).  fl(j, r, r2, m) is called for every liquid list entry j != i
+// The cell walk (grid update only).  fl(j, r, r2, m) is called for every liquid list entry j != i
 // inside the support (r = x_i - x_j, m = multiplicity of the entry in the reference's bucket multiset),
 // fs(j, r, r2, m) likewise for solid entries.  Entries outside the support contribute exactly zero
 // to every kernel-weighted sum of the reference (compact support) and are skipped here; the raw
 // list LENGTH the reference also uses (Q2/Q10) is d.ncount[i], built by the grid update.
-// Candidates come from the 3 x 3 columns around the particle's column, layers cz-2 .. cz+2: nine contiguous ranges.  The
-// 6 x 6 cross-section holds cells three away in x or y, which the reference does not walk: an entry must also pass
-// cell_near().  COUNT: returns the number of candidates in the 5x5x5 cells, self included (clean-mode neighborCount).
-template <bool COUNT = false, class FL, class FS>
-__device__ __forceinline__ int walk_cells(const Dev &d, int i, float4 pi, bool liquids, FL &&fl, FS &&fs) {
+template <class FL, class FS>
+__device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool liquids, FL &&fl, FS &&fs) {
   const int cw = __float_as_int(pi.w);
-  if (cw < 0) return 0;  // outside the grid box: no neighbours (ref: HashGrid.py:80-81, Q4)
+  if (cw < 0) return;  // outside the grid box: no neighbours (ref: HashGrid.py:80-81, Q4)
   const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
   const float3 xi = xyz(pi);
   const int info = d.cell_info[cell_lin(d, cx, cy, cz)];
-  const int t0 = (d.perm ? cy : cx) >> 1, t1 = (d.perm ? cx : cy) >> 1;
-  const int za = max(cz - 2, 0), zb = min(cz + 2, d.nz - 1) + 1;
-  int cnt = 0;
-  // the 18 cell-table lookups are issued together, then the ranges are scanned
-#define WALK_COLS(CS, POS, SELF, CALL, CELLW)                                                      \
-  {                                                                                               \
-    int lo[9], hi[9];                                                                             \
-    _Pragma("unroll") for (int q = 0; q < 9; q++) {                                               \
-      const int T0 = t0 + q / 3 - 1, T1 = t1 + q % 3 - 1;                                         \
-      lo[q] = hi[q] = 0;                                                                          \
-      if ((unsigned)T0 < (unsigned)d.nt0 && (unsigned)T1 < (unsigned)d.nt1) {                     \
-        lo[q] = CS[layer_lin(d, T0, T1, za)];                                                     \
-        hi[q] = CS[layer_lin(d, T0, T1, zb)];                                                     \
-      }                                                                                           \
+  // Row trimming: a row (dx, dy) of the 5x5 columns is walked only over the z-cells the support sphere can reach.
+  // Distances in cell units from the particle to the nearest face of the column; rm = list radius + a margin
+  // for the rounding of the cell assignment.  Purely a candidate filter: the r2 <= list_r2 test below decides.
+  const float ux = (pi.x - d.minx) * d.inv_grid - (float)(cx + d.x0), uy = (pi.y - d.miny) * d.inv_grid - (float)cy;
+  const float fz = (pi.z - d.minz) * d.inv_grid;
+  const float rm = __builtin_amdgcn_sqrtf(d.list_r2) * d.inv_grid * 1.0001f + 1e-3f, rm2 = rm * rm;
+  auto zrange = [&](int dx, int dy, int &za, int &zb) -> bool {
+    const float ex = dx > 0 ? (float)dx - ux : (dx < 0 ? (float)(-dx - 1) + ux : 0.0f);
+    const float ey = dy > 0 ? (float)dy - uy : (dy < 0 ? (float)(-dy - 1) + uy : 0.0f);
+    const float q = rm2 - ex * ex - ey * ey;
+    if (q < 0.0f) return false;
+    const float zr = __builtin_amdgcn_sqrtf(q);
+    za = max(max((int)floorf(fz - zr), cz - 2), 0);
+    zb = min(min((int)floorf(fz + zr), cz + 2), d.nz - 1) + 1;
+    return zb > za;
+  };
+  // The walk goes plane by plane along the OUTER axis of the tile order (x, or y when perm = 1), then row by row along
+  // the middle axis: indices grow almost monotonically, so the deltas of the neighbour streams stay small.  Per outer
+  // plane the cell-table lookups of its five rows (two pieces each, row_pieces) are issued together, then scanned.
+  const int c0 = d.perm ? cy : cx, c1 = d.perm ? cx : cy, n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
+#define WALK_PLANE(CS, POS, SELF, CALL)                                                            \
+  _Pragma("unroll 1") for (int e0 = -2; e0 <= 2; e0++) {                                          \
+    const int a0 = c0 + e0;                                                                       \
+    if ((unsigned)a0 >= (unsigned)n0) continue;                                                   \
+    RowPieces rp[5];                                                                              \
+    _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
+      const int a1 = c1 + t - 2;                                                                  \
+      int z0, z1;                                                                                 \
+      rp[t].lo0 = rp[t].hi0 = rp[t].lo1 = rp[t].hi1 = 0;                                          \
+      if ((unsigned)a1 < (unsigned)n1 && zrange(d.perm ? t - 2 : e0, d.perm ? e0 : t - 2, z0, z1)) \
+        rp[t] = row_pieces(d, CS, d.perm ? a1 : a0, d.perm ? a0 : a1, z0, z1);                    \
     }                                                                                             \
-    _Pragma("unroll") for (int q = 0; q < 9; q++) {                                               \
-      for (int j = lo[q]; j < hi[q]; j++) {                                                       \
+    _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
+      int j = rp[t].lo0, end = rp[t].hi0, j2 = rp[t].lo1;                                         \
+      const int end2 = rp[t].hi1;                                                                 \
+      for (;;) {                                                                                  \
+        if (j >= end) { if (j2 >= end2) break; j = j2; end = end2; j2 = end2; }                   \
         const float4 pj = POS[j];                                                                 \
         const float3 r = xi - xyz(pj);                                                            \
         const float r2 = dot3(r, r);                                                              \
-        if (COUNT || r2 <= d.list_r2) {                                                           \
-          const bool near = cell_near(CELLW, cx, cy);                                             \
-          if (COUNT) cnt += near;                                                                 \
-          if (near && r2 <= d.list_r2 && (SELF)) CALL(j, r, r2, 1.0f);                            \
-        }                                                                                         \
+        if (r2 <= d.list_r2 && (SELF)) CALL(j, r, r2, 1.0f);                                      \
+        j++;                                                                                      \
       }                                                                                           \
     }                                                                                             \
   }
-  if (liquids) WALK_COLS(d.cs_l, d.pos, j != i, fl, __float_as_int(pj.w))
-  if (info & 1) WALK_COLS(d.cs_s, d.spos, true, fs, cell_of_pos(d, xyz(pj)))
-#undef WALK_COLS
+  if (liquids) { WALK_PLANE(d.cs_l, d.pos, j != i, fl) }
+  if (info & 1) { WALK_PLANE(d.cs_s, d.spos, true, fs) }
+#undef WALK_PLANE
   if (info >> 1) {
     // faithful mode, rare: some of this cell's 125 walked cells share a hash bucket, so the
     // reference visits their particles again (Q1).  Entries: k = walked-cell index, extra visits.
@@ -275,7 +293,6 @@ __device__ __forceinline__ int walk_cells(const Dev &d, int i, float4 pi, bool l
       }
     }
   }
-  return cnt;
 }
 
 // ---- neighbour streams ---------------------------------------------------------------------------------

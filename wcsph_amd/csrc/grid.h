@@ -1,4 +1,4 @@
-// grid.h -- HashGrid replacement: dense column-ordered cell table (device.h cell_lin), counting sort of the particles,
+// grid.h -- HashGrid replacement: dense tile-ordered cell table (device.h cell_lin), counting sort of the particles,
 // and (faithful mode) the reference hash table's aliasing reproduced as static per-cell
 // multiplicity tables + a box-filtered bucket-count field for the raw list length.
 // ref: HashGrid.py:44-124.
@@ -11,11 +11,17 @@ __device__ __forceinline__ int ref_hash(int x, int y, int z, int T) {
   return ((p % T) + T) % T;
 }
 
-// packed cell + its index in the cell table (out-of-box bin for particles outside)
+// ref: HashGrid.py:68 -- ti.cast((pos - min) * invGridR, i32): f32 sub, f32 mul (no fma), trunc to zero
 __device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin, bool *finite = nullptr) {
-  const int w = cell_of_pos(d, p, finite);
-  *lin = w >= 0 ? cell_lin(d, w & 1023, (w >> 10) & 1023, w >> 20) : d.ncell_p;
-  return w;
+  float fx = __fmul_rn(__fsub_rn(p.x, d.minx), d.inv_grid);
+  float fy = __fmul_rn(__fsub_rn(p.y, d.miny), d.inv_grid);
+  float fz = __fmul_rn(__fsub_rn(p.z, d.minz), d.inv_grid);
+  bool fin = (fabsf(fx) < 1e9f) && (fabsf(fy) < 1e9f) && (fabsf(fz) < 1e9f);  // NaN/inf => outside
+  if (finite) *finite = (fabsf(fx) <= 3.0e38f) && (fabsf(fy) <= 3.0e38f) && (fabsf(fz) <= 3.0e38f);
+  int cx = (int)fx - d.x0, cy = (int)fy, cz = (int)fz;  // truncation toward zero BEFORE the window shift (Q4)
+  bool in = fin && (unsigned)cx < (unsigned)d.nx && (unsigned)cy < (unsigned)d.ny && (unsigned)cz < (unsigned)d.nz;
+  *lin = in ? cell_lin(d, cx, cy, cz) : d.ncell_p;
+  return in ? (cx | (cy << 10) | (cz << 20)) : -1;
 }
 
 // phase 1 of the counting sort (ref: HashGrid.py:67-76 "insert pos"): cell of every particle, slot in cell.
@@ -150,29 +156,25 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
   *total = tot;
   return off + inc - v;
 }
-// Scan blocks none of whose cells is within the walk radius (2 cells) of the occupied box hold only zeros: their block
+// Scan blocks none of whose tiles is within the walk radius (2 cells) of the occupied box hold only zeros: their block
 // sum is written as 0 without reading, their outputs are left alone (nothing reads the table that far from every
-// particle).  A block is a run of SCAN_TILE / 4 layers of the (column, z) sequence.  The table is read at layer starts
-// (column in the grown box, z in [zlo, zhi + 1]; z = nz is layer 0 of the NEXT column).  The last block (out-of-box bin,
-// grand total) is always processed.  bbox == nullptr: everything.  Every thread of the block must call this.
+// particle).  A tile is needed if it -- or its predecessor in tile order, whose last cell's END is this tile's first
+// START (row_pieces) -- intersects the grown box.  The last block (out-of-box bin, grand total) is always processed.
+// bbox == nullptr: everything.  Every thread of the block must call this.
 __device__ __forceinline__ bool scan_block_active(const Dev &d, const int *bbox, int n) {
   if (!bbox || (int)blockIdx.x == (n - 1) / SCAN_TILE) return true;
   if (bbox[3] < 0) return false;
-  const int lx = max(bbox[0] - 2, 0), ly = max(bbox[1] - 2, 0), zlo = max(bbox[2] - 2, 0);
-  const int hx = min(bbox[3] + 2, d.nx - 1), hy = min(bbox[4] + 2, d.ny - 1), zhi = min(bbox[5] + 2, d.nz - 1) + 1;
-  const int l0 = (d.perm ? ly : lx) >> 1, h0 = (d.perm ? hy : hx) >> 1, l1 = (d.perm ? lx : ly) >> 1, h1 = (d.perm ? hx : hy) >> 1;
-  const int layers = SCAN_TILE >> 2;
-  const int first = blockIdx.x * layers, last = first + layers - 1;   // flattened (column * nz + z)
-  const int ca = first / d.nz, cb = last / d.nz;
+  const int lx = max(bbox[0] - 2, 0), ly = max(bbox[1] - 2, 0), lz = max(bbox[2] - 2, 0);
+  const int hx = min(bbox[3] + 2, d.nx - 1), hy = min(bbox[4] + 2, d.ny - 1), hz = min(bbox[5] + 2, d.nz - 1);
+  const int l0 = (d.perm ? ly : lx) >> T0B, h0 = (d.perm ? hy : hx) >> T0B, l1 = (d.perm ? lx : ly) >> T1B, h1 = (d.perm ? hx : hy) >> T1B;
+  const int l2 = lz >> T2B, h2 = hz >> T2B;
+  const int tiles_per_block = SCAN_TILE >> TILE_SHIFT;
   int need = 0;
-  for (int c = ca + threadIdx.x; c <= cb; c += BLOCK) {
-    const int za = c == ca ? first - c * d.nz : 0, zb = c == cb ? last - c * d.nz : d.nz - 1;   // the block's layers of column c
-    const int T0 = c / d.nt1, T1 = c % d.nt1;
-    const bool in = T0 >= l0 && T0 <= h0 && T1 >= l1 && T1 <= h1;
-    need |= in && za <= zhi && zb >= zlo;
-    if (za == 0 && zhi == d.nz && c > 0) {   // layer 0 doubles as the end of the previous column
-      const int P0 = (c - 1) / d.nt1, P1 = (c - 1) % d.nt1;
-      need |= P0 >= l0 && P0 <= h0 && P1 >= l1 && P1 <= h1;
+  for (int k = threadIdx.x; k <= tiles_per_block; k += BLOCK) {   // the block's tiles and the one before them
+    const int T = blockIdx.x * tiles_per_block - 1 + k;
+    if (T >= 0) {
+      const int t2 = T % d.nt2, q = T / d.nt2, t1 = q % d.nt1, t0 = q / d.nt1;
+      need |= (t0 >= l0 && t0 <= h0 && t1 >= l1 && t1 <= h1 && t2 >= l2 && t2 <= h2);
     }
   }
   return __syncthreads_or(need) != 0;
@@ -230,22 +232,21 @@ __global__ void k_hist_unpack16(const int *packed, int T, int *l) {
 }
 
 // ---- static per-cell info ---------------------------------------------------------------
-// bit0: any solid particle inside the 3 x 3 columns x 5 layers the walk of this cell scans (lets bulk particles skip
-// the solid walk)
+// bit0: any solid particle inside the 5x5x5 walk of this cell (lets bulk particles skip the solid walk)
 __global__ void k_cell_solid_near(Dev d, int *cell_info) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;   // plain index
   if (c >= d.ncell) return;
   int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
-  const int t0 = (d.perm ? cy : cx) >> 1, t1 = (d.perm ? cx : cy) >> 1;
   int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
   int any = 0;
-  for (int e0 = -1; e0 <= 1; e0++) {
-    const int T0 = t0 + e0;
-    if ((unsigned)T0 >= (unsigned)d.nt0) continue;
-    for (int e1 = -1; e1 <= 1; e1++) {
-      const int T1 = t1 + e1;
-      if ((unsigned)T1 >= (unsigned)d.nt1) continue;
-      any |= d.cs_s[layer_lin(d, T0, T1, z1)] > d.cs_s[layer_lin(d, T0, T1, z0)];
+  for (int dx = -2; dx <= 2; dx++) {
+    int x = cx + dx;
+    if ((unsigned)x >= (unsigned)d.nx) continue;
+    for (int dy = -2; dy <= 2; dy++) {
+      int y = cy + dy;
+      if ((unsigned)y >= (unsigned)d.ny) continue;
+      const RowPieces rp = row_pieces(d, d.cs_s, x, y, z0, z1);
+      any |= (rp.hi0 > rp.lo0) | (rp.hi1 > rp.lo1);
     }
   }
   const int l = cell_lin(d, cx, cy, cz);
@@ -361,16 +362,31 @@ __global__ void k_ncount_faithful(Dev d, const int *boxsum) {
   if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
   d.ncount[i] = cnt;
 }
-// clean: every particle of the in-box 5x5x5 cells once, minus the particle itself -- counted by k_build_lists<true> while
-// it scans the candidates; this kernel only applies the reference's per-bucket cap to the particle's own cell
+// clean: every particle of the in-box 5x5x5 cells once, minus the particle itself
 __global__ void k_ncount_clean(Dev d) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl) return;
   int w = __float_as_int(d.pos[i].w);
+  int cnt = 0;
   if (w >= 0) {
-    int c = lin_of(d, w);
+    int cx = w & 1023, cy = (w >> 10) & 1023, cz = w >> 20;
+    int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
+    for (int dx = -2; dx <= 2; dx++) {
+      int x = cx + dx;
+      if ((unsigned)x >= (unsigned)d.nx) continue;
+      for (int dy = -2; dy <= 2; dy++) {
+        int y = cy + dy;
+        if ((unsigned)y >= (unsigned)d.ny) continue;
+        const RowPieces rl = row_pieces(d, d.cs_l, x, y, z0, z1), rs = row_pieces(d, d.cs_s, x, y, z0, z1);
+        cnt += (rl.hi0 - rl.lo0) + (rl.hi1 - rl.lo1) + (rs.hi0 - rs.lo0) + (rs.hi1 - rs.lo1);
+      }
+    }
+    cnt -= 1;
+    int c = cell_lin(d, cx, cy, cz);
     if (d.cs_l[c + 1] - d.cs_l[c] + d.cs_s[c + 1] - d.cs_s[c] > d.max_in_grid) atomicOr(&d.flags[FLAG_ERR], ERRBIT_BUCKET);
   }
+  if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);
+  d.ncount[i] = cnt;
 }
 
 // Compact per-step neighbour lists: the in-support entries of the reference's neighbour row, with the
@@ -378,16 +394,11 @@ __global__ void k_ncount_clean(Dev d) {
 // (Measured and rejected, r02: parking the plane's 20 cell-table ranges in LDS and testing candidates four at a time
 // from a runtime loop over the pieces -- 375 us against 327 us for this form at C3: the kernel issues ~160 M VALU
 // wave-instructions either way and half-empty 4-wide chunks add more than the shorter dependency chains save.)
-template <bool COUNT>   // COUNT: clean neighbour mode, neighborCount is taken from the scan
 __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   const int i = sorted_index();
   if (i >= d.nl) return;
   int2 head = d.nhead[i];
-  if (d.oid[i] >= d.n_owned) {   // ghosts never run a neighbour loop
-    d.nhead[i] = make_int2(liquid_too ? 0 : (head.x & 0xffff), 0);
-    if (COUNT) d.ncount[i] = 0;
-    return;
-  }
+  if (d.oid[i] >= d.n_owned) { d.nhead[i] = make_int2(liquid_too ? 0 : (head.x & 0xffff), 0); return; }  // ghosts never run a neighbour loop
   const float4 pi = d.pos[i];
   const size_t st = (size_t)d.nbr_stride;
   const int cap = d.nbr_cap;
@@ -395,7 +406,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   wl.init(d.nbl + i, st, i, cap);
   ws.init(d.nbs + i, st, 0, cap);
   int sbase = -1;
-  const int cnt = walk_cells<COUNT>(d, i, pi, liquid_too != 0,
+  walk_cells(d, i, pi, liquid_too != 0,
              [&](int j, float3, float, float m) { for (int rep = (int)m; rep > 0; rep--) wl.entry(j); },
              [&](int j, float3, float, float m) {
                if (sbase < 0) { sbase = j; ws.run = j; }
@@ -404,11 +415,6 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   int cl = liquid_too ? wl.finish() : (head.x & 0xffff), cs = ws.finish();
   if (cl > cap || cs > cap) { atomicOr(&d.flags[FLAG_ERR], ERRBIT_LISTCAP); cl = min(cl, cap); cs = min(cs, cap); }
   d.nhead[i] = make_int2(cl | (cs << 16), max(sbase, 0));
-  if (COUNT) {
-    const int c = max(cnt - 1, 0);   // minus the particle itself; 0 outside the grid box
-    if (c > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
-    d.ncount[i] = c;
-  }
 }
 
 // ---- slab decomposition: whole-state load / store in original (row) order -----------------------

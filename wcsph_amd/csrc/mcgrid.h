@@ -123,22 +123,20 @@ __global__ void __launch_bounds__(BLOCK) k_mc_value(Dev d, McDev m) {
   const int bx0 = d.bbox[0], by0 = d.bbox[1], bz0 = d.bbox[2], bx1 = d.bbox[3], by1 = d.bbox[4], bz1 = d.bbox[5];
   const int z0 = max(cz - 2, bz0), z1 = min(cz + 2, bz1) + 1;
   float s = 0.f;
-  const int xa = max(cx - 2, bx0), xb = min(cx + 2, bx1), ya = max(cy - 2, by0), yb = min(cy + 2, by1);
-  if (z1 > z0 && xb >= xa && yb >= ya) {
-    // the columns (device.h cell_lin) that hold the cells [xa, xb] x [ya, yb]: each is one contiguous range of layers
-    // z0 .. z1-1; their cells outside the 5 x 5 (x, y) window weigh zero or are dropped by W > 0 all the same
-    const int a0 = (d.perm ? ya : xa) >> 1, b0 = (d.perm ? yb : xb) >> 1, a1 = (d.perm ? xa : ya) >> 1, b1 = (d.perm ? xb : yb) >> 1;
-    for (int T0 = a0; T0 <= b0; T0++)
-      for (int T1 = a1; T1 <= b1; T1++)
-        for (int j = d.cs_l[layer_lin(d, T0, T1, z0)]; j < d.cs_l[layer_lin(d, T0, T1, z1)]; j++) {
-          const float3 r = p - xyz(d.pos[j]);
-          const float w = mc_cubic_W(m, dot3(r, r));
-          if (w > 0.0f) {
-            const float rho = d.rho[j];
-            if (rho > m.rho_min) s += d.mass / rho * w;
+  if (z1 > z0)
+    for (int xx = max(cx - 2, bx0); xx <= min(cx + 2, bx1); xx++)
+      for (int yy = max(cy - 2, by0); yy <= min(cy + 2, by1); yy++) {
+        const RowPieces rp = row_pieces(d, d.cs_l, xx, yy, z0, z1);
+        for (int piece = 0; piece < 2; piece++)
+          for (int j = piece ? rp.lo1 : rp.lo0; j < (piece ? rp.hi1 : rp.hi0); j++) {
+            const float3 r = p - xyz(d.pos[j]);
+            const float w = mc_cubic_W(m, dot3(r, r));
+            if (w > 0.0f) {
+              const float rho = d.rho[j];
+              if (rho > m.rho_min) s += d.mass / rho * w;
+            }
           }
-        }
-  }
+      }
   m.value[t] = s;
 }
 

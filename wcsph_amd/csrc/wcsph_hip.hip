@@ -293,11 +293,12 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
     d.x0 = x0; d.nx = x1 - x0;
     ncell = (long)d.nx * d.ny * d.nz;
   }
-  // column order (device.h cell_lin): the longer of x / y is the outer axis
+  // tile order (device.h cell_lin): the longer of x / y is the outer axis
   d.perm = d.ny > d.nx ? 1 : 0;
-  d.nt0 = ((d.perm ? d.ny : d.nx) + 1) >> 1;
-  d.nt1 = ((d.perm ? d.nx : d.ny) + 1) >> 1;
-  const long ncell_p = ((long)d.nt0 * d.nt1 * d.nz) << 2;
+  d.nt0 = ((d.perm ? d.ny : d.nx) + (1 << T0B) - 1) >> T0B;
+  d.nt1 = ((d.perm ? d.nx : d.ny) + (1 << T1B) - 1) >> T1B;
+  d.nt2 = (d.nz + (1 << T2B) - 1) >> T2B;
+  const long ncell_p = ((long)d.nt0 * d.nt1 * d.nt2) << TILE_SHIFT;
   if (ncell_p > 0x7fff0000L) return ctx->fail(WCSPH_EARG, "grid has too many cells");
   d.ncell = (int)ncell; d.ncell_p = (int)ncell_p;
   if (ctx->win_x1 >= 0) DALLOC(d.gid, (size_t)ctx->capacity + 1);   // slab rows carry their global particle id
@@ -421,10 +422,7 @@ static int grid_end(wcsph_ctx *ctx) {
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
   }
-  if (d.nl > 0) {
-    if (d.faithful) hipLaunchKernelGGL(k_build_lists<false>, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
-    else hipLaunchKernelGGL(k_build_lists<true>, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
-  }
+  if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
   LAUNCHCHK();
   ctx->grid_valid = true;
   ctx->bk_valid = false;
@@ -1747,7 +1745,7 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "visc_minv_residual_vort") { PASS(k_visc_minv_residual_vort, ctx->dt); return 0; }
     if (nm == "vorticity") { PASS(k_vorticity, ctx->dt); return 0; }
     if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; PASS(k_visc_minv_residual, ctx->dt); return 0; }
-    if (nm == "build_lists") { if (ctx->d.faithful) PASS(k_build_lists<false>, 1); else PASS(k_build_lists<true>, 1); return 0; }
+    if (nm == "build_lists") { PASS(k_build_lists, 1); return 0; }
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
     return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");
   };
