@@ -327,11 +327,14 @@ __global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags, co
 }
 // gridCount = static boundary particles + this step's liquid particles (both global sums on a slab decomposition);
 // the cap applies to every bucket, not only walked ones
-__global__ void k_bucket_sum(Dev d, const int *bs, const int *bl, int *bcount, int *flags) {
+// bcount8: the same counts as bytes (saturated at 255) -- a 3 MB table that stays in the 4 MB L2 of every XCD, where the
+// 12 MB of ints do not: k_cellval_occ's gathers are random (used while max_in_grid <= 255: every legal count fits)
+__global__ void k_bucket_sum(Dev d, const int *bs, const int *bl, int *bcount, unsigned char *bcount8, int *flags) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.table_size) return;
   const int v = bs[b] + bl[b];
   bcount[b] = v;
+  bcount8[b] = (unsigned char)min(v, 255);
   if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
 }
 __global__ void k_boxsum(Dev d, const int *in, int *out, int len, int stride, const int *bb, int mx, int my) {
@@ -361,6 +364,142 @@ __global__ void k_ncount_faithful(Dev d, const int *boxsum) {
   }
   if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
   d.ncount[i] = cnt;
+}
+// The same restricted to where the liquid is: the grid is cut into REGIONS of BC0 x BC1 x BCZ cells (outer x middle x z of
+// the tile order = 4 x 2 x 1 tiles).  k_region_occ flags the regions that hold particles; k_cellval_occ gathers
+// gridCount[hash(cell)] for every region that is, or touches, a flagged one (the hash scatters neighbouring cells all
+// over the table: these random gathers are the cost, so each cell is gathered ONCE); k_ncount_box loads a flagged
+// region and its 2-cell halo into LDS, runs the three 5-tap sums there and writes neighborCount of the particles in
+// its cells.  The cost follows the liquid's volume, not its bounding box (the five-launch version above: 100 us at
+// C3 at rest, 290 us once the dam has spread over the domain).
+#define BC0 8
+#define BC1 8
+#define BCZ 16
+struct Regions { int nb0, nb1, nbz; };
+__device__ __forceinline__ Regions regions_of(const Dev &d) {
+  Regions r;
+  r.nb0 = ((d.perm ? d.ny : d.nx) + BC0 - 1) / BC0; r.nb1 = ((d.perm ? d.nx : d.ny) + BC1 - 1) / BC1; r.nbz = (d.nz + BCZ - 1) / BCZ;
+  return r;
+}
+// one thread per region: does it hold a particle?  (one contiguous range per (outer, middle) tile pair; only tiles
+// touching the occupied box can hold particles, and the cell table is current for exactly those)
+__global__ void k_region_occ(Dev d, int *occ) {
+  const Regions R = regions_of(d);
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= R.nb0 * R.nb1 * R.nbz) return;
+  const int bz = g % R.nbz, q = g / R.nbz, o0 = (q / R.nb1) * BC0, o1 = (q % R.nb1) * BC1, oz = bz * BCZ;
+  const int *bb = d.bbox;
+  int any = 0;
+  if (bb[3] >= 0) {
+    const int l0 = d.perm ? bb[1] : bb[0], h0 = d.perm ? bb[4] : bb[3], l1 = d.perm ? bb[0] : bb[1], h1 = d.perm ? bb[3] : bb[4];
+    if (!(o0 > h0 || o0 + BC0 <= l0 || o1 > h1 || o1 + BC1 <= l1 || oz > bb[5] || oz + BCZ <= bb[2])) {
+      const int za = max(oz, bb[2]) >> T2B, zb = min(min(oz + BCZ, d.nz) - 1, bb[5]) >> T2B;
+      for (int k = 0; k < (BC0 >> T0B) * (BC1 >> T1B); k++) {
+        const int t0 = (o0 >> T0B) + k / (BC1 >> T1B), t1 = (o1 >> T1B) + k % (BC1 >> T1B);
+        const int c0 = t0 << T0B, c1 = t1 << T1B;
+        if (t0 < d.nt0 && t1 < d.nt1 && c0 <= h0 && c0 + (1 << T0B) > l0 && c1 <= h1 && c1 + (1 << T1B) > l1) {
+          const int base = (t0 * d.nt1 + t1) * d.nt2;
+          any |= d.cs_l[(base + zb + 1) << TILE_SHIFT] > d.cs_l[(base + za) << TILE_SHIFT];
+        }
+      }
+    }
+  }
+  occ[g] = any;
+}
+// one block per region that is or touches an occupied one: cellval[plain index] = gridCount[hash(cell)]
+template <class T>
+__global__ void __launch_bounds__(BLOCK) k_cellval_occ(Dev d, const T *bcount, const int *occ, int *cellval) {
+  const Regions R = regions_of(d);
+  const int bz = blockIdx.x % R.nbz, q = blockIdx.x / R.nbz, r1 = q % R.nb1, r0 = q / R.nb1;
+  __shared__ int need;
+  if (threadIdx.x == 0) need = 0;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int e0 = r0 + threadIdx.x / 9 - 1, e1 = r1 + (threadIdx.x / 3) % 3 - 1, ez = bz + threadIdx.x % 3 - 1;
+    if ((unsigned)e0 < (unsigned)R.nb0 && (unsigned)e1 < (unsigned)R.nb1 && (unsigned)ez < (unsigned)R.nbz && occ[(e0 * R.nb1 + e1) * R.nbz + ez]) need = 1;
+  }
+  __syncthreads();
+  if (!need) return;
+  const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
+#pragma unroll
+  for (int k = 0; k < BC0 * BC1 * BCZ / BLOCK; k++) {
+    const int t = threadIdx.x + k * BLOCK;
+    const int z = bz * BCZ + t % BCZ, u = t / BCZ, a1 = r1 * BC1 + u % BC1, a0 = r0 * BC0 + u / BC1;
+    if (a0 < n0 && a1 < n1 && z < d.nz) {
+      const int x = d.perm ? a1 : a0, y = d.perm ? a0 : a1;
+      cellval[(x * d.ny + y) * d.nz + z] = (int)bcount[ref_hash(x + d.x0, y, z, d.table_size)];
+    }
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_ncount_box(Dev d, const int *cellval, const int *occ) {
+  __shared__ int b0[(BC0 + 4) * (BC1 + 4) * (BCZ + 4)];
+  __shared__ int b1[(BC0 + 4) * (BC1 + 4) * BCZ];
+  const Regions R = regions_of(d);
+  const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
+  const int bz = blockIdx.x % R.nbz, bq = blockIdx.x / R.nbz;
+  const int o0 = (bq / R.nb1) * BC0, o1 = (bq % R.nb1) * BC1, oz = bz * BCZ;   // first cell of the region
+  const int *bb = d.bbox;
+  // particles outside the grid box (the last bin of the sort) have no list at all
+  if (blockIdx.x == 0) for (int j = d.cs_l[d.ncell_p] + threadIdx.x; j < d.nl; j += BLOCK) d.ncount[j] = 0;
+  if (!occ[blockIdx.x]) return;
+  const int l0 = d.perm ? bb[1] : bb[0], h0 = d.perm ? bb[4] : bb[3], l1 = d.perm ? bb[0] : bb[1], h1 = d.perm ? bb[3] : bb[4];
+  // gridCount of the region's cells + halo (0 outside the grid: the reference walks in-box cells only)
+  constexpr int E0 = BC0 + 4, E1 = BC1 + 4, EZ = BCZ + 4;
+  {
+    constexpr int NG = (E0 * E1 * EZ + BLOCK - 1) / BLOCK;
+    int v[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+      const int t = threadIdx.x + k * BLOCK;
+      const int z = oz - 2 + t % EZ, q = t / EZ, a1 = o1 - 2 + q % E1, a0 = o0 - 2 + q / E1;
+      v[k] = 0;
+      if (t < E0 * E1 * EZ && (unsigned)a0 < (unsigned)n0 && (unsigned)a1 < (unsigned)n1 && (unsigned)z < (unsigned)d.nz)
+        v[k] = cellval[((d.perm ? a1 : a0) * d.ny + (d.perm ? a0 : a1)) * d.nz + z];
+    }
+#pragma unroll
+    for (int k = 0; k < NG; k++) if (threadIdx.x + k * BLOCK < E0 * E1 * EZ) b0[threadIdx.x + k * BLOCK] = v[k];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < E0 * E1 * BCZ; t += BLOCK) {   // along z
+    const int z = t % BCZ, q = t / BCZ;
+    const int *r = b0 + q * EZ + z;
+    b1[t] = r[0] + r[1] + r[2] + r[3] + r[4];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < E0 * BC1 * BCZ; t += BLOCK) {   // along the middle axis -> b0 as [E0][BC1][BCZ]
+    const int z = t % BCZ, q = t / BCZ, a1 = q % BC1, a0 = q / BC1;
+    const int *r = b1 + (a0 * E1 + a1) * BCZ + z;
+    b0[t] = r[0] + r[BCZ] + r[2 * BCZ] + r[3 * BCZ] + r[4 * BCZ];
+  }
+  __syncthreads();
+  // along the outer axis, then the particles of the cell (the cell-table and cell_info loads of a thread's cells are
+  // issued together)
+  constexpr int NC = BC0 * BC1 * BCZ / BLOCK;
+  int ja[NC], jb[NC], info[NC];
+  const int zmin = bb[2], zmax = bb[5];
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    const int t = threadIdx.x + k * BLOCK;
+    const int zl = t % BCZ, q = t / BCZ, a1l = q % BC1, a0l = q / BC1;
+    const int a0 = o0 + a0l, a1 = o1 + a1l, z = oz + zl;
+    ja[k] = jb[k] = info[k] = 0;
+    if (a0 > h0 || a0 < l0 || a1 > h1 || a1 < l1 || z > zmax || z < zmin) continue;   // outside the occupied box: no particle
+    const int lin = cell_lin(d, d.perm ? a1 : a0, d.perm ? a0 : a1, z);
+    ja[k] = d.cs_l[lin]; jb[k] = d.cs_l[lin + 1]; info[k] = d.cell_info[lin];
+  }
+#pragma unroll
+  for (int k = 0; k < NC; k++) {
+    if (jb[k] <= ja[k]) continue;
+    const int t = threadIdx.x + k * BLOCK;
+    const int zl = t % BCZ, q = t / BCZ, a1l = q % BC1, a0l = q / BC1;
+    const int *r = b0 + (a0l * BC1 + a1l) * BCZ + zl;
+    constexpr int S = BC1 * BCZ;
+    const int sum = r[0] + r[S] + r[2 * S] + r[3 * S] + r[4 * S];
+    const int self = (info[k] >> 1) ? d.alias[(size_t)((info[k] >> 1) - 1) * ALIAS_STRIDE + 1] : 1;
+    const int cnt = sum - self;
+    if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
+    for (int j = ja[k]; j < jb[k]; j++) d.ncount[j] = cnt;
+  }
 }
 // clean: every particle of the in-box 5x5x5 cells once, minus the particle itself
 __global__ void k_ncount_clean(Dev d) {

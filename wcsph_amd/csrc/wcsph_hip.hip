@@ -36,7 +36,10 @@ struct wcsph_ctx {
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
   int *bcount = nullptr, *bcount_s = nullptr, *bcount_l = nullptr, *cellval = nullptr, *celltmp = nullptr;   // gridCount = _s (static solids) + _l (liquid, per step)
   int *bbox_part = nullptr;
-  int n_alias = 0, scan_blocks = 0;
+  int n_alias = 0, scan_blocks = 0, n_regions = 0;
+  unsigned char *bcount8 = nullptr;
+  int *region_occ = nullptr;      // neighborCount regions that hold particles (grid.h k_region_occ)
+  bool ncount_split = getenv("WCSPH_NCOUNT_SPLIT") != nullptr;   // development: the five-launch neighborCount
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false;
   // staging for original-order transfers
@@ -310,7 +313,13 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1));
   if (d.faithful) {
     DALLOC(ctx->bcount, d.table_size + 1); DALLOC(ctx->bcount_s, d.table_size + 1); DALLOC(ctx->bcount_l, d.table_size + 1);   // [T] stays 0: the scan's end sentinel
-    DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->celltmp, d.ncell);
+    DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->bcount8, d.table_size + 1);
+    if (ctx->ncount_split) DALLOC(ctx->celltmp, d.ncell);
+    {
+      const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
+      ctx->n_regions = ((n0 + BC0 - 1) / BC0) * ((n1 + BC1 - 1) / BC1) * ((d.nz + BCZ - 1) / BCZ);
+      DALLOC(ctx->region_occ, (size_t)ctx->n_regions);
+    }
   }
   // liquids: identity order until the first grid update
   std::vector<float4> tmp((size_t)(d.nl > d.ns ? d.nl : d.ns));
@@ -411,14 +420,25 @@ static int grid_end(wcsph_ctx *ctx) {
   hipStream_t s = ctx->stream;
   if (d.faithful) {
     const int *bb = d.bbox;
-    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, (const int *)ctx->bcount_l, ctx->bcount, d.flags);
-    // separable 5x5x5 box sum of gridCount[hash(cell)] on the occupied box: values on box +-2 in every axis, the z pass
-    // on box +-2 in x and y, the y pass on box +-2 in x, the x pass on the box itself
-    hipLaunchKernelGGL(k_cellval, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags, bb);
-    hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nz, 1, bb, 2, 2);
-    hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp, ctx->cellval, d.ny, d.nz, bb, 2, 0);
-    hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nx, d.ny * d.nz, bb, 0, 0);
-    if (d.nl > 0) hipLaunchKernelGGL(k_ncount_faithful, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, (const int *)ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
+    // neighborCount: 5x5x5 box sum of gridCount[hash(cell)] around every occupied cell, one LDS-tiled launch (grid.h)
+    if (d.nl > 0) {
+      if (ctx->ncount_split) {   // the separable five-launch version on the occupied box (kept for A/B timing)
+        hipLaunchKernelGGL(k_cellval, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags, bb);
+        hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nz, 1, bb, 2, 2);
+        hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp, ctx->cellval, d.ny, d.nz, bb, 2, 0);
+        hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nx, d.ny * d.nz, bb, 0, 0);
+        hipLaunchKernelGGL(k_ncount_faithful, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp);
+      } else {
+        const int nb = ctx->n_regions;
+        hipLaunchKernelGGL(k_region_occ, dim3(nblk(nb)), dim3(BLOCK), 0, s, d, ctx->region_occ);
+        if (d.max_in_grid <= 255)
+          hipLaunchKernelGGL(k_cellval_occ<unsigned char>, dim3(nb), dim3(BLOCK), 0, s, d, (const unsigned char *)ctx->bcount8, (const int *)ctx->region_occ, ctx->cellval);
+        else
+          hipLaunchKernelGGL(k_cellval_occ<int>, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, (const int *)ctx->region_occ, ctx->cellval);
+        hipLaunchKernelGGL(k_ncount_box, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
+      }
+    }
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
   }
