@@ -53,6 +53,7 @@ struct Dev {
   float4 *minv0, *minv1, *minv2;          // rows of cg_Minv
   float *rho, *adv_rho, *pressure, *vel_max, *alpha, *kbuf;
   float4 *pk;                             // per-pass packed gather record (pos.xyz, payload)
+  float4 *pr;                             // (pos.xyz, rho): one gather instead of two in the viscosity / vorticity / tension walks
   // pcisph.py / iisph.py private fields
   float4 *d_vel_pre, *pos_star, *vel_star, *d_ii, *dij_pj;
   float *a_ii, *pressure_pre;

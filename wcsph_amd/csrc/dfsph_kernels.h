@@ -18,7 +18,9 @@ __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
   float sl = 0.f, ss = 0.f;
   walk<8, true>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
           [&](int, float3, float r2) { ss += cubic_W(d, r2); });
-  d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  d.rho[i] = rho;
+  d.pr[i] = make_float4(pi.x, pi.y, pi.z, rho);
 }
 
 // ref: dfsph.py:345-372 compute_dfsph_coff
@@ -55,7 +57,9 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
             ss += cubic_W(d, r2);
             sg = sg + r * (cubic_gradW_scale(d, r2) * d.VS0);
           });
-  d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  d.rho[i] = rho;
+  d.pr[i] = make_float4(pi.x, pi.y, pi.z, rho);
   sq += dot3(sg, sg);
   d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
 }
@@ -84,7 +88,9 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
             sg = sg + r * (gw * d.VS0);
             a += d.VS0 * gw * dot3(vi, r);
           });
-  d.rho[i] = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
+  d.rho[i] = rho;
+  d.pr[i] = make_float4(pi.x, pi.y, pi.z, rho);
   sq += dot3(sg, sg);
   d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
   const float kv = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
@@ -159,6 +165,14 @@ __global__ void k_make_k(Dev d, float *kap, float bias) {
   if (d.oid[i] < d.n_owned) kap[i] += k;
 }
 
+// (pos.xyz, rho) records for the viscosity / vorticity / tension walks, for every row (ghosts included), when rho did not
+// come from this context's own density pass
+__global__ void k_pack_pr(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  float4 p = d.pos[i];
+  d.pr[i] = make_float4(p.x, p.y, p.z, d.rho[i]);
+}
 // (pos.xyz, kb) records for k_vel_from_k when k comes from an existing array (warm start: kappa_v)
 __global__ void k_pack_k(Dev d, const float *kb) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,7 +272,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_normal(Dev d) {
   LOAD_I
   if (!own) return;
   float3 n = f3(0, 0, 0);
-  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
+  walk<8>(d, i, pi, d.pr, [](int, float4 p) { return p.w; },
           [&](int, float3 r, float r2, float rhoj) { n = n + r * (d.mass * frcp(rhoj) * cubic_gradW_scale(d, r2)); },
           [&](int, float3, float) {});
   d.normal[i] = f4(n * d.h, 0);
@@ -303,7 +317,7 @@ __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const 
   float3 ret = f3(0, 0, 0);
   const float cl = d.dim_coff * d.visc * d.mass;
   const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
-  walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(x, j); xj.w = nb_ld(d.rho, j); return xj; },
+  walk<8, true>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(x, j); xj.w = p.w; return xj; },
           [&](int, float3 r, float r2, float4 xj) {
             float s = cl * dot3(xi - xyz(xj), r) * frcp(xj.w * (r2 + e));
             ret = ret + r * (s * cubic_gradW_scale(d, r2));
@@ -336,7 +350,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
     m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
     m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
   };
-  walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.rho, j); },
+  walk<8, true>(d, i, pi, d.pr, [](int, float4 p) { return p.w; },
           [&](int, float3 r, float r2, float rhoj) { accum(r, cl * frcp(rhoj * (r2 + e)) * cubic_gradW_scale(d, r2)); },
           [&](int, float3 r, float r2) { accum(r, cs * frcp(r2 + e) * cubic_gradW_scale(d, r2)); });
   const float f = dt / rhoi;
@@ -384,7 +398,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
       m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
       m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
     };
-    walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { float4 xj = nb_ld(d.vel_guess, j); xj.w = nb_ld(d.rho, j); return xj; },
+    walk<8, true>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(d.vel_guess, j); xj.w = p.w; return xj; },
             [&](int, float3 r, float r2, float4 xj) {
               const float c = cl * cubic_gradW_scale(d, r2) * frcp(xj.w * (r2 + e));
               accum(r, c);
@@ -436,7 +450,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float 
     const float c2 = d.vort_coff / rhoi * d.mass;
     const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
     struct XVW { float4 x, v, w; };
-    walk<4, true>(d, i, pi, d.pos, [&](int j, float4) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = nb_ld(d.rho, j); q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
+    walk<4, true>(d, i, pi, d.pr, [&](int j, float4 p) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = p.w; q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
             [&](int, float3 r, float r2, XVW q) {
               const float g = cubic_gradW_scale(d, r2);
               const float irho = frcp(q.x.w);
@@ -541,7 +555,7 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
   const float c2 = d.vort_coff / rhoi * d.mass;
   const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
   struct WV { float4 w, v; };
-  walk<4, true>(d, i, pi, d.pos, [&](int j, float4) { WV p; p.w = nb_ld(d.omega, j); p.w.w = nb_ld(d.rho, j); p.v = nb_ld(d.vel, j); return p; },
+  walk<4, true>(d, i, pi, d.pr, [&](int j, float4 q) { WV p; p.w = nb_ld(d.omega, j); p.w.w = q.w; p.v = nb_ld(d.vel, j); return p; },
        [&](int, float3 r, float r2, WV pj) {
          float3 dw = wi - xyz(pj.w);
          float g = cubic_gradW_scale(d, r2);

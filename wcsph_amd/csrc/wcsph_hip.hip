@@ -42,6 +42,7 @@ struct wcsph_ctx {
   bool ncount_split = getenv("WCSPH_NCOUNT_SPLIT") != nullptr;   // development: the five-launch neighborCount
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false;
+  bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats
   std::vector<float> solid_host;  // original-order solid positions
@@ -223,7 +224,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.cg_r, nl); DALLOC(d.cg_dir, nl); DALLOC(d.cg_Ad, nl); DALLOC(d.cg_s, nl);
   DALLOC(d.minv0, nl); DALLOC(d.minv1, nl); DALLOC(d.minv2, nl);
   DALLOC(d.rho, nl); DALLOC(d.adv_rho, nl); DALLOC(d.pressure, nl); DALLOC(d.vel_max, nl); DALLOC(d.alpha, nl); DALLOC(d.kbuf, nl);
-  DALLOC(d.ncount, nl); DALLOC(d.nhead, nl); DALLOC(d.pk, nl);
+  DALLOC(d.ncount, nl); DALLOC(d.nhead, nl); DALLOC(d.pk, nl); DALLOC(d.pr, nl);
   DALLOC(d.d_vel_pre, nl); DALLOC(d.pos_star, nl); DALLOC(d.vel_star, nl); DALLOC(d.d_ii, nl); DALLOC(d.dij_pj, nl);
   DALLOC(d.a_ii, nl); DALLOC(d.pressure_pre, nl);
   d.nbr_stride = (int)((nl + 63) / 64 * 64);
@@ -395,6 +396,7 @@ static int grid_begin(wcsph_ctx *ctx) {
   // overflow / non-finite conditions are re-detected by every update: what the previous one raised has been reported by
   // the pull_scalars() calls of its step and must not stick to the context (the reference prints and keeps stepping)
   HIPCHK(hipMemsetAsync(d.flags + FLAG_ERR, 0, sizeof(int), s));
+  ctx->pr_valid = false;   // rows are re-sorted
   if (d.faithful) HIPCHK(hipMemsetAsync(ctx->bcount_l, 0, (size_t)d.table_size * sizeof(int), s));
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
@@ -631,6 +633,7 @@ int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t byt
   LAUNCHCHK();
   HIPCHK(hipStreamSynchronize(s));
   if (field == WCSPH_F_POS) ctx->grid_valid = false;  // cells are stale until the next grid update
+  ctx->pr_valid = false;
   return WCSPH_OK;
 }
 
@@ -671,6 +674,7 @@ int wcsph_field_rows_from_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n,
   LAUNCHCHK();
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (field == WCSPH_F_POS) ctx->grid_valid = false;
+  ctx->pr_valid = false;
   return WCSPH_OK;
 }
 
@@ -693,6 +697,7 @@ int wcsph_field_scatter_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, in
   else hipLaunchKernelGGL(k_scatter_rows1, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, (float *)fd.ptr, (const int *)ctx->d.where, d_idx, n, (const float *)d_src);
   LAUNCHCHK();
   if (field == WCSPH_F_POS) ctx->grid_valid = false;
+  ctx->pr_valid = false;
   return WCSPH_OK;
 }
 int wcsph_set_owned(wcsph_ctx *ctx, int32_t n_owned) {
@@ -754,6 +759,15 @@ int wcsph_set_iters(wcsph_ctx *ctx, int32_t vs, int32_t dv, int32_t pr) {
     if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk8(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
     LAUNCHCHK();                                                                                  \
   } while (0)
+/* walks over the (pos, rho) records: packed first unless this context's own density pass just wrote them for every row */
+#define RPASS(kern, ...)                                                                          \
+  do {                                                                                            \
+    if (!ctx->pr_valid && ctx->d.nl > 0) {                                                        \
+      hipLaunchKernelGGL(k_pack_pr, dim3(nblk(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d);  \
+      ctx->pr_valid = true;                                                                       \
+    }                                                                                             \
+    PASS(kern, ##__VA_ARGS__);                                                                    \
+  } while (0)
 #define ELEM(kern, ...)                                                                           \
   do {                                                                                            \
     if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
@@ -776,7 +790,7 @@ int wcsph_dfsph_reset_param(wcsph_ctx *ctx) {
   ctx->dt = 0.001f;  // ref: dfsph.py:178
   return WCSPH_OK;
 }
-int wcsph_dfsph_compute_density(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_density); return WCSPH_OK; }
+int wcsph_dfsph_compute_density(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_density); ctx->pr_valid = ctx->d.n_owned == ctx->d.nl; return WCSPH_OK; }
 int wcsph_dfsph_compute_coff(wcsph_ctx *ctx) { NEED_GRID(); PASS(k_coff); return WCSPH_OK; }
 
 int wcsph_dfsph_warmstart_divergence(wcsph_ctx *ctx) {
@@ -869,7 +883,7 @@ int wcsph_dfsph_tension(wcsph_ctx *ctx) {
     ELEM(k_tension_accel_literal, ctx->bk);
     return WCSPH_OK;
   }
-  PASS(k_tension_normal);
+  RPASS(k_tension_normal);
   PASS(k_tension_accel);
   return WCSPH_OK;
 }
@@ -877,7 +891,7 @@ int wcsph_dfsph_tension(wcsph_ctx *ctx) {
 int wcsph_dfsph_visc_init(wcsph_ctx *ctx) {
   NEED_GRID();
   ELEM(k_visc_guess);                   // also clears ACC_DZERO and ACC_DAD
-  PASS(k_visc_minv_residual, ctx->dt);  // dfsph.py:202-223 in one neighbour walk
+  RPASS(k_visc_minv_residual, ctx->dt);  // dfsph.py:202-223 in one neighbour walk
   int rc = pull_scalars(ctx);
   if (rc) return rc;
   ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
@@ -887,7 +901,7 @@ int wcsph_dfsph_visc_init(wcsph_ctx *ctx) {
 int wcsph_dfsph_visc_iter(wcsph_ctx *ctx) {
   NEED_GRID();
   // ACC_DAD was cleared by k_visc_guess / the previous k_visc_dir, ACC_DNEW is cleared by k_visc_Ad
-  PASS(k_visc_Ad, ctx->dt);
+  RPASS(k_visc_Ad, ctx->dt);
   ELEM(k_visc_update, ctx->cg_delta);
   ELEM(k_visc_dir, ctx->cg_delta);  // delta_old == the delta this iteration started with (dfsph.py:234)
   int rc = pull_scalars(ctx);
@@ -900,7 +914,7 @@ int wcsph_dfsph_visc_end(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_visc_end, ctx->d
 
 int wcsph_dfsph_vorticity(wcsph_ctx *ctx) {
   NEED_GRID();
-  PASS(k_vorticity, ctx->dt);
+  RPASS(k_vorticity, ctx->dt);
   ELEM(k_vorticity_integrate, ctx->dt);
   return WCSPH_OK;
 }
@@ -937,8 +951,8 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
   // its first iteration can take delta_zero from the device (the reference waits after each, dfsph.py:86-91)
   ELEM(k_visc_guess);
   const bool fuse_vort = ctx->vort_fuse;
-  if (fuse_vort) PASS(k_visc_minv_residual_vort, ctx->dt); else PASS(k_visc_minv_residual, ctx->dt);
-  PASS(k_visc_Ad, ctx->dt);
+  if (fuse_vort) RPASS(k_visc_minv_residual_vort, ctx->dt); else RPASS(k_visc_minv_residual, ctx->dt);
+  RPASS(k_visc_Ad, ctx->dt);
   ELEM(k_visc_update, 0.0f, 1);
   if ((rc = pull_scalars(ctx))) return rc;
   ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
@@ -954,7 +968,7 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
                (double)ctx->cg_delta_zero < (double)ctx->p.eps)
       break;
     ELEM(k_visc_dir, ctx->cg_delta_old);   // beta = delta_new (still in ACC_DNEW) / delta the last iteration started with
-    PASS(k_visc_Ad, ctx->dt);
+    RPASS(k_visc_Ad, ctx->dt);
     ELEM(k_visc_update, ctx->cg_delta);
     if ((rc = pull_scalars(ctx))) return rc;
     ctx->cg_delta_old = ctx->cg_delta;
@@ -1041,6 +1055,7 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   if (ctx->d.n_owned == ctx->d.nl) {
     PASS(k_density_coff_warm, ctx->dt);  // compute_density + compute_dfsph_coff + first warm-start pass in one walk
     ctx->warm_fused = true;
+    ctx->pr_valid = true;                // ... and the (pos, rho) records of every row
   } else PASS(k_density_coff);           // compute_density + compute_dfsph_coff in one walk
   if ((rc = wcsph_dfsph_solve_divergence(ctx))) return rc;
   ctx->in_step = true;
@@ -1076,7 +1091,7 @@ static Dev sesph_view(const wcsph_ctx *ctx) {
     LAUNCHCHK();                                                                                  \
   } while (0)
 int wcsph_sesph_reset_param(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_reset); ctx->dt = 0.001f; return WCSPH_OK; }
-int wcsph_sesph_density(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_density); return WCSPH_OK; }
+int wcsph_sesph_density(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_density); ctx->pr_valid = false; return WCSPH_OK; }
 int wcsph_sesph_pressure(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_pressure); return WCSPH_OK; }
 int wcsph_sesph_force(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_force); return WCSPH_OK; }
 int wcsph_sesph_integrate(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_integrate, ctx->dt); return WCSPH_OK; }
@@ -1095,6 +1110,7 @@ int wcsph_pcisph_reset_param(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_pc_reset); c
 int wcsph_pcisph_compute_nonpressure_force(wcsph_ctx *ctx) {
   NEED_GRID();
   SPASS(k_ss_density);   // rho_i = (VL0 (W0 + sum) + VS0 sum_s) rho_0, pcisph.py:203,212,215
+  ctx->pr_valid = false;
   SPASS(k_pc_force, ctx->p.pc_visc, ctx->p.pc_visc_b);
   return WCSPH_OK;
 }
@@ -1149,11 +1165,15 @@ static Dev iisph_view(const wcsph_ctx *ctx) {   // sesph kernel constants + the 
 #define IPASS(kern, ...)                                                                          \
   do {                                                                                            \
     Dev iv_ = iisph_view(ctx);                                                                    \
+    if (!ctx->pr_valid && iv_.nl > 0) {                                                           \
+      hipLaunchKernelGGL(k_pack_pr, dim3(nblk(iv_.nl)), dim3(BLOCK), 0, ctx->stream, iv_);        \
+      ctx->pr_valid = true;                                                                       \
+    }                                                                                             \
     if (iv_.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk8(iv_.nl)), dim3(BLOCK), 0, ctx->stream, iv_, ##__VA_ARGS__); \
     LAUNCHCHK();                                                                                  \
   } while (0)
 int wcsph_iisph_reset_param(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_ss_reset); ctx->dt = 0.001f; return WCSPH_OK; }
-int wcsph_iisph_compute_density(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_density); return WCSPH_OK; }
+int wcsph_iisph_compute_density(wcsph_ctx *ctx) { NEED_GRID(); SPASS(k_ss_density); ctx->pr_valid = false; return WCSPH_OK; }
 int wcsph_iisph_visc_init(wcsph_ctx *ctx) {
   NEED_GRID();
   ELEM(k_visc_guess);
@@ -1528,6 +1548,7 @@ int wcsph_halo_unpack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, c
   hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(n * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, d_idx, n, (const float *)d_in);
   LAUNCHCHK();
   for (int k = 0; k < n_fields; k++) if (fields[k] == WCSPH_F_POS) ctx->grid_valid = false;
+  ctx->pr_valid = false;
   return WCSPH_OK;
 }
 int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows) {
@@ -1595,10 +1616,10 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
   int rc = 0;
   const float dt = ctx->dt;
   switch (ph) {
-    case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); break;
-    case WCSPH_PH_DENSITY_COFF_WARM: PASS(k_density_coff_warm, dt); break;
-    case WCSPH_PH_VISC_MINV_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual, dt); break;
-    case WCSPH_PH_VISC_MINV_RESIDUAL_VORT: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_minv_residual_vort, dt); break;
+    case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); ctx->pr_valid = false; break;   // ghost rows: rho arrives by halo exchange
+    case WCSPH_PH_DENSITY_COFF_WARM: PASS(k_density_coff_warm, dt); ctx->pr_valid = false; break;
+    case WCSPH_PH_VISC_MINV_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; RPASS(k_visc_minv_residual, dt); break;
+    case WCSPH_PH_VISC_MINV_RESIDUAL_VORT: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; RPASS(k_visc_minv_residual_vort, dt); break;
     case WCSPH_PH_DRHO_DIV_WARM: HOT_DRHO_DIV(DRHO_WARM, dt); break;
     case WCSPH_PH_VEL_WARM: HOT_VEL(1, ctx->d.kappa_v, dt, 1); break;
     case WCSPH_PH_DRHO_DIV_BEGIN: HOT_DRHO_DIV(DRHO_BEGIN, dt); break;
@@ -1613,16 +1634,16 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_DRHO_PRESS_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_PRESS(DRHO_ITER, dt); break;
     case WCSPH_PH_END_PRESS: ELEM(k_end_press, dt); break;
     case WCSPH_PH_CLEAR: ELEM(k_clear_nonpressure); break;
-    case WCSPH_PH_TENSION_NORMAL: if (ctx->p.tension_fixed == 0) return ctx->fail(WCSPH_EARG, "literal tension is not available phase by phase"); PASS(k_tension_normal); break;
+    case WCSPH_PH_TENSION_NORMAL: if (ctx->p.tension_fixed == 0) return ctx->fail(WCSPH_EARG, "literal tension is not available phase by phase"); RPASS(k_tension_normal); break;
     case WCSPH_PH_TENSION_ACCEL: if (ctx->p.tension_fixed == 0) return ctx->fail(WCSPH_EARG, "literal tension is not available phase by phase"); PASS(k_tension_accel); break;
     case WCSPH_PH_VISC_GUESS: ELEM(k_visc_guess); break;
-    case WCSPH_PH_VISC_MINV: PASS(k_visc_minv, dt); break;
-    case WCSPH_PH_VISC_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; PASS(k_visc_residual, dt); break;
-    case WCSPH_PH_VISC_AD: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DAD))) return rc; PASS(k_visc_Ad, dt); break;
+    case WCSPH_PH_VISC_MINV: RPASS(k_visc_minv, dt); break;
+    case WCSPH_PH_VISC_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; RPASS(k_visc_residual, dt); break;
+    case WCSPH_PH_VISC_AD: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DAD))) return rc; RPASS(k_visc_Ad, dt); break;
     case WCSPH_PH_VISC_UPDATE: if ((rc = zero_acc(ctx, ACC_DNEW))) return rc; ELEM(k_visc_update, ctx->cg_delta); break;
     case WCSPH_PH_VISC_DIR: ELEM(k_visc_dir, ctx->cg_delta); break;
     case WCSPH_PH_VISC_END: ELEM(k_visc_end, dt); break;
-    case WCSPH_PH_VORTICITY: PASS(k_vorticity, dt); break;
+    case WCSPH_PH_VORTICITY: RPASS(k_vorticity, dt); break;
     case WCSPH_PH_VORTICITY_INT: ELEM(k_vorticity_integrate, dt); break;
     case WCSPH_PH_UPDATE_VEL: ELEM(k_update_vel, dt); break;
     case WCSPH_PH_UPDATE_POS: ELEM(k_update_pos, dt); break;
@@ -1761,12 +1782,13 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "pressure_drho_loop") { HOT_DRHO_PRESS(DRHO_ITER, ctx->dt); return 0; }
     if (nm == "density") { PASS(k_density); return 0; }
     if (nm == "density_coff") { PASS(k_density_coff); return 0; }
+    if (nm == "density_coff_warm") { PASS(k_density_coff_warm, ctx->dt); return 0; }
     if (nm == "grid_update") return wcsph_grid_update(ctx);
-    if (nm == "visc_minv_residual_vort") { PASS(k_visc_minv_residual_vort, ctx->dt); return 0; }
-    if (nm == "vorticity") { PASS(k_vorticity, ctx->dt); return 0; }
-    if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; PASS(k_visc_minv_residual, ctx->dt); return 0; }
+    if (nm == "visc_minv_residual_vort") { RPASS(k_visc_minv_residual_vort, ctx->dt); return 0; }
+    if (nm == "vorticity") { RPASS(k_vorticity, ctx->dt); return 0; }
+    if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; RPASS(k_visc_minv_residual, ctx->dt); return 0; }
     if (nm == "build_lists") { PASS(k_build_lists, 1); return 0; }
-    if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; PASS(k_visc_Ad, ctx->dt); return 0; }
+    if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; RPASS(k_visc_Ad, ctx->dt); return 0; }
     return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");
   };
   if (nm == "pressure_iter" && (rc = pressure_iter_async(ctx))) return rc;      // primes the (pos, k) records
