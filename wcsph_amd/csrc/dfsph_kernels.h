@@ -668,6 +668,36 @@ __global__ void k_update_pos(Dev d, float dt) {
   d.pos[i] = make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w);
 }
 
+// wcsph_dfsph_step only -- elementwise neighbours in the launch sequence, fused (each touches particle i alone and nothing
+// in between reads their outputs):
+// end of solve_divergence (dfsph.py:480-484) + clear_nonpressure (:333-336) + the v_guess update of init_viscosity_para (:199-200)
+__global__ void k_end_div_begin_nonpressure(Dev d, float dt) {
+  acc_clear(ACC_SLOT(d, ACC_DZERO));   // as k_visc_guess
+  acc_clear(ACC_SLOT(d, ACC_DAD));
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl) return;
+  if (d.oid[i] < d.n_owned) { d.kappa_v[i] *= dt; d.alpha[i] *= dt; }
+  d.d_vel[i] = make_float4(d.gx, d.gy, d.gz, 0);
+  float4 g = d.vel_guess[i], v = d.vel[i];
+  d.vel_guess[i] = make_float4(g.x + v.x, g.y + v.y, g.z + v.z, 0);
+}
+// update_vel (dfsph.py:572-575) + the kappa rescale that opens warmstart_pressure (:490)
+__global__ void k_update_vel_warm_scale(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  float4 v = d.vel[i], a = d.d_vel[i];
+  d.vel[i] = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);
+  d.kappa[i] = fmaxf(d.kappa[i] / dt / dt, -0.5f * d.rho_L0 * d.rho_L0);
+}
+// end of solve_pressure (dfsph.py:549-552) + update_pos (:577-580)
+__global__ void k_end_press_update_pos(Dev d, float dt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  d.kappa[i] *= dt * dt;
+  float4 p = d.pos[i], v = d.vel[i];
+  d.pos[i] = make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w);
+}
+
 // ---- sesph.py (ref: sesph.py:130-196); Dev.h/ml_h3/mk_h3 hold the script's private kernel constants --
 __global__ void k_ss_reset(Dev d) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -58,7 +58,9 @@ struct wcsph_ctx {
   size_t prof_used = 0;
   bool prof_on = false;
   bool in_step = false, cfl_done = false;   // wcsph_dfsph_step in progress; CFL maxima already taken
-  bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
+  bool warm_fused = false;
+  bool fuse_elem = false;         // wcsph_dfsph_step: elementwise neighbours of the launch sequence run fused (set per step)
+  bool nonp_begun = false, warm_scaled = false;   // ... what the fused launches have already done        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
   float dt = 0.0f;
@@ -854,7 +856,8 @@ int wcsph_dfsph_end_divergence(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_end_div, c
 
 int wcsph_dfsph_warmstart_pressure(wcsph_ctx *ctx) {
   NEED_GRID();
-  ELEM(k_warm_press_scale, ctx->dt);
+  if (ctx->warm_scaled) ctx->warm_scaled = false;   // wcsph_dfsph_step: done by k_update_vel_warm_scale
+  else ELEM(k_warm_press_scale, ctx->dt);
   PASS(k_warm_press_vel, ctx->dt);
   return WCSPH_OK;
 }
@@ -945,11 +948,13 @@ int wcsph_dfsph_update_pos(wcsph_ctx *ctx) {
 int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84-103
   NEED_GRID();
   int rc;
-  if ((rc = wcsph_dfsph_clear_nonpressure(ctx))) return rc;
+  const bool begun = ctx->nonp_begun;   // solve_divergence's last launch already cleared d_vel and advanced v_guess
+  ctx->nonp_begun = false;
+  if (!begun && (rc = wcsph_dfsph_clear_nonpressure(ctx))) return rc;
   if ((rc = wcsph_dfsph_tension(ctx))) return rc;
   // init_viscosity_para + the first compute_viscosity_force with ONE host wait: the loop below always runs once, and
   // its first iteration can take delta_zero from the device (the reference waits after each, dfsph.py:86-91)
-  ELEM(k_visc_guess);
+  if (!begun) ELEM(k_visc_guess);
   const bool fuse_vort = ctx->vort_fuse;
   if (fuse_vort) RPASS(k_visc_minv_residual_vort, ctx->dt); else RPASS(k_visc_minv_residual, ctx->dt);
   RPASS(k_visc_Ad, ctx->dt);
@@ -1024,6 +1029,11 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
     err = 0.001 * (double)ctx->d.n_owned / (double)dt;
     ctx->dv_iter++;
   }
+  if (ctx->fuse_elem) {   // + clear_nonpressure + the v_guess update: compute_nonpressure_force follows immediately
+    ELEM(k_end_div_begin_nonpressure, ctx->dt);
+    ctx->nonp_begun = true;
+    return WCSPH_OK;
+  }
   return wcsph_dfsph_end_divergence(ctx);
 }
 
@@ -1045,6 +1055,7 @@ int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
     if ((rc = fused_iter_sync(ctx))) return rc;
     err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
   }
+  if (ctx->fuse_elem) { ELEM(k_end_press_update_pos, ctx->dt); return WCSPH_OK; }   // + update_pos: the step ends here
   return wcsph_dfsph_end_pressure(ctx);
 }
 
@@ -1057,15 +1068,24 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
     ctx->warm_fused = true;
     ctx->pr_valid = true;                // ... and the (pos, rho) records of every row
   } else PASS(k_density_coff);           // compute_density + compute_dfsph_coff in one walk
-  if ((rc = wcsph_dfsph_solve_divergence(ctx))) return rc;
+  const bool fuse = ctx->d.n_owned == ctx->d.nl;
+  ctx->fuse_elem = fuse;
+  rc = wcsph_dfsph_solve_divergence(ctx);
+  ctx->fuse_elem = false;
+  if (rc) { ctx->nonp_begun = false; return rc; }
   ctx->in_step = true;
   rc = wcsph_dfsph_compute_nonpressure_force(ctx);
   ctx->in_step = false;
+  ctx->nonp_begun = false;
   if (rc) { ctx->cfl_done = false; return rc; }
   if ((rc = wcsph_dfsph_optimize_time_step(ctx))) return rc;
-  if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
-  if ((rc = wcsph_dfsph_solve_pressure(ctx))) return rc;
-  return wcsph_dfsph_update_pos(ctx);
+  if (fuse) { ELEM(k_update_vel_warm_scale, ctx->dt); ctx->warm_scaled = true; }
+  else if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
+  ctx->fuse_elem = fuse;
+  rc = wcsph_dfsph_solve_pressure(ctx);
+  ctx->fuse_elem = false; ctx->warm_scaled = false;
+  if (rc) return rc;
+  return fuse ? WCSPH_OK : wcsph_dfsph_update_pos(ctx);
 }
 
 int wcsph_dfsph_step_fixed(wcsph_ctx *ctx, int32_t dv, int32_t pr, int32_t vs) {
