@@ -257,13 +257,22 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
     _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
       int j = rp[t].lo0, end = rp[t].hi0, j2 = rp[t].lo1;                                         \
       const int end2 = rp[t].hi1;                                                                 \
-      for (;;) {                                                                                  \
-        if (j >= end) { if (j2 >= end2) break; j = j2; end = end2; j2 = end2; }                   \
-        const float4 pj = POS[j];                                                                 \
-        const float3 r = xi - xyz(pj);                                                            \
-        const float r2 = dot3(r, r);                                                              \
-        if (r2 <= d.list_r2 && (SELF)) CALL(j, r, r2, 1.0f);                                      \
-        j++;                                                                                      \
+      if (j >= end) { j = j2; end = end2; j2 = end2; }                                            \
+      if (j < end) {                                                                              \
+        /* the next candidate's position is requested before this one is tested */               \
+        float4 pj = POS[j];                                                                       \
+        for (;;) {                                                                                \
+          int jn = j + 1, endn = end;                                                             \
+          if (jn >= end) { jn = j2; endn = end2; j2 = end2; }                                     \
+          const bool more = jn < endn;                                                            \
+          float4 pn = pj;                                                                         \
+          if (more) pn = POS[jn];                                                                 \
+          const float3 r = xi - xyz(pj);                                                          \
+          const float r2 = dot3(r, r);                                                            \
+          if (r2 <= d.list_r2 && (SELF)) CALL(j, r, r2, 1.0f);                                    \
+          if (!more) break;                                                                       \
+          pj = pn; j = jn; end = endn;                                                            \
+        }                                                                                         \
       }                                                                                           \
     }                                                                                             \
   }
