@@ -4,6 +4,7 @@
 TAG=${1:-r02}; R=/root/repo; O=$R/gpurun_out
 cd $R
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python tools/slab_overhead.py > $O/${TAG}_slab_overhead.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
 rocprofv3 --kernel-trace -d /tmp/prof -o rest -- python $R/tools/run_steps.py 45 > /dev/null 2>&1
