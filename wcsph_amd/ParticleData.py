@@ -4,9 +4,11 @@ Python / NumPy; every field lives on the GPU inside a libwcsph_hip.so context in
 cell-sorted float4-padded SoA arrays and is presented here in the caller's original
 particle order through `Field` proxies (.to_numpy / .from_numpy / [i]).
 
-Deliberately NOT carried over: the marching-cubes grid the reference constructs and
-allocates unconditionally (ParticleData.py:29,177,184; ~30 GB at 2 M particles) and the
-surface-reconstruction kernels (:187-311) -- out of the hot path.
+The marching-cubes grid the reference constructs and allocates unconditionally
+(ParticleData.py:29,177,184; ~30 GB at 2 M particles) is constructed here too (`mc_grid`,
+wcsph_amd.MarchingCubeGrid.MCGrid) but its device arrays are allocated on first use; the
+surface-reconstruction kernels (:187-311) are `compute_color_map / cal_anistropic_kernel`
+below (csrc/surface.h).
 """
 import ctypes as C
 import math
