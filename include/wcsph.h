@@ -322,6 +322,9 @@ enum wcsph_phase {
   WCSPH_PH_DENSITY_COFF_WARM, /* DENSITY_COFF + DRHO_DIV_WARM in one walk (neither reads a neighbour field the other writes) */
   WCSPH_PH_VISC_MINV_RESIDUAL, /* VISC_MINV + VISC_RESIDUAL in one walk, slot 3 <- local sum */
   WCSPH_PH_VISC_MINV_RESIDUAL_VORT, /* ... + the sums of VORTICITY (reads vel_j, omega_j, rho_j: unchanged by the viscosity solve) */
+  WCSPH_PH_END_DIV_BEGIN_NONPRESSURE, /* END_DIV + CLEAR + VISC_GUESS in one elementwise launch (dfsph.py:480-484, 333-336, 199-200) */
+  WCSPH_PH_UPDATE_VEL_WARM_SCALE,     /* UPDATE_VEL + WARM_PRESS_SCALE (dfsph.py:572-575, 489-490) */
+  WCSPH_PH_END_PRESS_UPDATE_POS,      /* END_PRESS + UPDATE_POS (dfsph.py:549-552, 577-580) */
   WCSPH_PH__COUNT
 };
 int wcsph_phase(wcsph_ctx *ctx, int phase);

@@ -21,6 +21,9 @@ _PH = {
     "DENSITY_COFF_WARM": ["compute_density", "compute_dfsph_coff", "warmstart_divergence_drho"],
     "VISC_MINV_RESIDUAL": ["visc_minv", "visc_residual"],
     "VISC_MINV_RESIDUAL_VORT": ["visc_minv", "visc_residual", "vorticity_accumulate"],
+    "END_DIV_BEGIN_NONPRESSURE": ["end_divergence_iter", "clear_nonpressure", "visc_guess"],
+    "UPDATE_VEL_WARM_SCALE": ["update_vel", "warmstart_pressure_scale"],
+    "END_PRESS_UPDATE_POS": ["end_pressure_iter", "update_pos"],
 }
 
 

@@ -80,7 +80,8 @@ ALL_SYMBOLS = CTX_ONLY + OTHER
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
           "WARM_PRESS_SCALE", "WARM_PRESS_VEL", "DRHO_PRESS_BEGIN", "MAKE_K_PRESS", "DRHO_PRESS_ITER", "END_PRESS", "CLEAR",
           "TENSION_NORMAL", "TENSION_ACCEL", "VISC_GUESS", "VISC_MINV", "VISC_RESIDUAL", "VISC_AD", "VISC_UPDATE", "VISC_DIR",
-          "VISC_END", "VORTICITY", "VORTICITY_INT", "UPDATE_VEL", "UPDATE_POS", "DENSITY_COFF_WARM", "VISC_MINV_RESIDUAL", "VISC_MINV_RESIDUAL_VORT"]
+          "VISC_END", "VORTICITY", "VORTICITY_INT", "UPDATE_VEL", "UPDATE_POS", "DENSITY_COFF_WARM", "VISC_MINV_RESIDUAL", "VISC_MINV_RESIDUAL_VORT",
+          "END_DIV_BEGIN_NONPRESSURE", "UPDATE_VEL_WARM_SCALE", "END_PRESS_UPDATE_POS"]
 PHASE_ID = {n: i for i, n in enumerate(PHASES)}
 ACC_STRIPES = 64   # csrc/device.h
 ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = 0, 1, 2, 3

@@ -1667,6 +1667,9 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_VORTICITY_INT: ELEM(k_vorticity_integrate, dt); break;
     case WCSPH_PH_UPDATE_VEL: ELEM(k_update_vel, dt); break;
     case WCSPH_PH_UPDATE_POS: ELEM(k_update_pos, dt); break;
+    case WCSPH_PH_END_DIV_BEGIN_NONPRESSURE: ELEM(k_end_div_begin_nonpressure, dt); break;
+    case WCSPH_PH_UPDATE_VEL_WARM_SCALE: ELEM(k_update_vel_warm_scale, dt); break;
+    case WCSPH_PH_END_PRESS_UPDATE_POS: ELEM(k_end_press_update_pos, dt); break;
     default: return ctx->fail(WCSPH_EARG, "unknown phase id");
   }
   return WCSPH_OK;

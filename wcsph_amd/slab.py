@@ -616,15 +616,14 @@ class SlabSim:
             self.avg_density_err = np.float32(self.reduce_acc(ACC_ERR))
             err = 0.001 * N / dt
             self.dv_iter += 1
-        ph("END_DIV")
-
-        # compute_nonpressure_force()  (dfsph.py:84-103)
-        ph("CLEAR")
+        # end of solve_vel_divergence + compute_nonpressure_force()'s clear_nonpressure and v_guess update (dfsph.py:84-103)
+        # in one elementwise launch: each touches particle i alone, tension only adds to d_vel afterwards
+        ph("END_DIV_BEGIN_NONPRESSURE")
         if self.tension:
             ph("TENSION_NORMAL"); x("normal"); ph("TENSION_ACCEL")
         # the sums of compute_vorticity() (dfsph.py:307-328) ride on the residual walk: vel_j, omega_j, rho_j do not change
         # during the viscosity solve
-        ph("VISC_GUESS"); xp("vel_guess", "VISC_MINV_RESIDUAL_VORT")
+        xp("vel_guess", "VISC_MINV_RESIDUAL_VORT")
         self.cg_delta_zero = np.float32(self.reduce_acc(ACC_DZERO))
         self.cg_delta = self.cg_delta_zero
         self.vs_iter = 0
@@ -655,11 +654,9 @@ class SlabSim:
                 d = np.float32(d * 1.1)
             self.dt = np.float32(min(d, time_step))
             B.set_scalar("deltaT", self.dt)
-        ph("UPDATE_VEL")
-
-        # solve_pressure()  (dfsph.py:150-164); the warm start is a no-op in the reference (Q7): its gate
+        # update_vel + solve_pressure()  (dfsph.py:150-164); the warm start is a no-op in the reference (Q7): its gate
         # adv_rho > rho_L0 never opens, so kappa_j of ghosts is not refreshed for it and it changes no velocity
-        ph("WARM_PRESS_SCALE"); ph("WARM_PRESS_VEL")
+        ph("UPDATE_VEL_WARM_SCALE"); ph("WARM_PRESS_VEL")
         self.pr_iter = 0
         err = 0.0
         xp("vel", "DRHO_PRESS_BEGIN")
@@ -672,8 +669,7 @@ class SlabSim:
                 continue
             self.avg_density_err = np.float32(self.reduce_acc(ACC_ERR))
             err = float(self.avg_density_err) / N
-        ph("END_PRESS")
-        ph("UPDATE_POS")
+        ph("END_PRESS_UPDATE_POS")
         self.rows = B.store_state()
         return float(self.dt)
 
