@@ -263,3 +263,55 @@ def test_escaped_particle_has_no_neighbours():
     assert g.pd.hash_grid.neighborCount.to_numpy()[3] == 0 == o.neighborCount[3]
     assert np.abs(g.pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-5
     g.close()
+
+
+def test_packed_density_records_follow_host_writes():
+    """The viscosity / vorticity walks read rho_j from a packed (pos, rho) record written by the density pass
+    (csrc/dfsph_kernels.h k_pack_pr): a density written from the host afterwards must reach them."""
+    g, o = make_pair(8, "faithful", jitter=0.4)
+    nl = g.pd.liquid_count
+    g.call("dfsph_reset_param"); o.reset_param()
+    rng = np.random.default_rng(5)
+    set_state(g, o, vel=_random_vel(nl), omega=_random_vel(nl, 5, 0.5),
+              vel_guess=(rng.standard_normal((nl, 3)) * 0.01).astype(np.float32))
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    rho = (o.rho * (1.0 + 0.05 * rng.random(nl))).astype(np.float32)
+    g.pd.rho.from_numpy(rho); o.rho[:] = rho
+    g.call("dfsph_clear_nonpressure"); o.clear_nonpressure()
+    g.call("dfsph_visc_init"); o.init_viscosity_para()
+    assert rel_err(g.pd.cg_Minv.to_numpy(), o.cg_Minv) < TOL
+    assert rel_err(g.pd.cg_r.to_numpy(), o.cg_r) < 5 * TOL
+    g.call("dfsph_visc_iter"); o.compute_viscosity_force()
+    assert rel_err(g.pd.cg_Ad.to_numpy(), o.cg_Ad) < 1e-4
+    g.call("dfsph_vorticity"); o.compute_vorticity()
+    assert rel_err(g.pd.d_omega.to_numpy(), o.d_omega) < 1e-4
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_neighbor_count_of_scattered_clusters(mode):
+    """Liquid in separate clumps with empty space between them: the faithful neighborCount is computed region by region
+    (csrc/grid.h k_region_occ / k_cellval_occ / k_ncount_box) and must not depend on what lies in between -- exact
+    against the oracle, list contents included."""
+    from oracle import Oracle
+    from util import GpuSim
+    rng = np.random.default_rng(3)
+    R = 0.025
+    centres = np.array([[0.3, 0.4, 0.3], [1.7, 0.5, 0.4], [0.9, 1.6, 1.8], [1.75, 1.7, 1.75], [0.25, 0.3, 1.7], [1.0, 1.0, 1.0]])
+    liquid = np.concatenate([c + (rng.random((700, 3)) - 0.5) * 0.38 for c in centres]).astype(np.float32)
+    ax = (np.arange(42, dtype=np.float32) + 0.5) * np.float32(2 * R)
+    X, Z = np.meshgrid(ax, ax, indexing="ij")
+    solid = np.stack([X.ravel(), np.full(X.size, -R, np.float32), Z.ravel()], 1).astype(np.float32)   # a floor: fixes the grid box
+    solid = np.concatenate([solid, solid + np.array([0, 2.1 + 2 * R, 0], np.float32)])
+    g = GpuSim(liquid, solid, mode=mode)
+    o = Oracle(g.pd.pos.to_numpy(), len(liquid), R, mode=mode)
+    for step in range(2):
+        g.pd.hash_grid.update_grid(); o.update_grid()
+        np.testing.assert_array_equal(g.pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)
+        g.call("dfsph_compute_density"); o.compute_density()
+        assert np.abs(g.pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-5
+        pos = o.pos.copy()
+        pos[:len(liquid)] += rng.normal(0, 0.02, (len(liquid), 3)).astype(np.float32)   # move every liquid particle a little
+        set_state(g, o, pos=pos)
+    g.close()
