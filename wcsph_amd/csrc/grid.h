@@ -24,10 +24,27 @@ __device__ __forceinline__ int cell_packed(const Dev &d, float3 p, int *lin, boo
   return in ? (cx | (cy << 10) | (cz << 20)) : -1;
 }
 
+// neighborCount regions (see k_ncount_box below): BC0 x BC1 x BCZ cells (outer x middle x z of the tile order = 4 x 2 x 1 tiles)
+#define BC0 8
+#define BC1 8
+#define BCZ 16
+struct Regions { int nb0, nb1, nbz; };
+__device__ __forceinline__ Regions regions_of(const Dev &d) {
+  Regions r;
+  r.nb0 = ((d.perm ? d.ny : d.nx) + BC0 - 1) / BC0; r.nb1 = ((d.perm ? d.nx : d.ny) + BC1 - 1) / BC1; r.nbz = (d.nz + BCZ - 1) / BCZ;
+  return r;
+}
+__device__ __forceinline__ int region_of_cell(const Dev &d, int w) {   // w: packed cell
+  const Regions R = regions_of(d);
+  const int cx = w & 1023, cy = (w >> 10) & 1023, cz = w >> 20;
+  return (((d.perm ? cy : cx) / BC0) * R.nb1 + (d.perm ? cx : cy) / BC1) * R.nbz + cz / BCZ;
+}
+
 // phase 1 of the counting sort (ref: HashGrid.py:67-76 "insert pos"): cell of every particle, slot in cell.
+// occ != nullptr: the particle's neighborCount region is flagged (k_ncount_box clears the flags it consumes).
 // bbox != nullptr: also this block's bounding box of the occupied cells -> bbox[6 * blockIdx.x ..] (no atomics: the
 // particles are x-sorted, so a shared max would be raised by nearly every block); k_bbox_final reduces them.
-__global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox, int count_limit) {
+__global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox, int count_limit, int *occ = nullptr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
   if (i < n) {
@@ -47,6 +64,7 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
       if (bcount && i < count_limit && gx >= d.own_lo && gx < d.own_hi)
         atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
       lo[0] = hi[0] = w & 1023; lo[1] = hi[1] = (w >> 10) & 1023; lo[2] = hi[2] = w >> 20;
+      if (occ) occ[region_of_cell(d, w)] = 1;
     }
   }
   if (!bbox) return;
@@ -329,10 +347,13 @@ __global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags, co
 // the cap applies to every bucket, not only walked ones
 // bcount8: the same counts as bytes (saturated at 255) -- a 3 MB table that stays in the 4 MB L2 of every XCD, where the
 // 12 MB of ints do not: k_cellval_occ's gathers are random (used while max_in_grid <= 255: every legal count fits)
-__global__ void k_bucket_sum(Dev d, const int *bs, const int *bl, int *bcount, unsigned char *bcount8, int *flags) {
+// The liquid histogram is zeroed as it is consumed (the next grid update needs no 12 MB memset).
+__global__ void k_bucket_sum(Dev d, const int *bs, int *bl, int *bcount, unsigned char *bcount8, int *flags) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.table_size) return;
-  const int v = bs[b] + bl[b];
+  const int l = bl[b];
+  if (l != 0) bl[b] = 0;
+  const int v = bs[b] + l;
   bcount[b] = v;
   bcount8[b] = (unsigned char)min(v, 255);
   if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
@@ -372,15 +393,6 @@ __global__ void k_ncount_faithful(Dev d, const int *boxsum) {
 // region and its 2-cell halo into LDS, runs the three 5-tap sums there and writes neighborCount of the particles in
 // its cells.  The cost follows the liquid's volume, not its bounding box (the five-launch version above: 100 us at
 // C3 at rest, 290 us once the dam has spread over the domain).
-#define BC0 8
-#define BC1 8
-#define BCZ 16
-struct Regions { int nb0, nb1, nbz; };
-__device__ __forceinline__ Regions regions_of(const Dev &d) {
-  Regions r;
-  r.nb0 = ((d.perm ? d.ny : d.nx) + BC0 - 1) / BC0; r.nb1 = ((d.perm ? d.nx : d.ny) + BC1 - 1) / BC1; r.nbz = (d.nz + BCZ - 1) / BCZ;
-  return r;
-}
 // one thread per region: does it hold a particle?  (one contiguous range per (outer, middle) tile pair; only tiles
 // touching the occupied box can hold particles, and the cell table is current for exactly those)
 __global__ void k_region_occ(Dev d, int *occ) {
@@ -441,7 +453,7 @@ __global__ void __launch_bounds__(BLOCK) k_ncount_box(Dev d, const int *cellval,
   const int *bb = d.bbox;
   // particles outside the grid box (the last bin of the sort) have no list at all
   if (blockIdx.x == 0) for (int j = d.cs_l[d.ncell_p] + threadIdx.x; j < d.nl; j += BLOCK) d.ncount[j] = 0;
-  if (!occ[blockIdx.x]) return;
+  if (!occ[blockIdx.x]) return;   // flagged by k_cell_assign; cleared below, once every thread has passed this test
   const int l0 = d.perm ? bb[1] : bb[0], h0 = d.perm ? bb[4] : bb[3], l1 = d.perm ? bb[0] : bb[1], h1 = d.perm ? bb[3] : bb[4];
   // gridCount of the region's cells + halo (0 outside the grid: the reference walks in-box cells only)
   constexpr int E0 = BC0 + 4, E1 = BC1 + 4, EZ = BCZ + 4;
@@ -500,6 +512,7 @@ __global__ void __launch_bounds__(BLOCK) k_ncount_box(Dev d, const int *cellval,
     if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
     for (int j = ja[k]; j < jb[k]; j++) d.ncount[j] = cnt;
   }
+  if (threadIdx.x == 0) const_cast<int *>(occ)[blockIdx.x] = 0;   // k_cellval_occ, the other reader, has finished
 }
 // clean: every particle of the in-box 5x5x5 cells once, minus the particle itself
 __global__ void k_ncount_clean(Dev d) {

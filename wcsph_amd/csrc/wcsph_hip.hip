@@ -38,7 +38,8 @@ struct wcsph_ctx {
   int *bbox_part = nullptr;
   int n_alias = 0, scan_blocks = 0, n_regions = 0;
   unsigned char *bcount8 = nullptr;
-  int *region_occ = nullptr;      // neighborCount regions that hold particles (grid.h k_region_occ)
+  int *region_occ = nullptr;
+  bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ      // neighborCount regions that hold particles (grid.h k_region_occ)
   bool ncount_split = getenv("WCSPH_NCOUNT_SPLIT") != nullptr;   // development: the five-launch neighborCount
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false;
@@ -399,10 +400,17 @@ static int grid_begin(wcsph_ctx *ctx) {
   // the pull_scalars() calls of its step and must not stick to the context (the reference prints and keeps stepping)
   HIPCHK(hipMemsetAsync(d.flags + FLAG_ERR, 0, sizeof(int), s));
   ctx->pr_valid = false;   // rows are re-sorted
-  if (d.faithful) HIPCHK(hipMemsetAsync(ctx->bcount_l, 0, (size_t)d.table_size * sizeof(int), s));
+  // the liquid bucket histogram and the region flags are zero here: their consumers (k_bucket_sum, k_ncount_box) clear
+  // them -- unless the previous update did not run to its end
+  if (d.faithful && ctx->hist_dirty) {
+    HIPCHK(hipMemsetAsync(ctx->bcount_l, 0, (size_t)d.table_size * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(ctx->region_occ, 0, (size_t)ctx->n_regions * sizeof(int), s));
+  }
+  ctx->hist_dirty = true;
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
-                       d.faithful ? ctx->bcount_l : (int *)nullptr, ctx->bbox_part, d.n_owned);
+                       d.faithful ? ctx->bcount_l : (int *)nullptr, ctx->bbox_part, d.n_owned,
+                       d.faithful && !ctx->ncount_split ? ctx->region_occ : (int *)nullptr);
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
@@ -424,7 +432,7 @@ static int grid_end(wcsph_ctx *ctx) {
   hipStream_t s = ctx->stream;
   if (d.faithful) {
     const int *bb = d.bbox;
-    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, (const int *)ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
     // neighborCount: 5x5x5 box sum of gridCount[hash(cell)] around every occupied cell, one LDS-tiled launch (grid.h)
     if (d.nl > 0) {
       if (ctx->ncount_split) {   // the separable five-launch version on the occupied box (kept for A/B timing)
@@ -435,7 +443,6 @@ static int grid_end(wcsph_ctx *ctx) {
         hipLaunchKernelGGL(k_ncount_faithful, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp);
       } else {
         const int nb = ctx->n_regions;
-        hipLaunchKernelGGL(k_region_occ, dim3(nblk(nb)), dim3(BLOCK), 0, s, d, ctx->region_occ);
         if (d.max_in_grid <= 255)
           hipLaunchKernelGGL(k_cellval_occ<unsigned char>, dim3(nb), dim3(BLOCK), 0, s, d, (const unsigned char *)ctx->bcount8, (const int *)ctx->region_occ, ctx->cellval);
         else
@@ -448,6 +455,7 @@ static int grid_end(wcsph_ctx *ctx) {
   }
   if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
   LAUNCHCHK();
+  ctx->hist_dirty = false;   // k_bucket_sum / k_ncount_box have left the histogram and the region flags zeroed
   ctx->grid_valid = true;
   ctx->bk_valid = false;
   return WCSPH_OK;
