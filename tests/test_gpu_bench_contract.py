@@ -32,3 +32,20 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert "developed_flow" in d["config"] and d["config"]["developed_flow"]["value"] > 0
     assert rf["traffic"] is None or rf["traffic"] > 0
     assert d["value"] > 0 and abs(d["ms_per_step"] - d["config"]["n_liquid"] / d["value"] / 1e3) / d["ms_per_step"] < 0.02
+
+
+def test_two_rank_bench_line_over_gloo():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks on the
+    one GPU of the test box and the halos staged through the host (WCSPH_BENCH_COMM=gloo): rank 0 prints ONE JSON line
+    for the whole job, weak scaling, faithful neighbour semantics across the ranks."""
+    env = dict(os.environ, WCSPH_BENCH_COMM="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "24"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["neighbor_mode"] == "faithful" and sum(d["config"]["owned_per_rank"]) == d["config"]["n_liquid"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
