@@ -128,6 +128,50 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_div(Dev d, float dt) {
   if (MODE == DRHO_ITER) block_accumulate(ACC_SLOT(d, ACC_ERR), a);  // ref: dfsph.py:476 avg_density_err += adv_rho
 }
 
+// wcsph_dfsph_step only: k_drho_div<DRHO_ITER, true> + the sums of compute_vorticity (dfsph.py:307-328, see k_vorticity).
+// The last divergence iteration already gathers pos_j and vel_j with the velocities compute_vorticity will see (nothing
+// between the end of solve_vel_divergence and compute_vorticity changes vel, omega or rho): riding along costs one more
+// gather per entry (omega_j; rho_j comes with the (pos, rho) record) instead of two in the viscosity walk.  Every
+// iteration recomputes the sums, the last one stands.  dv is parked in cg_s (free until the PCG update) because d_vel is
+// cleared after this kernel (k_end_div_begin_nonpressure adds it back).
+__global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
+  LOAD_I
+  float a = 0.f;
+  if (own) {
+    const float3 vi = xyz(d.vel[i]), wi = xyz(d.omega[i]);
+    const float rhoi = d.rho[i];
+    float3 dom = f3(0, 0, 0), dv = f3(0, 0, 0);
+    const float c1 = -1.0f / dt * d.vort_init * d.visc_omega * d.mass;
+    const float c2 = d.vort_coff / rhoi * d.mass;
+    const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
+    struct VW { float4 v, w; };
+    walk<4>(d, i, pi, d.pr, [&](int j, float4 p) { VW q; q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); q.w.w = p.w; return q; },
+            [&](int, float3 r, float r2, VW q) {
+              const float g = cubic_gradW_scale(d, r2);
+              const float3 dvel = vi - xyz(q.v), dw = wi - xyz(q.w);
+              a += d.VL0 * g * dot3(dvel, r);
+              dom = dom + dw * (c1 * frcp(q.w.w) * cubic_W(d, r2));
+              dv = dv + cross3(dw, r) * (c2 * g);
+              dom = dom + cross3(dvel, r) * (c3 * g);
+            },
+            [&](int, float3 r, float r2) {
+              const float g = cubic_gradW_scale(d, r2);
+              a += d.VS0 * g * dot3(vi, r);
+              dv = dv + cross3(wi, r) * (d.vort_coff / rhoi * d.rho_L0 * d.VS0 * g);
+              dom = dom + cross3(vi, r) * (d.vort_coff / rhoi * d.vort_init * d.rho_L0 * d.VL0 * g);
+            });
+    const int nc = d.ncount[i];
+    a = fmaxf(a, 0.0f);
+    if (nc < 20) a = 0.0f;  // raw list length, Q2
+    d.adv_rho[i] = a;
+    d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * d.alpha[i]);
+    dom = dom + wi * (-2.0f * d.vort_init * d.vort_coff * (float)nc);
+    d.d_omega[i] = f4(dom, 0);
+    d.cg_s[i] = f4(dv, 0);
+  }
+  block_accumulate(ACC_SLOT(d, ACC_ERR), a);  // ref: dfsph.py:476 avg_density_err += adv_rho
+}
+
 // ref: dfsph.py:394-412 update_drho_pressure, inlined at :513 (BEGIN), :545 (ITER)
 template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
@@ -671,13 +715,16 @@ __global__ void k_update_pos(Dev d, float dt) {
 // wcsph_dfsph_step only -- elementwise neighbours in the launch sequence, fused (each touches particle i alone and nothing
 // in between reads their outputs):
 // end of solve_divergence (dfsph.py:480-484) + clear_nonpressure (:333-336) + the v_guess update of init_viscosity_para (:199-200)
-__global__ void k_end_div_begin_nonpressure(Dev d, float dt) {
+// vort != 0: k_drho_div_iter_vort parked the vorticity acceleration in cg_s
+__global__ void k_end_div_begin_nonpressure(Dev d, float dt, int vort) {
   acc_clear(ACC_SLOT(d, ACC_DZERO));   // as k_visc_guess
   acc_clear(ACC_SLOT(d, ACC_DAD));
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl) return;
   if (d.oid[i] < d.n_owned) { d.kappa_v[i] *= dt; d.alpha[i] *= dt; }
-  d.d_vel[i] = make_float4(d.gx, d.gy, d.gz, 0);
+  float4 a = make_float4(d.gx, d.gy, d.gz, 0);
+  if (vort) { const float4 dv = d.cg_s[i]; a.x += dv.x; a.y += dv.y; a.z += dv.z; }
+  d.d_vel[i] = a;
   float4 g = d.vel_guess[i], v = d.vel[i];
   d.vel_guess[i] = make_float4(g.x + v.x, g.y + v.y, g.z + v.z, 0);
 }

@@ -61,7 +61,9 @@ struct wcsph_ctx {
   bool in_step = false, cfl_done = false;   // wcsph_dfsph_step in progress; CFL maxima already taken
   bool warm_fused = false;
   bool fuse_elem = false;         // wcsph_dfsph_step: elementwise neighbours of the launch sequence run fused (set per step)
-  bool nonp_begun = false, warm_scaled = false;   // ... what the fused launches have already done        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
+  bool nonp_begun = false, warm_scaled = false;
+  bool vort_in_div = false;       // the last divergence iteration of this step also took the vorticity sums (k_drho_div_iter_vort)
+  bool vort_div = getenv("WCSPH_NO_VORT_IN_DIV") == nullptr;   // ... what the fused launches have already done        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
   float dt = 0.0f;
@@ -832,7 +834,10 @@ static int pressure_iter_async(wcsph_ctx *ctx) {
 static int divergence_iter_fused(wcsph_ctx *ctx) {
   if (ctx->d.n_owned < ctx->d.nl) return divergence_iter_async(ctx);
   PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v);   // also clears ACC_ERR
-  PASS((k_drho_div<DRHO_ITER, true>), ctx->dt);
+  if (ctx->fuse_elem && ctx->vort_fuse && ctx->vort_div && ctx->pr_valid) {
+    PASS(k_drho_div_iter_vort, ctx->dt);
+    ctx->vort_in_div = true;
+  } else PASS((k_drho_div<DRHO_ITER, true>), ctx->dt);
   return 0;
 }
 static int pressure_iter_fused(wcsph_ctx *ctx) {
@@ -964,7 +969,9 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
   // its first iteration can take delta_zero from the device (the reference waits after each, dfsph.py:86-91)
   if (!begun) ELEM(k_visc_guess);
   const bool fuse_vort = ctx->vort_fuse;
-  if (fuse_vort) RPASS(k_visc_minv_residual_vort, ctx->dt); else RPASS(k_visc_minv_residual, ctx->dt);
+  const bool vort_taken = ctx->vort_in_div;   // by the last divergence iteration: only the viscosity part is left
+  ctx->vort_in_div = false;
+  if (fuse_vort && !vort_taken) RPASS(k_visc_minv_residual_vort, ctx->dt); else RPASS(k_visc_minv_residual, ctx->dt);
   RPASS(k_visc_Ad, ctx->dt);
   ELEM(k_visc_update, 0.0f, 1);
   if ((rc = pull_scalars(ctx))) return rc;
@@ -1038,7 +1045,7 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
     ctx->dv_iter++;
   }
   if (ctx->fuse_elem) {   // + clear_nonpressure + the v_guess update: compute_nonpressure_force follows immediately
-    ELEM(k_end_div_begin_nonpressure, ctx->dt);
+    ELEM(k_end_div_begin_nonpressure, ctx->dt, ctx->vort_in_div ? 1 : 0);
     ctx->nonp_begun = true;
     return WCSPH_OK;
   }
@@ -1080,11 +1087,11 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   ctx->fuse_elem = fuse;
   rc = wcsph_dfsph_solve_divergence(ctx);
   ctx->fuse_elem = false;
-  if (rc) { ctx->nonp_begun = false; return rc; }
+  if (rc) { ctx->nonp_begun = false; ctx->vort_in_div = false; return rc; }
   ctx->in_step = true;
   rc = wcsph_dfsph_compute_nonpressure_force(ctx);
   ctx->in_step = false;
-  ctx->nonp_begun = false;
+  ctx->nonp_begun = false; ctx->vort_in_div = false;
   if (rc) { ctx->cfl_done = false; return rc; }
   if ((rc = wcsph_dfsph_optimize_time_step(ctx))) return rc;
   if (fuse) { ELEM(k_update_vel_warm_scale, ctx->dt); ctx->warm_scaled = true; }
@@ -1675,7 +1682,7 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_VORTICITY_INT: ELEM(k_vorticity_integrate, dt); break;
     case WCSPH_PH_UPDATE_VEL: ELEM(k_update_vel, dt); break;
     case WCSPH_PH_UPDATE_POS: ELEM(k_update_pos, dt); break;
-    case WCSPH_PH_END_DIV_BEGIN_NONPRESSURE: ELEM(k_end_div_begin_nonpressure, dt); break;
+    case WCSPH_PH_END_DIV_BEGIN_NONPRESSURE: ELEM(k_end_div_begin_nonpressure, dt, 0); break;
     case WCSPH_PH_UPDATE_VEL_WARM_SCALE: ELEM(k_update_vel_warm_scale, dt); break;
     case WCSPH_PH_END_PRESS_UPDATE_POS: ELEM(k_end_press_update_pos, dt); break;
     default: return ctx->fail(WCSPH_EARG, "unknown phase id");
@@ -1808,6 +1815,7 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
   auto one = [&]() -> int {
     if (nm == "pressure_iter") return pressure_iter_fused(ctx);      // what wcsph_dfsph_solve_pressure launches per iteration
     if (nm == "divergence_iter") return divergence_iter_fused(ctx);
+    if (nm == "divergence_iter_vort") { PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v); RPASS(k_drho_div_iter_vort, ctx->dt); return 0; }
     if (nm == "pressure_iter_unfused") return pressure_iter_async(ctx);  // k_make_k + vel + drho (per-kernel API)
     if (nm == "pressure_vel_loop") { HOT_VEL(0, ctx->d.kbuf, ctx->dt, 0); return 0; }
     if (nm == "pressure_drho_loop") { HOT_DRHO_PRESS(DRHO_ITER, ctx->dt); return 0; }
