@@ -271,13 +271,18 @@ def _main():
         p3.close()
         # BASELINE.json configs[4] (C5): 1 M particles with the Akinci surface tension on (the reference ships 0.0 for both
         # coefficients, which skips the passes) and the adhesion ball of the reference's sphere scene inside the liquid,
-        # so that the boundary term (dfsph.py:297-304, gated to that ball) does work; repaired normals (tension_fixed = 1)
+        # so that the boundary term (dfsph.py:297-304, gated to that ball) does work
         liq5, sol5 = scene.dam_break_with_ball(scene.CONFIGS["C5"])
-        d5, p5, _ = build_sim(scene.CONFIGS["C5"], args.mode, liquid=liq5, boundary=sol5, tension_coff=0.05, tension_coff_b=0.05)
-        out["config"]["C5_1M_tension"] = dict(leg(p5.liquid_count, timed_steps(d5, p5, args.warmup, args.steps, tsync), args.steps),
-                                              n_liquid=p5.liquid_count, n_solid=p5.solid_count, tension_coff=0.05, tension_coff_b=0.05,
-                                              tension_semantics="fixed normals (tension_fixed=1); parity-tested against the oracle in both semantics")
-        p5.close()
+        # two semantics of compute_tension (dfsph.py:264-305), both parity-tested against the oracle at this size
+        # (tests/test_gpu_configs.py::test_C5_1M_tension_one_step): "literal" = what the reference computes (raw bucket rows,
+        # the running normal scaled by h once per entry, Q8) -- the default of faithful mode; "fixed" = the repaired normals
+        for key, fixed in (("C5_1M_tension", 0 if args.mode == "faithful" else 1), ("C5_1M_tension_fixed", 1)):
+            d5, p5, _ = build_sim(scene.CONFIGS["C5"], args.mode, liquid=liq5, boundary=sol5, tension_coff=0.05, tension_coff_b=0.05, tension_fixed=fixed)
+            out["config"][key] = dict(leg(p5.liquid_count, timed_steps(d5, p5, args.warmup, args.steps, tsync), args.steps),
+                                      n_liquid=p5.liquid_count, n_solid=p5.solid_count, tension_coff=0.05, tension_coff_b=0.05,
+                                      tension_semantics="reference-literal loop over the raw bucket rows (tension_fixed=0)" if fixed == 0
+                                      else "repaired normals over the compact lists (tension_fixed=1)")
+            p5.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(n, args.cpu_n)
     return out

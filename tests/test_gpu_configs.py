@@ -59,13 +59,18 @@ def test_C3_2M_one_step_faithful():
     pd.close(); o.close()
 
 
-def test_C5_1M_tension_one_step():
+@pytest.mark.parametrize("fixed", [0, 1])
+def test_C5_1M_tension_one_step(fixed):
     """100^3 lattice minus the adhesion ball's volume, tension_coff = tension_coff_b = 0.05 (the reference ships 0.0 for
-    both); the ball lies inside the 0.26 gate, so the solid branch of compute_tension contributes."""
+    both); the ball lies inside the 0.26 gate, so the solid branch of compute_tension contributes.
+    fixed = 0: compute_tension as the reference computes it (dfsph.py:264-305 over the raw bucket rows: the running normal
+    scaled by h once per entry, Q8, the curvature term over every raw liquid entry); fixed = 1: the repaired normals."""
     from wcsph_amd import scene
     liquid, solid = scene.dam_break_with_ball(100)
-    pd, o, _ = _one_step(100, "faithful", 14, liquid=liquid, boundary=solid, tension_coff=0.05, tension_coff_b=0.05, tension_fixed=1)
+    pd, o, _ = _one_step(100, "faithful", 14, liquid=liquid, boundary=solid, tension_coff=0.05, tension_coff_b=0.05, tension_fixed=fixed)
     assert abs(pd.liquid_count - 1000000) < 1000
+    from util import rel_err
+    assert rel_err(pd.normal.to_numpy(), o.normal) < 2e-5
     pd.close(); o.close()
 
 

@@ -169,7 +169,7 @@ def test_viscosity_pcg_and_vorticity(mode):
 
 @pytest.mark.parametrize("mode", MODES)
 def test_tension_fixed_semantics(mode):
-    g, o = make_pair(8, mode, jitter=0.4, tension_coff=0.5, tension_coff_b=0.5)
+    g, o = make_pair(8, mode, jitter=0.4, tension_coff=0.5, tension_coff_b=0.5, tension_fixed=1)
     o.tension_coff, o.tension_coff_b, o.tension_fixed = 0.5, 0.5, 1
     g.pd.hash_grid.update_grid(); o.update_grid()
     g.call("dfsph_compute_density"); o.compute_density()
@@ -292,7 +292,7 @@ def test_packed_density_records_follow_host_writes():
 @pytest.mark.parametrize("mode", MODES)
 def test_neighbor_count_of_scattered_clusters(mode):
     """Liquid in separate clumps with empty space between them: the faithful neighborCount is computed region by region
-    (csrc/grid.h k_region_occ / k_cellval_occ / k_ncount_box) and must not depend on what lies in between -- exact
+    (csrc/grid.h: flags set by k_cell_assign, then k_cellval_occ / k_ncount_box) and must not depend on what lies in between -- exact
     against the oracle, list contents included."""
     from oracle import Oracle
     from util import GpuSim

@@ -67,23 +67,26 @@ def test_hip_slab_one_rank_matches_checker(tmp_path):
     np.testing.assert_allclose(glog[:, 3], np.array(rlog)[:, 3], rtol=1e-6)
 
 
-def test_hip_slab_two_ranks_match_one_rank(tmp_path):
+@pytest.mark.parametrize("world,n", [(2, 8), (3, 12)])
+def test_hip_slab_ranks_match_one_rank(tmp_path, world, n):
+    """world = 3: an INTERIOR rank (two neighbours, ghosts and migration on both sides); the block drifts at 4 m/s, so
+    rows cross both cuts during the run"""
     import slab_util
     from test_slab_gloo import _free_port
-    n, out = 8, str(tmp_path)
+    out = str(tmp_path)
     _hip_run(0, 1, 0, out, n)
-    mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+    mp.spawn(_hip_run, args=(world, _free_port(), out, n), nprocs=world, join=True)
     one = np.load(os.path.join(out, "hrows_w1_r0.npy"))
-    two = np.concatenate([np.load(os.path.join(out, "hrows_w2_r%d.npy" % r)) for r in range(2)])
-    assert len(one) == len(two) == n ** 3
-    dpos, dvel, _ = slab_util.match_rows(one, two)
+    many = np.concatenate([np.load(os.path.join(out, "hrows_w%d_r%d.npy" % (world, r))) for r in range(world)])
+    assert len(one) == len(many) == n ** 3
+    dpos, dvel, _ = slab_util.match_rows(one, many)
     assert dpos < 5e-6 and dvel < 1e-3
     l1 = np.load(os.path.join(out, "hlog_w1_r0.npy"))
-    l2 = [np.load(os.path.join(out, "hlog_w2_r%d.npy" % r)) for r in range(2)]
-    np.testing.assert_array_equal(l1[:, :3], l2[0][:, :3])
-    np.testing.assert_array_equal(l2[0][:, :3], l2[1][:, :3])
-    assert (l2[0][:, 4] + l2[1][:, 4] == n ** 3).all()
-    assert l2[0][0, 4] != l2[0][-1, 4]
+    lw = [np.load(os.path.join(out, "hlog_w%d_r%d.npy" % (world, r))) for r in range(world)]
+    for l in lw:
+        np.testing.assert_array_equal(l1[:, :3], l[:, :3])
+    assert (sum(l[:, 4] for l in lw) == n ** 3).all()
+    assert all(l[0, 4] != l[-1, 4] for l in lw)           # every rank gained or lost rows
 
 
 def test_faithful_slabs_reproduce_the_single_context(tmp_path):

@@ -32,3 +32,29 @@ def test_color_map_and_anisotropic_kernel(mode):
     assert rel_err(G, Go) < 2e-4
     np.testing.assert_allclose(G, np.transpose(G, (0, 2, 1)), atol=1e-6)   # symmetric
     g.close()
+
+
+def test_reference_diagnostics_export_kernel_and_max_neighbour(tmp_path, capsys):
+    """ParticleData.export_kernel (ref: ParticleData.py:302-311) and HashGrid.get_max_neighbour (ref: HashGrid.py:126-152):
+    debug helpers the reference's drivers never call; kept for surface completeness."""
+    g, o = make_pair(7, "faithful", jitter=0.3)
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.pd.compute_color_map()
+    f = tmp_path / "out" / "test.obj"
+    g.pd.export_kernel(str(f))
+    rows = [l.split() for l in f.read_text().splitlines()]
+    assert len(rows) == g.pd.liquid_count and all(r[0] == "v" and len(r) == 10 for r in rows)
+    a = np.array([[float(x) for x in r[1:]] for r in rows])
+    np.testing.assert_allclose(a[:, :3], g.pd.pos.to_numpy()[:g.pd.liquid_count], atol=1e-6)
+    np.testing.assert_allclose(a[:, 6:9], g.pd.color_grad.to_numpy(), atol=1e-6)
+    np.testing.assert_allclose(a[:, 3:6], a[:, 6:9] * 512.0, atol=3e-4)
+    # the reference's "tree" leaves max(gridCount[0], gridCount[s / 2]) in slot 0, s = the last power of two < n_liquid
+    gc = g.pd.hash_grid.gridCount
+    np.testing.assert_array_equal(gc, o.gridCount)
+    s = 2
+    while s * 2 < g.pd.liquid_count:
+        s *= 2
+    assert g.pd.hash_grid.get_max_neighbour() == max(int(gc[0]), int(gc[s // 2]))
+    assert capsys.readouterr().out.strip().splitlines()[-1] == str(max(int(gc[0]), int(gc[s // 2])))
+    g.close()

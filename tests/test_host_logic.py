@@ -78,3 +78,16 @@ def test_hashgrid_host_hash_matches_oracle():
     for c, h in zip(cells, got):
         assert o.cell_hash(*c) == int(h)
     assert isinstance(pd.hash_grid, HashGrid)
+
+
+def test_pci_coff_is_the_reference_lattice_sum():
+    """pcisph.GetPciCoff (ref: pcisph.py:87-115) as one array expression vs the oracle's loop restatement, and vs a
+    hand count: the pitch-2R lattice has 5^3 points in [-h, h]^3, the inner 3^3 = 27 of them strictly inside the support
+    (r = 0 included, which contributes no gradient; the six axis points sit exactly ON the support radius)."""
+    import oracle.oracle as oo
+    from wcsph_amd import pcisph
+    got, exp = pcisph.GetPciCoff(), oo._load().orc_pci_coff(0.025)
+    assert abs(got - exp) <= 1e-12 * exp
+    ax = np.array([-0.1, -0.05, 0.0, 0.05, 0.1])
+    g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    assert int((np.sqrt((g * g).sum(1)) < 0.1 - 1e-12).sum()) == 27

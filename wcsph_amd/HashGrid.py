@@ -143,6 +143,28 @@ class HashGrid:
         _lib.check(ctx, _lib.load().wcsph_grid_update(ctx))
 
     # ---- host-side inspection helpers (not on the hot path) ----------------------------------
+    def process_neighbour(self, index):
+        """ref: HashGrid.py:126-142 -- one level of the reference's diagnostic "tree": every slot i that is a multiple of
+        `index` takes max(gridCount[i], gridCount[i + index // 2]).  (It re-reads gridCount, not the previous level, so
+        the tree does not propagate; reproduced as written.  Slots whose partner lies past the table keep their value --
+        the reference reads out of bounds there.)"""
+        gc = self.gridCount
+        if getattr(self, "maxCurNeighbour", None) is None or len(self.maxCurNeighbour) != len(gc):
+            self.maxCurNeighbour = np.zeros(len(gc), np.int32)
+        i = np.arange(0, len(gc), int(index))
+        i = i[i + int(index) // 2 < len(gc)]
+        self.maxCurNeighbour[i] = np.maximum(gc[i], gc[i + int(index) // 2])
+
+    def get_max_neighbour(self):
+        """ref: HashGrid.py:146-152 (never called by the reference's drivers); prints and returns slot 0"""
+        size = 2
+        while size < self.particle_data.liquid_count:
+            self.process_neighbour(size)
+            size = size * 2
+        v = int(self.maxCurNeighbour[0]) if getattr(self, "maxCurNeighbour", None) is not None else 0
+        print(v)
+        return v
+
     def _cells(self, pos):
         mn = self.min_boundary.to_numpy()[0]
         f = (pos.astype(np.float32) - mn) * np.float32(self.invGridR)

@@ -79,9 +79,11 @@ class ParticleData:
         # tension
         self.tension_coff = 0.0
         self.tension_coff_b = 0.0
-        # 1: n_i = h * sum (m/rho_j) gradW, curvature term over the support (the documented repair of Q8);
-        # 0: the reference loop literally (dfsph.py:264-305) over its raw bucket lists -- faithful neighbour mode only
-        self.tension_fixed = 1
+        # 0: the reference loop literally (dfsph.py:264-305) over its raw bucket lists -- faithful neighbour mode only;
+        # 1: n_i = h * sum (m/rho_j) gradW, curvature term over the support (the documented repair of Q8).
+        # None (default): what the neighbour mode implies -- faithful computes what the reference computes (0), clean the
+        # repaired form (1).  A slab window (slab.HipBackend) asks for 1: the raw rows span all ranks.
+        self.tension_fixed = None
 
         # vorticity
         self.viscosity_omega = 0.1
@@ -175,7 +177,7 @@ class ParticleData:
         p.neighbor_mode = _lib.MODE_FAITHFUL if self.neighbor_mode == "faithful" else _lib.MODE_CLEAN
         p.max_in_grid, p.max_neighbour = self.hash_grid.maxInGrid, self.hash_grid.maxNeighbour
         p.hash_table_size = int(self.hash_table_size)
-        p.tension_fixed = int(self.tension_fixed)
+        p.tension_fixed = int(self.tension_fixed) if self.tension_fixed is not None else (0 if self.neighbor_mode == "faithful" else 1)
         p.list_cap = int(self.list_cap)
         p.particle_radius, p.cfl_radius = float(self.particleR), float(self.cfl_radius)
         p.user_max_t, p.user_min_t = float(self.user_max_t), float(self.user_min_t)
@@ -230,6 +232,17 @@ class ParticleData:
         """ref: ParticleData.py:220-289: weighted mean positions and the anisotropy matrices G (Yu & Turk)"""
         ctx = self._need_ctx()
         _lib.check(ctx, _lib.load().wcsph_surface_anisotropic_kernel(ctx, float(self.mc_grid.searchR)))
+
+    def export_kernel(self, filename="out/test.obj"):
+        """ref: ParticleData.py:302-311 -- debug dump of the colour-field gradient: one `v x y z r g b nx ny nz` line per
+        liquid particle (colour = 512 x gradient).  compute_color_map() must have run."""
+        import os
+        pos = self.pos.to_numpy()[:self.liquid_count]
+        grad = self.color_grad.to_numpy()
+        d = os.path.dirname(filename)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        np.savetxt(filename, np.hstack([pos, grad * 512.0, grad]), fmt="v" + " %f" * 9)
 
     def _need_ctx(self):
         if self._ctx is None:

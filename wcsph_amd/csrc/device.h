@@ -122,7 +122,7 @@ __device__ __forceinline__ float cubic_gradW_scale(const Dev &d, float r2) {
 #define T2B 4   /* z: 16 cells per tile (row_pieces relies on >= 5 cells: a walked row touches at most two tiles) */
 #endif
 #define TILE_SHIFT (T0B + T1B + T2B)
-// index of the first cell (z = 0 of tile row 0) of the z-row through (cx, cy): cell (cx, cy, cz) = row + (cz >> 3) * 64 + (cz & 7)
+// index of the first cell (z = 0 of z-tile 0) of the z-row through (cx, cy): cell (cx, cy, cz) = row + ((cz >> T2B) << TILE_SHIFT) + (cz & (2^T2B - 1))
 __device__ __forceinline__ int cell_row(const Dev &d, int cx, int cy) {
   const int a0 = d.perm ? cy : cx, a1 = d.perm ? cx : cy;
   return ((((a0 >> T0B) * d.nt1 + (a1 >> T1B)) * d.nt2) << TILE_SHIFT) | ((a0 & ((1 << T0B) - 1)) << (T1B + T2B)) | ((a1 & ((1 << T1B) - 1)) << T2B);
@@ -130,7 +130,7 @@ __device__ __forceinline__ int cell_row(const Dev &d, int cx, int cy) {
 __device__ __forceinline__ int cell_lin(const Dev &d, int cx, int cy, int cz) {
   return cell_row(d, cx, cy) + ((cz >> T2B) << TILE_SHIFT) + (cz & ((1 << T2B) - 1));
 }
-// particle ranges of the cells (x, y, z0 .. z1-1), 0 < z1 - z0 <= 8: a z-run of up to 8 cells touches at most two tiles
+// particle ranges of the cells (x, y, z0 .. z1-1), 0 < z1 - z0 <= 2^T2B (= 16; the walk asks for <= 5): such a z-run touches at most two tiles
 struct RowPieces { int lo0, hi0, lo1, hi1; };
 __device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int x, int y, int z0, int z1) {
   const int rb = cell_row(d, x, y);
@@ -138,7 +138,7 @@ __device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int
   const int bA = rb + (tA << TILE_SHIFT);
   RowPieces r;
   r.lo0 = CS[bA + (z0 & ((1 << T2B) - 1))];
-  r.hi0 = CS[bA + min(z1 - (tA << T2B), 1 << T2B)];   // [.. + 8] is the next row of the tile (or the next tile): the end of cell z = 7
+  r.hi0 = CS[bA + min(z1 - (tA << T2B), 1 << T2B)];   // [.. + 2^T2B] is the next row of the tile (or the next tile): the end of the tile row's last cell
   // branch free: when the run stays in one tile the second piece reads the same entry twice (an empty range)
   const int bB = rb + (tB << TILE_SHIFT);
   r.lo1 = CS[bB];
@@ -407,17 +407,12 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
       run = j7;
-#ifdef WCSPH_EXP_SELFGATHER   /* development: every gather goes to the lane's own record (trip counts kept) */
-#define SELFG(jj) (i + ((jj) & 0))
-#else
-#define SELFG(jj) (jj)
-#endif
       WALK_OK(0, d0) WALK_OK(1, d1) WALK_OK(2, d2) WALK_OK(3, d3) WALK_OK(4, d4) WALK_OK(5, d5) WALK_OK(6, d6) WALK_OK(7, d7)
-      float4 p0 = nb_ld(P, SELFG(j0));
-      const float4 p1 = nb_ld(P, SELFG(j1)), p2 = nb_ld(P, SELFG(j2)), p3 = nb_ld(P, SELFG(j3));
-      auto b0 = gl(SELFG(j0), p0); const auto b1 = gl(SELFG(j1), p1); const auto b2 = gl(SELFG(j2), p2); const auto b3 = gl(SELFG(j3), p3);
-      const float4 p4 = nb_ld(P, SELFG(j4)), p5 = nb_ld(P, SELFG(j5)), p6 = nb_ld(P, SELFG(j6)), p7 = nb_ld(P, SELFG(j7));
-      const auto b4 = gl(SELFG(j4), p4); const auto b5 = gl(SELFG(j5), p5); const auto b6 = gl(SELFG(j6), p6); const auto b7 = gl(SELFG(j7), p7);
+      float4 p0 = nb_ld(P, j0);
+      const float4 p1 = nb_ld(P, j1), p2 = nb_ld(P, j2), p3 = nb_ld(P, j3);
+      auto b0 = gl(j0, p0); const auto b1 = gl(j1, p1); const auto b2 = gl(j2, p2); const auto b3 = gl(j3, p3);
+      const float4 p4 = nb_ld(P, j4), p5 = nb_ld(P, j5), p6 = nb_ld(P, j6), p7 = nb_ld(P, j7);
+      const auto b4 = gl(j4, p4); const auto b5 = gl(j5, p5); const auto b6 = gl(j6, p6); const auto b7 = gl(j7, p7);
       nb_pin(p0); nb_pin(b0);
       WALK_ONE(0, ok0, j0, p0, b0) WALK_ONE(1, ok1, j1, p1, b1) WALK_ONE(2, ok2, j2, p2, b2) WALK_ONE(3, ok3, j3, p3, b3)
       WALK_ONE(4, ok4, j4, p4, b4) WALK_ONE(5, ok5, j5, p5, b5) WALK_ONE(6, ok6, j6, p6, b6) WALK_ONE(7, ok7, j7, p7, b7)

@@ -1,6 +1,6 @@
 // dfsph_kernels.h -- the @ti.kernel loops of dfsph.py as hand-written gfx950 kernels.
-// One thread per cell-sorted liquid particle; neighbours are re-walked from the cell table
-// (device.h walk()) instead of read from a materialised 8 KiB/particle list.
+// One thread per cell-sorted liquid particle; every pass iterates the compact per-step neighbour list of the particle
+// (16-bit delta streams built by the grid update, device.h walk()) instead of the reference's 8 KiB/particle row.
 #pragma once
 #include "device.h"
 
@@ -180,11 +180,7 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
   if (own) {
     const float3 vi = xyz(d.vel[i]);
     float t = 0.f;
-#ifdef WCSPH_EXP_SAMELINE   /* development: the payload gather hits the line the position gather just fetched */
-    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.pos, j ^ 1); },
-#else
     walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
-#endif
             [&](int, float3 r, float r2, float4 vj) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
             [&](int, float3 r, float r2) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);

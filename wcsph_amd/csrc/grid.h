@@ -234,11 +234,13 @@ __global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, c
 }
 
 // slab decomposition, faithful mode: the per-step liquid histogram travels as two 16-bit counts per int32 word (an int32
-// SUM all-reduce adds both halves independently while every global count stays below 65536; RCCL has no 16-bit integer)
-__global__ void k_hist_pack16(const int *l, int T, int *packed) {
+// SUM all-reduce adds both halves independently while every global count stays below 65536; RCCL has no 16-bit integer).
+// Each rank's count is clamped to `clamp` = max_in_grid + 1: the summed count still exceeds the cap wherever any rank's
+// did (k_bucket_sum raises ERRBIT_BUCKET), and the low half cannot carry into the neighbouring bucket's count.
+__global__ void k_hist_pack16(const int *l, int T, int *packed, int clamp) {
   int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (2 * w >= T) return;
-  const int a = min(l[2 * w], 0xffff), b = (2 * w + 1 < T) ? min(l[2 * w + 1], 0xffff) : 0;
+  const int a = min(l[2 * w], clamp), b = (2 * w + 1 < T) ? min(l[2 * w + 1], clamp) : 0;
   packed[w] = a | (b << 16);
 }
 __global__ void k_hist_unpack16(const int *packed, int T, int *l) {
@@ -320,29 +322,7 @@ __global__ void __launch_bounds__(ALIAS_TB) k_alias_fill(Dev d, const int *cell_
 
 // ---- raw list length (HashGrid.neighborCount) --------------------------------------------
 // faithful: count_i = sum over the in-box walked cells c of gridCount[hash(c)]  -  (visits of the own bucket)
-// (ref: HashGrid.py:79-106).  cellval[c] = gridCount[hash(c)], then a separable 5x5x5 box sum.
-// Only cells within the walk radius of an occupied cell can be walked by a liquid particle, so the box filter
-// runs on the occupied box bb = {xmin,ymin,zmin,xmax,ymax,zmax} (k_cell_assign) grown by a per-pass margin.
-// thread index -> cell of that sub-box, or -1
-__device__ __forceinline__ int subbox_cell(const Dev &d, const int *bb, int mx, int my, int mz, int t) {
-  if (bb[3] < 0) return -1;
-  const int x0 = max(bb[0] - mx, 0), y0 = max(bb[1] - my, 0), z0 = max(bb[2] - mz, 0);
-  const int x1 = min(bb[3] + mx, d.nx - 1), y1 = min(bb[4] + my, d.ny - 1), z1 = min(bb[5] + mz, d.nz - 1);
-  const int sz = z1 - z0 + 1, sy = y1 - y0 + 1;
-  const int z = z0 + t % sz, q = t / sz;
-  const int x = x0 + q / sy, y = y0 + q % sy;
-  if (x > x1) return -1;
-  return (x * d.ny + y) * d.nz + z;
-}
-// (fixed-size grids + grid-stride loops: the sub-box volume lives on the device)
-__global__ void k_cellval(Dev d, const int *bcount, int *cellval, int *flags, const int *bb) {
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x;; t += gridDim.x * blockDim.x) {
-    int c = subbox_cell(d, bb, 2, 2, 2, t);
-    if (c < 0) return;
-    int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
-    cellval[c] = bcount[ref_hash(cx + d.x0, cy, cz, d.table_size)];
-  }
-}
+// (ref: HashGrid.py:79-106).  cellval[c] = gridCount[hash(c)], then a separable 5x5x5 box sum in LDS.
 // gridCount = static boundary particles + this step's liquid particles (both global sums on a slab decomposition);
 // the cap applies to every bucket, not only walked ones
 // bcount8: the same counts as bytes (saturated at 255) -- a 3 MB table that stays in the 4 MB L2 of every XCD, where the
@@ -358,66 +338,13 @@ __global__ void k_bucket_sum(Dev d, const int *bs, int *bl, int *bcount, unsigne
   bcount8[b] = (unsigned char)min(v, 255);
   if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
 }
-__global__ void k_boxsum(Dev d, const int *in, int *out, int len, int stride, const int *bb, int mx, int my) {
-  // 5-tap sum along one axis; len = cells along the axis, stride = element stride of the axis
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x;; t += gridDim.x * blockDim.x) {
-    int c = subbox_cell(d, bb, mx, my, 0, t);
-    if (c < 0) return;
-    int a = (c / stride) % len;
-    int s = 0;
-#pragma unroll
-    for (int k = -2; k <= 2; k++) {
-      int q = a + k;
-      if (q >= 0 && q < len) s += in[c + k * stride];
-    }
-    out[c] = s;
-  }
-}
-__global__ void k_ncount_faithful(Dev d, const int *boxsum) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl) return;
-  int w = __float_as_int(d.pos[i].w);
-  int cnt = 0;
-  if (w >= 0) {
-    int info = d.cell_info[lin_of(d, w)];
-    int self = (info >> 1) ? d.alias[(size_t)((info >> 1) - 1) * ALIAS_STRIDE + 1] : 1;
-    cnt = boxsum[plain_of(d, w)] - self;
-  }
-  if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);  // ref: HashGrid.py:100-103 (Q3)
-  d.ncount[i] = cnt;
-}
-// The same restricted to where the liquid is: the grid is cut into REGIONS of BC0 x BC1 x BCZ cells (outer x middle x z of
-// the tile order = 4 x 2 x 1 tiles).  k_region_occ flags the regions that hold particles; k_cellval_occ gathers
+// Restricted to where the liquid is: the grid is cut into REGIONS of BC0 x BC1 x BCZ cells (outer x middle x z of
+// the tile order = 4 x 2 x 1 tiles).  k_cell_assign flags the regions that hold particles; k_cellval_occ gathers
 // gridCount[hash(cell)] for every region that is, or touches, a flagged one (the hash scatters neighbouring cells all
 // over the table: these random gathers are the cost, so each cell is gathered ONCE); k_ncount_box loads a flagged
 // region and its 2-cell halo into LDS, runs the three 5-tap sums there and writes neighborCount of the particles in
-// its cells.  The cost follows the liquid's volume, not its bounding box (the five-launch version above: 100 us at
-// C3 at rest, 290 us once the dam has spread over the domain).
-// one thread per region: does it hold a particle?  (one contiguous range per (outer, middle) tile pair; only tiles
-// touching the occupied box can hold particles, and the cell table is current for exactly those)
-__global__ void k_region_occ(Dev d, int *occ) {
-  const Regions R = regions_of(d);
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= R.nb0 * R.nb1 * R.nbz) return;
-  const int bz = g % R.nbz, q = g / R.nbz, o0 = (q / R.nb1) * BC0, o1 = (q % R.nb1) * BC1, oz = bz * BCZ;
-  const int *bb = d.bbox;
-  int any = 0;
-  if (bb[3] >= 0) {
-    const int l0 = d.perm ? bb[1] : bb[0], h0 = d.perm ? bb[4] : bb[3], l1 = d.perm ? bb[0] : bb[1], h1 = d.perm ? bb[3] : bb[4];
-    if (!(o0 > h0 || o0 + BC0 <= l0 || o1 > h1 || o1 + BC1 <= l1 || oz > bb[5] || oz + BCZ <= bb[2])) {
-      const int za = max(oz, bb[2]) >> T2B, zb = min(min(oz + BCZ, d.nz) - 1, bb[5]) >> T2B;
-      for (int k = 0; k < (BC0 >> T0B) * (BC1 >> T1B); k++) {
-        const int t0 = (o0 >> T0B) + k / (BC1 >> T1B), t1 = (o1 >> T1B) + k % (BC1 >> T1B);
-        const int c0 = t0 << T0B, c1 = t1 << T1B;
-        if (t0 < d.nt0 && t1 < d.nt1 && c0 <= h0 && c0 + (1 << T0B) > l0 && c1 <= h1 && c1 + (1 << T1B) > l1) {
-          const int base = (t0 * d.nt1 + t1) * d.nt2;
-          any |= d.cs_l[(base + zb + 1) << TILE_SHIFT] > d.cs_l[(base + za) << TILE_SHIFT];
-        }
-      }
-    }
-  }
-  occ[g] = any;
-}
+// its cells.  The cost follows the liquid's volume, not its bounding box (a separable five-launch version over the
+// occupied box, round 1: 100 us at C3 at rest, 290 us once the dam has spread over the domain).
 // one block per region that is or touches an occupied one: cellval[plain index] = gridCount[hash(cell)]
 template <class T>
 __global__ void __launch_bounds__(BLOCK) k_cellval_occ(Dev d, const T *bcount, const int *occ, int *cellval) {

@@ -34,13 +34,12 @@ struct wcsph_ctx {
   int *oid_b = nullptr;
   // grid scratch
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
-  int *bcount = nullptr, *bcount_s = nullptr, *bcount_l = nullptr, *cellval = nullptr, *celltmp = nullptr;   // gridCount = _s (static solids) + _l (liquid, per step)
+  int *bcount = nullptr, *bcount_s = nullptr, *bcount_l = nullptr, *cellval = nullptr;   // gridCount = _s (static solids) + _l (liquid, per step)
   int *bbox_part = nullptr;
   int n_alias = 0, scan_blocks = 0, n_regions = 0;
   unsigned char *bcount8 = nullptr;
-  int *region_occ = nullptr;
-  bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ      // neighborCount regions that hold particles (grid.h k_region_occ)
-  bool ncount_split = getenv("WCSPH_NCOUNT_SPLIT") != nullptr;   // development: the five-launch neighborCount
+  int *region_occ = nullptr;      // neighborCount regions that hold particles: flagged by k_cell_assign, cleared by k_ncount_box
+  bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false;
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
@@ -53,17 +52,16 @@ struct wcsph_ctx {
   McDev mc = {};                  // MarchingCubeGrid (lazily set up)
   int *mc_tables = nullptr;       // device: edge[256] + tri[256][MC_TRI_ROW]
   size_t mc_nodes = 0;
-  bool vort_fuse = getenv("WCSPH_NO_VORT_FUSE") == nullptr;   // compute_nonpressure_force: vorticity sums in the residual walk
+  static constexpr bool vort_fuse = true;   // compute_nonpressure_force: the vorticity sums ride on a walk that gathers vel_j anyway
   // in-situ timing of the fused pressure_iter launches (wcsph_profile_begin/end): event pairs on the context's stream
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   bool prof_on = false;
   bool in_step = false, cfl_done = false;   // wcsph_dfsph_step in progress; CFL maxima already taken
-  bool warm_fused = false;
+  bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: the warm-start density-change pass is already done
   bool fuse_elem = false;         // wcsph_dfsph_step: elementwise neighbours of the launch sequence run fused (set per step)
   bool nonp_begun = false, warm_scaled = false;
   bool vort_in_div = false;       // the last divergence iteration of this step also took the vorticity sums (k_drho_div_iter_vort)
-  bool vort_div = getenv("WCSPH_NO_VORT_IN_DIV") == nullptr;   // ... what the fused launches have already done        // wcsph_dfsph_step -> solve_divergence: warm-start density-change pass already done
   int *h_flags = nullptr;         // pinned [4]
   // host-side solver state (ref: dfsph.py:36-41 module globals)
   float dt = 0.0f;
@@ -126,27 +124,39 @@ static int check_flags(wcsph_ctx *ctx) {
   if (f & ERRBIT_NONFINITE) return ctx->fail(WCSPH_ENONFINITE, "non-finite particle position (ref: dfsph.py:645-647)");
   return 0;
 }
-// copy reduction slots + flags to the host and wait
 // Device -> host hand-over of the reduction slots and error flags at the solvers' decision points (4-5 per step).
 // One tiny kernel sums the stripes and writes the totals, the flags and then a sequence number straight into pinned
 // host memory; the host polls the sequence word.  A copy + blocking stream wait costs ~25 us of idle GPU per
 // decision, this ~10.
+// Error flags (bucket / list overflow, non-finite position) are STICKY ON THE DEVICE UNTIL THEY HAVE BEEN HANDED TO THE
+// HOST ONCE: no grid update clears them, k_publish clears the word it has just published.  A step that never waits for
+// a reduction (wcsph_sesph_step, a bare update_grid()) therefore reports at the next synchronisation point -- the next
+// wcsph_sync(), solver decision or field transfer -- instead of losing the condition to the following grid update.
 struct HostMail { double acc[8]; int flags[4]; unsigned long long seq; };
-__global__ void k_publish(const double *acc, const int *flags, HostMail *m, unsigned long long seq) {
+__global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned long long seq) {
   const int t = threadIdx.x;
   if (t < 8) {
     double v = 0.0;
     for (int k = 0; k < ACC_STRIPES; k++) v += acc[t * ACC_STRIPES + k];
     m->acc[t] = v;
-  } else if (t < 12) m->flags[t - 8] = flags[t - 8];
+  } else if (t < 12) {
+    m->flags[t - 8] = flags[t - 8];
+    if (t - 8 == FLAG_ERR) flags[FLAG_ERR] = 0;   // handed over: reported exactly once
+  }
   __syncthreads();
   if (t == 0) { __threadfence_system(); __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
-static int pull_scalars(wcsph_ctx *ctx) {
+static int publish_async(wcsph_ctx *ctx) {
   HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw);
   const unsigned long long seq = ++ctx->mail_seq;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->d.acc, (const int *)ctx->d.flags, m, seq);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->d.acc, ctx->d.flags, m, seq);
   LAUNCHCHK();
+  return 0;
+}
+// waits for the mail of the last publish_async(); check_acc: also refuse non-finite reduction totals
+static int collect_mail(wcsph_ctx *ctx, bool check_acc) {
+  HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw);
+  const unsigned long long seq = ctx->mail_seq;
   volatile unsigned long long *flag = &m->seq;
   for (unsigned long spins = 0; *flag != seq; spins++) {
     if ((spins & 0xfffff) == 0xfffff) {   // every ~1 M polls: is the stream still alive?
@@ -159,12 +169,17 @@ static int pull_scalars(wcsph_ctx *ctx) {
   for (int s = 0; s < 8; s++) ctx->h_acc[s] = m->acc[s];
   for (int s = 0; s < 4; s++) ctx->h_flags[s] = m->flags[s];
   int rc = check_flags(ctx);
-  if (rc) return rc;
+  if (rc || !check_acc) return rc;
   // a NaN error sum makes every `err > tol` test of the reference's host loops false, i.e. "converged" (dfsph.py:141-163)
   for (int s = 0; s < 8; s++)
     if (!std::isfinite(ctx->h_acc[s])) return ctx->fail(WCSPH_ENONFINITE, "non-finite reduction result (solver error sum / PCG dot product)");
   { float vm; memcpy(&vm, &ctx->h_flags[FLAG_VMAX], 4); if (!std::isfinite(vm)) return ctx->fail(WCSPH_ENONFINITE, "non-finite CFL velocity maximum"); }
   return 0;
+}
+static int pull_scalars(wcsph_ctx *ctx) {
+  int rc = publish_async(ctx);
+  if (rc) return rc;
+  return collect_mail(ctx, true);
 }
 static int zero_acc(wcsph_ctx *ctx, int slot) {
   HIPCHK(hipMemsetAsync(ctx->d.acc + slot * ACC_STRIPES, 0, ACC_STRIPES * sizeof(double), ctx->stream));
@@ -320,7 +335,6 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   if (d.faithful) {
     DALLOC(ctx->bcount, d.table_size + 1); DALLOC(ctx->bcount_s, d.table_size + 1); DALLOC(ctx->bcount_l, d.table_size + 1);   // [T] stays 0: the scan's end sentinel
     DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->bcount8, d.table_size + 1);
-    if (ctx->ncount_split) DALLOC(ctx->celltmp, d.ncell);
     {
       const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
       ctx->n_regions = ((n0 + BC0 - 1) / BC0) * ((n1 + BC1 - 1) / BC1) * ((d.nz + BCZ - 1) / BCZ);
@@ -397,10 +411,8 @@ static int grid_begin(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
-  // ctx->cnt is all zero here: k_scan_final clears the counters it consumes
-  // overflow / non-finite conditions are re-detected by every update: what the previous one raised has been reported by
-  // the pull_scalars() calls of its step and must not stick to the context (the reference prints and keeps stepping)
-  HIPCHK(hipMemsetAsync(d.flags + FLAG_ERR, 0, sizeof(int), s));
+  // ctx->cnt is all zero here: k_scan_final clears the counters it consumes.  The error flags are NOT cleared here: a
+  // condition stays on the device until k_publish has handed it to the host once (see pull_scalars)
   ctx->pr_valid = false;   // rows are re-sorted
   // the liquid bucket histogram and the region flags are zero here: their consumers (k_bucket_sum, k_ncount_box) clear
   // them -- unless the previous update did not run to its end
@@ -412,7 +424,7 @@ static int grid_begin(wcsph_ctx *ctx) {
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
                        d.faithful ? ctx->bcount_l : (int *)nullptr, ctx->bbox_part, d.n_owned,
-                       d.faithful && !ctx->ncount_split ? ctx->region_occ : (int *)nullptr);
+                       d.faithful ? ctx->region_occ : (int *)nullptr);
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
@@ -433,24 +445,15 @@ static int grid_end(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   hipStream_t s = ctx->stream;
   if (d.faithful) {
-    const int *bb = d.bbox;
     hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
     // neighborCount: 5x5x5 box sum of gridCount[hash(cell)] around every occupied cell, one LDS-tiled launch (grid.h)
     if (d.nl > 0) {
-      if (ctx->ncount_split) {   // the separable five-launch version on the occupied box (kept for A/B timing)
-        hipLaunchKernelGGL(k_cellval, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, ctx->cellval, d.flags, bb);
-        hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nz, 1, bb, 2, 2);
-        hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp, ctx->cellval, d.ny, d.nz, bb, 2, 0);
-        hipLaunchKernelGGL(k_boxsum, dim3(2048), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, ctx->celltmp, d.nx, d.ny * d.nz, bb, 0, 0);
-        hipLaunchKernelGGL(k_ncount_faithful, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const int *)ctx->celltmp);
-      } else {
-        const int nb = ctx->n_regions;
-        if (d.max_in_grid <= 255)
-          hipLaunchKernelGGL(k_cellval_occ<unsigned char>, dim3(nb), dim3(BLOCK), 0, s, d, (const unsigned char *)ctx->bcount8, (const int *)ctx->region_occ, ctx->cellval);
-        else
-          hipLaunchKernelGGL(k_cellval_occ<int>, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, (const int *)ctx->region_occ, ctx->cellval);
-        hipLaunchKernelGGL(k_ncount_box, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
-      }
+      const int nb = ctx->n_regions;
+      if (d.max_in_grid <= 255)
+        hipLaunchKernelGGL(k_cellval_occ<unsigned char>, dim3(nb), dim3(BLOCK), 0, s, d, (const unsigned char *)ctx->bcount8, (const int *)ctx->region_occ, ctx->cellval);
+      else
+        hipLaunchKernelGGL(k_cellval_occ<int>, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, (const int *)ctx->region_occ, ctx->cellval);
+      hipLaunchKernelGGL(k_ncount_box, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
     }
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
@@ -476,7 +479,10 @@ int wcsph_bucket_hist_pack(wcsph_ctx *ctx, void **d_ptr, int64_t *n_words) {   /
   if (!d_ptr || !n_words) return WCSPH_EARG;
   if (!ctx->d.faithful) return ctx->fail(WCSPH_EARG, "the bucket histogram exists in faithful neighbour mode only");
   const int T = ctx->d.table_size, W = (T + 1) / 2;
-  hipLaunchKernelGGL(k_hist_pack16, dim3(nblk(W)), dim3(BLOCK), 0, ctx->stream, (const int *)ctx->bcount_l, T, ctx->bcount);   // bcount is rebuilt by grid_end
+  // per-rank clamp max_in_grid + 1: enough to trip the cap after the sum, and world * (max_in_grid + 1) stays below 2^16
+  // for every sane cap (a carry into the neighbouring bucket's half needs max_in_grid > 8190 at 8 ranks)
+  const int clamp = ctx->d.max_in_grid + 1 < 0xffff ? ctx->d.max_in_grid + 1 : 0xffff;
+  hipLaunchKernelGGL(k_hist_pack16, dim3(nblk(W)), dim3(BLOCK), 0, ctx->stream, (const int *)ctx->bcount_l, T, ctx->bcount, clamp);   // bcount is rebuilt by grid_end
   LAUNCHCHK();
   *d_ptr = ctx->bcount; *n_words = W;
   return WCSPH_OK;
@@ -485,7 +491,7 @@ int wcsph_bucket_hist_unpack(wcsph_ctx *ctx) {
   NEED_SETUP();
   if (!ctx->d.faithful) return ctx->fail(WCSPH_EARG, "the bucket histogram exists in faithful neighbour mode only");
   const int T = ctx->d.table_size, W = (T + 1) / 2;
-  // unpack through celltmp-free path: bcount holds the summed words, bcount_l receives the global counts
+  // bcount holds the summed words, bcount_l receives the global counts
   hipLaunchKernelGGL(k_hist_unpack16, dim3(nblk(W)), dim3(BLOCK), 0, ctx->stream, (const int *)ctx->bcount, T, ctx->bcount_l);
   LAUNCHCHK();
   return WCSPH_OK;
@@ -622,9 +628,13 @@ int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(dst, ctx->stage, (size_t)nl * per * 4, hipMemcpyDeviceToHost, s));
   }
+  // a transfer is a synchronisation point: error flags raised since the last one travel with it (the data is delivered
+  // either way; the return code says whether an overflow / non-finite condition was raised while it was produced)
+  int frc = publish_async(ctx);
+  if (frc) return frc;
   HIPCHK(hipStreamSynchronize(s));
   if (field == WCSPH_F_POS && d.ns > 0) memcpy((float *)dst + (size_t)nl * 3, ctx->solid_host.data(), (size_t)d.ns * 12);
-  return WCSPH_OK;   // a transfer never fails on the overflow flags: wcsph_sync() and the solver entry points report them
+  return collect_mail(ctx, false);
 }
 
 int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes) {
@@ -834,7 +844,7 @@ static int pressure_iter_async(wcsph_ctx *ctx) {
 static int divergence_iter_fused(wcsph_ctx *ctx) {
   if (ctx->d.n_owned < ctx->d.nl) return divergence_iter_async(ctx);
   PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v);   // also clears ACC_ERR
-  if (ctx->fuse_elem && ctx->vort_fuse && ctx->vort_div && ctx->pr_valid) {
+  if (ctx->fuse_elem && ctx->vort_fuse && ctx->pr_valid) {
     PASS(k_drho_div_iter_vort, ctx->dt);
     ctx->vort_in_div = true;
   } else PASS((k_drho_div<DRHO_ITER, true>), ctx->dt);
@@ -1669,8 +1679,16 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_DRHO_PRESS_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_PRESS(DRHO_ITER, dt); break;
     case WCSPH_PH_END_PRESS: ELEM(k_end_press, dt); break;
     case WCSPH_PH_CLEAR: ELEM(k_clear_nonpressure); break;
-    case WCSPH_PH_TENSION_NORMAL: if (ctx->p.tension_fixed == 0) return ctx->fail(WCSPH_EARG, "literal tension is not available phase by phase"); RPASS(k_tension_normal); break;
-    case WCSPH_PH_TENSION_ACCEL: if (ctx->p.tension_fixed == 0) return ctx->fail(WCSPH_EARG, "literal tension is not available phase by phase"); PASS(k_tension_accel); break;
+    // tension_fixed = 0: the reference loop literally, over its raw bucket rows (bucket.h).  On a slab window the table
+    // spans all ranks (far aliased entries name particles of other slabs): bucket_build refuses with a message.
+    case WCSPH_PH_TENSION_NORMAL:
+      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build(ctx))) return rc; ELEM(k_tension_normal_literal, ctx->bk); }
+      else RPASS(k_tension_normal);
+      break;
+    case WCSPH_PH_TENSION_ACCEL:
+      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build(ctx))) return rc; ELEM(k_tension_accel_literal, ctx->bk); }
+      else PASS(k_tension_accel);
+      break;
     case WCSPH_PH_VISC_GUESS: ELEM(k_visc_guess); break;
     case WCSPH_PH_VISC_MINV: RPASS(k_visc_minv, dt); break;
     case WCSPH_PH_VISC_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; RPASS(k_visc_residual, dt); break;

@@ -42,49 +42,25 @@ pci_coff = None
 vel = d_vel = d_vel_pre = pos_star = vel_star = rho = adv_rho = pressure = rho_err = deltaT = None
 
 
-def CpuGradW(r):
-    """ref: pcisph.py:75-85"""
-    res = np.array([0.0, 0.0, 0.0])
-    rl = np.linalg.norm(r)
-    q = rl / searchR
-    if (rl > 1.0e-5) and (q <= 1.0):
-        gradq = r / (rl * searchR)
-        if q <= 0.5:
-            res = m_l * q * (3.0 * q - 2.0) * gradq
-        else:
-            factor = 1.0 - q
-            res = -m_l * (factor * factor) * gradq
-    return res
-
-
 def GetPciCoff():
-    """ref: pcisph.py:87-115 (host side, float64)"""
-    supportRadius = searchR
-    diam = 2.0 * particleRadius
-    sumGradW = np.array([0.0, 0.0, 0.0])
-    sumGradW2 = 0.0
-    V00 = particleRadius * particleRadius * particleRadius * 0.8 * 8.0
-    xi = np.array([0.0, 0.0, 0.0])
-    xj = np.array([-supportRadius, -supportRadius, -supportRadius])
-    while xj[0] <= supportRadius:
-        while xj[1] <= supportRadius:
-            while xj[2] <= supportRadius:
-                r = xi - xj
-                dist = np.linalg.norm(r)
-                if dist < supportRadius:
-                    grad = CpuGradW(r)
-                    sumGradW += grad
-                    dist_grad = np.linalg.norm(grad)
-                    sumGradW2 += dist_grad * dist_grad
-                xj[2] += diam
-            xj[1] += diam
-            xj[2] = -supportRadius
-        xj[0] += diam
-        xj[1] = -supportRadius
-        xj[2] = -supportRadius
-    beta = 2.0 * V00 * V00
-    dist_sumgrad = np.linalg.norm(sumGradW)
-    return 1.0 / (beta * (dist_sumgrad * dist_sumgrad + sumGradW2))
+    """The PCISPH stiffness constant delta of a filled neighbourhood (ref: pcisph.py:87-115; host side, float64):
+    1 / (2 V0^2 (|sum_j gradW_j|^2 + sum_j |gradW_j|^2)) over the lattice points of pitch 2R inside the support.
+    One array expression over the whole lattice; the lattice coordinates are built by repeated addition from -h, as
+    the reference's running xj is, so every coordinate has the reference's float64 rounding."""
+    h, diam = searchR, 2.0 * particleRadius
+    axis = [-h]
+    while axis[-1] + diam <= h:
+        axis.append(axis[-1] + diam)
+    r = -np.stack(np.meshgrid(axis, axis, axis, indexing="ij"), -1).reshape(-1, 3)     # x_i - x_j with x_i = 0
+    rl = np.sqrt((r * r).sum(1))
+    q = rl / h
+    ok = (rl < h) & (rl > 1.0e-5)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        scale = np.where(q <= 0.5, m_l * q * (3.0 * q - 2.0), -m_l * (1.0 - q) ** 2) / (rl * h)
+    grad = np.where(ok[:, None], scale[:, None] * r, 0.0)
+    sum_grad = grad.sum(0)
+    sum_grad2 = (grad * grad).sum()
+    return float(1.0 / (2.0 * VL0 * VL0 * (sum_grad @ sum_grad + sum_grad2)))
 
 
 def _call(name):

@@ -45,12 +45,13 @@ class HipBackend:
     """Compute backend of one rank: a libwcsph_hip.so context with a slab-local cell window."""
 
     def __init__(self, capacity, solid_local, bounds, window, particleR=0.025, device=None, neighbor_mode="clean",
-                 owned=None, n_global=(0, 0), **attrs):
+                 owned=None, n_global=(0, 0), stream=None, **attrs):
         from .ParticleData import ParticleData
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.load()
         self.faithful = neighbor_mode == "faithful"
         pd = ParticleData(particleR, neighbor_mode=neighbor_mode)
+        pd.tension_fixed = 1   # the literal compute_tension reads the reference's raw bucket rows, which span all ranks
         for k, v in attrs.items():
             setattr(pd, k, v)
         if self.faithful:   # the reference hash table has `count` buckets: the GLOBAL particle count (HashGrid.py:114)
@@ -69,8 +70,9 @@ class HipBackend:
         if self.faithful:
             _lib.check(self.ctx, self.lib.wcsph_set_global_liquid(self.ctx, int(n_global[0])))
         # one HIP stream for everything this rank does: the library's kernels, torch's row shuffling and the
-        # RCCL calls torch.distributed enqueues are ordered by it (SlabSim.step runs under torch.cuda.stream)
-        self.stream = torch.cuda.Stream(self.device)
+        # RCCL calls torch.distributed enqueues are ordered by it (SlabSim.step runs under torch.cuda.stream).  SlabSim
+        # passes ITS stream, so a backend rebuilt by a rebalance keeps the stream the rows were written on.
+        self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
         _lib.check(self.ctx, self.lib.wcsph_set_stream(self.ctx, C.c_void_p(self.stream.cuda_stream)))
         pd.setup_data_cpu()
         # reduction slots in a torch tensor: the slab driver all-reduces them in place on the device (SlabSim.reduce_acc)
@@ -193,6 +195,9 @@ def balanced_cuts(cellx_hist, world, min_width=GHOST_CELLS):
     """Cell-column cuts [world+1] giving ~equal particle counts per slab; cut[0] = 0, cut[-1] = nx; every slab at least
     min_width columns wide (SlabSim uses MIN_SLAB)."""
     nx = len(cellx_hist)
+    if nx < world * min_width:
+        raise ValueError("the domain is %d cell columns wide: %d slabs need at least %d columns each (%d in all); use fewer "
+                         "ranks or a wider box" % (nx, world, min_width, world * min_width))
     cum = np.concatenate([[0], np.cumsum(cellx_hist)])
     total = cum[-1]
     cuts = [0]
@@ -241,6 +246,8 @@ class SlabSim:
         rows[:, 14] = np.asarray(gid_local, np.int32).view(np.float32)
         self.rows = torch.from_numpy(rows).to(self.device)
         self.B = None
+        # ONE stream for the life of the simulation, handed to every backend (a rebalance rebuilds the backend)
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self._set_cuts(list(cuts))
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
@@ -267,9 +274,15 @@ class SlabSim:
         solid_local = self.solid_all[(scx >= w0) & (scx < w1)]
         capacity = int(max(self.rows.shape[0], self.n_global // world) * self._cap_factor) + 4096
         if self.B is not None:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)   # nothing of the old backend may still be in flight when it is freed
             self.B.close()
+        if self.hi - self.lo < MIN_SLAB and world > 1:
+            raise ValueError("rank %d: slab [%d, %d) is narrower than %d cell columns" % (rank, self.lo, self.hi, MIN_SLAB))
         kw = dict(capacity=capacity, solid_local=solid_local, bounds=(self.minb, self.maxb), window=self.window,
                   particleR=self.particleR, device=self.device)
+        if self.stream is not None:
+            kw["stream"] = self.stream
         if self.neighbor_mode == "faithful":
             big = 1 << 30
             kw.update(neighbor_mode="faithful", owned=(self.lo if rank > 0 else -big, self.hi if rank < world - 1 else big),
@@ -285,6 +298,8 @@ class SlabSim:
         self.interior = (self.lo + GHOST_CELLS if rank > 0 else -big, self.hi - GHOST_CELLS if rank < world - 1 else big)
         # preallocated halo buffers (sized for the widest exchange: two vec3 fields), grown on demand
         self._hb = {}
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)   # backend construction used the default stream (setup copies)
 
     # ---- geometry -------------------------------------------------------------------------------------
     def _cellx_np(self, x):
@@ -527,10 +542,10 @@ class SlabSim:
             self.B.load_state(n, torch.cat([owned, gl, gr], 0))
 
     def rebalance(self, force=False):
-        stream = getattr(self.B, "stream", None)
-        if stream is None:
+        """between steps only (never from inside _step: the backend, and everything queued on it, is replaced)"""
+        if self.stream is None:
             return self._rebalance(force)
-        with torch.cuda.stream(stream):      # the rows were written on the backend's stream
+        with torch.cuda.stream(self.stream):      # the rows were written on this stream
             return self._rebalance(force)
 
     def _rebalance(self, force=False):
@@ -577,20 +592,20 @@ class SlabSim:
 
     # ---- the step -------------------------------------------------------------------------------------------
     def step(self):
-        stream = getattr(self.B, "stream", None)
-        if stream is None:
+        # the periodic rebalance runs BEFORE the step and outside its stream context: it closes the backend and builds a
+        # new one, and nothing of the old one may still be in flight or referenced by the step's locals
+        if self.rebalance_every and self.steps_done and self.steps_done % self.rebalance_every == 0:
+            self.rebalance()
+        self.steps_done += 1
+        if self.stream is None:
             return self._step()
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(self.stream):
             return self._step()
 
     def _step(self):
         B, ph, x = self.B, self.B.phase, self.xchg
         ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = _lib.ACC_ERR, _lib.ACC_DAD, _lib.ACC_DNEW, _lib.ACC_DZERO
         N = float(self.n_global)
-        if self.rebalance_every and self.steps_done and self.steps_done % self.rebalance_every == 0:
-            self._rebalance()
-            B, ph, x = self.B, self.B.phase, self.xchg
-        self.steps_done += 1
         self.redistribute()
         B.set_scalar("deltaT", self.dt)
         if self.neighbor_mode == "faithful" and self.world > 1:
@@ -675,10 +690,11 @@ class SlabSim:
 
 
 # ---------------------------------------------------------------------------------------------------------
-def dam_break_slab(n, rank, world, particleRadius=scene.PARTICLE_RADIUS):
+def dam_break_slab(n, rank, world, particleRadius=scene.PARTICLE_RADIUS, cuts=None):
     """This rank's share of the n^3 dam break (dfsph.py:59-82 recipe) without building the whole scene:
     returns (liquid_local, solid_all, bounds, cuts, n_global, gid_local); gid = the particle's index in the reference's
-    own creation order (dfsph.py:69-73: i = (x * ny + y) * nz + z), which the faithful CFL prefix (Q5) is defined on."""
+    own creation order (dfsph.py:69-73: i = (x * ny + y) * nz + z), which the faithful CFL prefix (Q5) is defined on.
+    cuts: explicit cell-column cuts instead of the balanced ones (tests start from skewed cuts and rebalance)."""
     dis = particleRadius * 2.0
     L = n * dis
     solid = scene.box_shell(L)
@@ -689,7 +705,7 @@ def dam_break_slab(n, rank, world, particleRadius=scene.PARTICLE_RADIUS):
     cellx = np.trunc((xs.astype(np.float32) - minb[0]) * inv).astype(np.int64)
     nx = int(float(maxb[0] - minb[0]) / dis + 1.0)
     hist = np.bincount(cellx, minlength=nx) * (n * n)
-    cuts = balanced_cuts(hist, world, MIN_SLAB)
+    cuts = balanced_cuts(hist, world, MIN_SLAB) if cuts is None else list(cuts)
     mine = np.nonzero((cellx >= cuts[rank]) & (cellx < cuts[rank + 1]))[0]
     j = np.arange(n * n)
     y = (j // n).astype(np.float64) * dis + 0.2
