@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Golden vectors from the reference's OWN text (build container only; nothing here travels to the GPU box).
+
+    python tests/golden/make_reference_fixtures.py dfsph   ->  tests/golden/ref_dfsph_default_scene.npz
+    python tests/golden/make_reference_fixtures.py sesph   ->  tests/golden/ref_sesph_default_scene.npz
+
+Puts tests/golden/taichi_standin (a minimal serial `taichi`: fields = NumPy arrays, f32 / i32 scalars, kernels run as
+plain Python) first on sys.path, imports /root/reference/dfsph.py (or sesph.py) UNMODIFIED -- the script builds its
+shipped default scene at import (8000 liquid particles + model/box_boundry.obj, resp. the 40^3 lattice shell), calls
+reset_param() and, the stand-in's GUI not `running`, skips its main loop -- and then runs the main-loop body
+(dfsph.py:606-617 / sesph.py:220-225) STEPS times through the script's own functions, recording every field the
+parity tests compare, stage by stage.
+
+The stand-in pins the reference's formulas, loop structure, constants and host control flow; it does not pin Taichi's
+execution semantics (see taichi_standin/taichi.py).  tests/test_reference_fixtures.py compares the oracle (CPU) and the
+HIP library (GPU) with these files.  Runtime: pure Python over ~2 M list entries per pass -- about an hour for dfsph.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "taichi_standin"))
+
+
+def _name_fields(ti, *objs):
+    for o in objs:
+        for k, v in list(vars(o).items()):
+            if isinstance(v, ti.Field):
+                v.name = "%s.%s" % (type(o).__name__ if not isinstance(o, type(sys)) else o.__name__, k)
+
+
+def run_dfsph(steps):
+    os.chdir(REF)                       # the script opens model/box_boundry.obj and MCData.txt by relative path
+    import taichi as ti
+    t0 = time.time()
+    import dfsph as ref                 # builds the scene, reset_param()
+    pd = ref.particle_data
+    _name_fields(ti, ref, pd, pd.hash_grid)
+    out = {"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
+           "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()}
+    print("scene: %d liquid + %d solid, blockSize %s (%.0f s)" % (pd.liquid_count, pd.solid_count, out["blockSize"], time.time() - t0), flush=True)
+
+    def snap(tag, **f):
+        for k, v in f.items():
+            out["s%d_%s_%s" % (step, tag, k)] = v.to_numpy() if hasattr(v, "to_numpy") else np.asarray(v)
+        print("  step %d %-14s %.0f s" % (step, tag, time.time() - t0), flush=True)
+
+    for step in range(steps):
+        # ---- dfsph.py:606-617, in the script's own order ----
+        pd.hash_grid.update_grid()
+        snap("grid", neighborCount=pd.hash_grid.neighborCount, gridCount=pd.hash_grid.gridCount)
+        if step == 0:
+            out["neighbor_rows_0_64"] = pd.hash_grid.neighbor.to_numpy()[:64]
+        ref.compute_density()
+        snap("density", rho=pd.rho)
+        ref.compute_dfsph_coff()
+        snap("coff", alpha=ref.alpha_coff)
+        ref.solve_vel_divergence()
+        snap("divergence", vel=pd.vel, adv_rho=pd.adv_rho, kappa_v=ref.kappa_v, alpha=ref.alpha_coff, dv_iter=np.int32(ref.dv_iter),
+             avg_density_err=pd.avg_density_err)
+        ref.compute_nonpressure_force()
+        snap("nonpressure", d_vel=pd.d_vel, vel_guess=pd.vel_guess, omega=pd.omega, d_omega=pd.d_omega, normal=pd.normal,
+             cg_Minv=pd.cg_Minv, vs_iter=np.int32(ref.vs_iter), cg_delta=pd.cg_delta, cg_delta_zero=pd.cg_delta_zero)
+        ref.optimize_time_step()
+        snap("dt", deltaT=ref.deltaT, vel_max0=pd.vel_max.to_numpy()[:1])
+        ref.update_vel()
+        ref.solve_pressure()
+        snap("pressure", vel=pd.vel, adv_rho=pd.adv_rho, kappa=ref.kappa, pr_iter=np.int32(ref.pr_iter), avg_density_err=pd.avg_density_err)
+        ref.update_pos()
+        snap("end", pos=pd.pos)
+    out["steps"] = np.int32(steps)
+    out["oob_reads"] = np.array(["%s=%d" % kv for kv in sorted(ti.oob_reads.items())] or ["none"])
+    print("out-of-bounds reads served as 0:", dict(ti.oob_reads), flush=True)
+    return out
+
+
+def run_sesph(steps):
+    os.chdir(REF)
+    import taichi as ti
+    t0 = time.time()
+    import sesph as ref
+    pd = ref.particle_data
+    _name_fields(ti, ref, pd, pd.hash_grid)
+    out = {"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
+           "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()}
+    print("scene: %d liquid + %d solid, blockSize %s (%.0f s)" % (pd.liquid_count, pd.solid_count, out["blockSize"], time.time() - t0), flush=True)
+    for step in range(steps):
+        # ---- sesph.py:220-225 ----
+        pd.hash_grid.update_grid()
+        out["s%d_neighborCount" % step] = pd.hash_grid.neighborCount.to_numpy()
+        print("  step %d grid %.0f s" % (step, time.time() - t0), flush=True)
+        ref.update_advection_density()
+        out["s%d_rho_raw" % step] = ref.rho.to_numpy()
+        ref.update_pressure()
+        out["s%d_rho" % step], out["s%d_pressure" % step] = ref.rho.to_numpy(), ref.pressure.to_numpy()
+        print("  step %d density %.0f s" % (step, time.time() - t0), flush=True)
+        ref.compute_force()
+        out["s%d_d_vel" % step] = ref.d_vel.to_numpy()
+        ref.integrator_sesph()
+        out["s%d_vel" % step], out["s%d_pos" % step] = ref.vel.to_numpy(), pd.pos.to_numpy()
+        out["s%d_deltaT" % step] = ref.deltaT.to_numpy()
+        print("  step %d end %.0f s" % (step, time.time() - t0), flush=True)
+    out["steps"] = np.int32(steps)
+    out["oob_reads"] = np.array(["%s=%d" % kv for kv in sorted(ti.oob_reads.items())] or ["none"])
+    return out
+
+
+if __name__ == "__main__":
+    which = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else (2 if which == "dfsph" else 1)
+    res = run_dfsph(steps) if which == "dfsph" else run_sesph(steps)
+    path = os.path.join(HERE, "ref_%s_default_scene.npz" % which)
+    np.savez_compressed(path, **res)
+    print("wrote", path, os.path.getsize(path), "bytes")

@@ -40,8 +40,9 @@ def test_one_step_from_a_developed_state(mode, n, steps):
     nl = pd.liquid_count
     ctx, lib = pd._need_ctx(), _lib.load()
     pos = pd.pos.to_numpy()
-    # the state really is a developed one: the column has collapsed and spread, particles sit in crowded cells
-    assert pos[:nl, 1].max() < 0.2 + 0.75 * n * 0.05
+    # the state really is a developed one: the column has collapsed (centre of mass well below the initial one) and
+    # splashed up the walls (particles above the initial column top)
+    assert pos[:nl, 1].mean() < 0.6 * (0.2 + 0.5 * n * 0.05)
     state = {f: getattr(pd, f).to_numpy() for f in ("vel", "omega", "vel_guess")}
     state["kappa"], state["kappa_v"] = dfsph.kappa.to_numpy(), dfsph.kappa_v.to_numpy()
     dt0 = float(dfsph.deltaT[0])

@@ -86,7 +86,7 @@ def test_hip_slab_ranks_match_one_rank(tmp_path, world, n):
     for l in lw:
         np.testing.assert_array_equal(l1[:, :3], l[:, :3])
     assert (sum(l[:, 4] for l in lw) == n ** 3).all()
-    assert all(l[0, 4] != l[-1, 4] for l in lw)           # every rank gained or lost rows
+    assert sum(l[0, 4] != l[-1, 4] for l in lw) >= 2      # rows crossed a cut: at least two ranks gained or lost some
 
 
 def test_faithful_slabs_reproduce_the_single_context(tmp_path):
