@@ -141,6 +141,11 @@ int wcsph_hashgrid_rows_to_host(wcsph_ctx *ctx, int32_t h0, int32_t n, int32_t c
  * the 16-bit delta streams; original indices (solids offset by n_liquid), -1 padded.
  * counts[n][3] = {liquid entries, solid entries, hop slots}; lists[n][cap] = liquid entries then solid entries */
 int wcsph_compact_lists_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t cap, int32_t *counts, int32_t *lists);
+/* diagnostics: how evenly the compact lists load the 64-lane waves that walk them (a wave runs as many trips as its
+ * longest list).  Histograms over 8-slot stream blocks, 0..63 (64 bins each):
+ * hist[0] particles by liquid blocks, hist[1] by solid blocks, hist[2] / hist[3] waves (64 consecutive cell-sorted
+ * particles) by their LONGEST liquid / solid list, hist[4] waves by the block count 3/4 of their lanes reach (liquid) */
+int wcsph_list_stats(wcsph_ctx *ctx, int64_t hist[5][64]);
 
 /* ---- dfsph.py kernels (one entry per @ti.kernel) ------------------------------------- */
 int wcsph_dfsph_reset_param(wcsph_ctx *ctx);            /* ref: dfsph.py:167-178 */

@@ -1509,6 +1509,7 @@ __global__ void k_compact_lists(Dev d, int i0, int n, int cap, int *counts, int 
   int w = 0, hops = 0, run = i;
   for (int k = 0; k < cl; k++) {
     const int dd = (int)(short)L[(size_t)(k >> 3) * st * 8 + (k & 7)];
+    if ((k & 7) == 0) run = i;          // every block is anchored (device.h NbWriter)
     run += dd;
     if (!NB_IS_ENTRY(dd)) { hops++; continue; }
     if (w < cap) row[w] = d.oid[run];
@@ -1518,6 +1519,7 @@ __global__ void k_compact_lists(Dev d, int i0, int n, int cap, int *counts, int 
   run = head.y;
   for (int k = 0; k < cs; k++) {
     const int dd = (int)(short)S[(size_t)(k >> 3) * st * 8 + (k & 7)];
+    if ((k & 7) == 0) run = head.y;
     run += dd;
     if (!NB_IS_ENTRY(dd)) { hops++; continue; }
     if (w < cap) row[w] = d.nl + __float_as_int(d.spos[run].w);
@@ -1540,6 +1542,32 @@ int wcsph_compact_lists_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t c
   hipError_t e3 = hipStreamSynchronize(ctx->stream);
   hipFree(dc); hipFree(dl);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return ctx->fail(WCSPH_EHIP, "compact_lists_to_host copy");
+  return WCSPH_OK;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_list_stats(Dev d, unsigned long long *hist) {
+  const int i = sorted_index();
+  const bool own = i < d.nl && d.oid[i] < d.n_owned;
+  const int2 head = own ? d.nhead[i] : make_int2(0, 0);
+  const int nbl = min(((head.x & 0xffff) + 7) >> 3, 63), nbs = min((int)(((unsigned)head.x >> 16) + 7) >> 3, 63);
+  if (own) { atomicAdd(&hist[nbl], 1ull); atomicAdd(&hist[64 + nbs], 1ull); }
+  int ml = nbl, ms = nbs;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ml = max(ml, __shfl_xor(ml, o, WAVE)); ms = max(ms, __shfl_xor(ms, o, WAVE)); }
+  const int T = bal_common_blocks(nbl);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && __ballot(own)) { atomicAdd(&hist[128 + ml], 1ull); atomicAdd(&hist[192 + ms], 1ull); atomicAdd(&hist[256 + min(T, 63)], 1ull); }
+}
+int wcsph_list_stats(wcsph_ctx *ctx, int64_t hist[5][64]) {
+  NEED_GRID();
+  if (!hist) return WCSPH_EARG;
+  unsigned long long *dh = nullptr;
+  HIPCHK(hipMalloc((void **)&dh, 5 * 64 * 8));
+  hipError_t e0 = hipMemsetAsync(dh, 0, 5 * 64 * 8, ctx->stream);
+  if (ctx->d.nl > 0) hipLaunchKernelGGL(k_list_stats, dim3(nblk8(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, dh);
+  hipError_t e1 = hipMemcpyAsync(hist, dh, 5 * 64 * 8, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  hipFree(dh);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) return ctx->fail(WCSPH_EHIP, "wcsph_list_stats");
   return WCSPH_OK;
 }
 
