@@ -112,16 +112,13 @@ template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_div(Dev d, float dt) {
   LOAD_I
   float a = 0.f;
-  struct Own { float3 vi; } o;
-  float acc[1] = {0.f};
-  auto load_own = [&](int q) { Own w; w.vi = xyz(d.vel[q]); return w; };
-  if (own) o = load_own(i);
-  walk_bal<8, false>(d, i, own, pi, d.pos, o, acc, load_own, [&](int j, float4) { return nb_ld(d.vel, j); },
-                     [&](int, float3 r, float r2, float4 vj) { acc[0] += d.VL0 * cubic_gradW_scale(d, r2) * dot3(o.vi - xyz(vj), r); },
-                     [&](int, float3 r, float r2) { acc[0] += d.VS0 * cubic_gradW_scale(d, r2) * dot3(o.vi, r); });
   if (own) {
     if (MODE == DRHO_WARM) d.kappa_v[i] = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
-    a = fmaxf(acc[0], 0.0f);
+    const float3 vi = xyz(d.vel[i]);
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+            [&](int, float3 r, float r2, float4 vj) { a += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
+            [&](int, float3 r, float r2) { a += d.VS0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
+    a = fmaxf(a, 0.0f);
     if (d.ncount[i] < 20) a = 0.0f;  // raw list length, Q2
     d.adv_rho[i] = a;
     float al = d.alpha[i];
@@ -180,15 +177,12 @@ template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
   LOAD_I
   float e = 0.f;
-  struct Own { float3 vi; } o;
-  float acc[1] = {0.f};
-  auto load_own = [&](int q) { Own w; w.vi = xyz(d.vel[q]); return w; };
-  if (own) o = load_own(i);
-  walk_bal<8, false>(d, i, own, pi, d.pos, o, acc, load_own, [&](int j, float4) { return nb_ld(d.vel, j); },
-                     [&](int, float3 r, float r2, float4 vj) { acc[0] += d.VL0 * cubic_gradW_scale(d, r2) * dot3(o.vi - xyz(vj), r); },
-                     [&](int, float3 r, float r2) { acc[0] += d.VL0 * cubic_gradW_scale(d, r2) * dot3(o.vi, r); });
   if (own) {
-    const float t = acc[0];
+    const float3 vi = xyz(d.vel[i]);
+    float t = 0.f;
+    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+            [&](int, float3 r, float r2, float4 vj) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
+            [&](int, float3 r, float r2) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
     d.adv_rho[i] = a;
     e = a - 1.0f;
@@ -235,24 +229,23 @@ template <int COND>
 __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, float dt, float *kap = nullptr) {
   if (kap) acc_clear(ACC_SLOT(d, ACC_ERR));   // fused solver loops: the density-change pass launched next sums into it
   LOAD_I
-  const bool run = own && !(COND == 1 && !(d.adv_rho[i] > 0.0f));
-  struct Own { float ki; } o;
-  float acc[3] = {0.f, 0.f, 0.f};
-  auto load_own = [&](int q) { Own w; w.ki = pk[q].w; return w; };
-  if (run) o = load_own(i);
-  walk_bal<8, false>(d, i, run, pi, pk, o, acc, load_own, [](int, float4 p) { return p.w; },
-                     [&](int, float3 r, float r2, float kj) {
-                       const float s = o.ki + kj;
-                       if (fabsf(s) > d.eps) { const float g = s * cubic_gradW_scale(d, r2); acc[0] += r.x * g; acc[1] += r.y * g; acc[2] += r.z * g; }
-                     },
-                     [&](int, float3 r, float r2) {
-                       if (fabsf(o.ki) > d.eps) { const float g = o.ki * (d.VS0 / d.VL0) * cubic_gradW_scale(d, r2); acc[0] += r.x * g; acc[1] += r.y * g; acc[2] += r.z * g; }
-                     });
-  if (!run) return;
-  if (kap) kap[i] += o.ki;
+  if (!own) return;
+  if (COND == 1 && !(d.adv_rho[i] > 0.0f)) return;
+  const float ki = pk[i].w;
+  if (kap) kap[i] += ki;
+  float3 acc = f3(0, 0, 0);
+  const bool ks = fabsf(ki) > d.eps;
+  walk<8>(d, i, pi, pk, [](int, float4 p) { return p.w; },
+          [&](int, float3 r, float r2, float kj) {
+            float s = ki + kj;
+            if (fabsf(s) > d.eps) acc = acc + r * (s * cubic_gradW_scale(d, r2));
+          },
+          [&](int, float3 r, float r2) {
+            if (ks) acc = acc + r * (ki * (d.VS0 / d.VL0) * cubic_gradW_scale(d, r2));
+          });
   float4 v = d.vel[i];
   const float f = dt * d.VL0;
-  v.x += f * acc[0]; v.y += f * acc[1]; v.z += f * acc[2];
+  v.x += f * acc.x; v.y += f * acc.y; v.z += f * acc.z;
   d.vel[i] = v;
 }
 
