@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
 """Golden vectors from the reference's OWN text (build container only; nothing here travels to the GPU box).
 
-    python tests/golden/make_reference_fixtures.py dfsph   ->  tests/golden/ref_dfsph_default_scene.npz
-    python tests/golden/make_reference_fixtures.py sesph   ->  tests/golden/ref_sesph_default_scene.npz
+    python tests/golden/make_reference_fixtures.py dfsph            ->  tests/golden/ref_dfsph_default_scene.npz
+    python tests/golden/make_reference_fixtures.py dfsph_perturbed  ->  tests/golden/ref_dfsph_perturbed_default_scene.npz
+    python tests/golden/make_reference_fixtures.py sesph            ->  tests/golden/ref_sesph_default_scene.npz
+
+`dfsph` starts from the script's own rest state, where most neighbour sums are identically zero for the first steps
+(v = 0, omega = 0).  `dfsph_perturbed` is the same imported script with a non-trivial STATE written into its fields
+before the loop body runs (positions jittered by +-0.2 R, a smooth velocity and spin field, tension_coff =
+tension_coff_b = 0.05 -- the attributes the reference says to edit, ParticleData.py:80-81): every term of every pass
+contributes, the solvers iterate.  The state is part of the fixture.
 
 Puts tests/golden/taichi_standin (a minimal serial `taichi`: fields = NumPy arrays, f32 / i32 scalars, kernels run as
 plain Python) first on sys.path, imports /root/reference/dfsph.py (or sesph.py) UNMODIFIED -- the script builds its
@@ -34,15 +41,35 @@ def _name_fields(ti, *objs):
                 v.name = "%s.%s" % (type(o).__name__ if not isinstance(o, type(sys)) else o.__name__, k)
 
 
-def run_dfsph(steps):
+def perturb(ref, pd, out):
+    """a deterministic non-trivial state, written through the fields' own from_numpy()"""
+    rng = np.random.default_rng(20240901)
+    nl = pd.liquid_count
+    pos = pd.pos.to_numpy()
+    pos[:nl] += rng.uniform(-0.2, 0.2, (nl, 3)).astype(np.float32) * np.float32(ref.particleRadius)
+    pd.pos.from_numpy(pos)
+    x, y, z = (pos[:nl, k].astype(np.float64) for k in range(3))
+    vel = 0.5 * np.stack([np.sin(3.0 * y), np.cos(2.0 * x + z) - 0.3, np.sin(x - 2.0 * z)], 1)
+    omega = 0.2 * np.stack([np.cos(4.0 * z), np.sin(3.0 * x), np.cos(2.0 * y + x)], 1)
+    pd.vel.from_numpy(vel.astype(np.float32))
+    pd.omega.from_numpy(omega.astype(np.float32))
+    pd.tension_coff, pd.tension_coff_b = 0.05, 0.05
+    out["vel0"], out["omega0"] = pd.vel.to_numpy(), pd.omega.to_numpy()
+    out["tension_coff"], out["tension_coff_b"] = np.float32(0.05), np.float32(0.05)
+
+
+def run_dfsph(steps, perturbed=False):
     os.chdir(REF)                       # the script opens model/box_boundry.obj and MCData.txt by relative path
     import taichi as ti
     t0 = time.time()
     import dfsph as ref                 # builds the scene, reset_param()
     pd = ref.particle_data
     _name_fields(ti, ref, pd, pd.hash_grid)
-    out = {"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
-           "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()}
+    out = {}
+    if perturbed:
+        perturb(ref, pd, out)
+    out.update({"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
+           "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()})
     print("scene: %d liquid + %d solid, blockSize %s (%.0f s)" % (pd.liquid_count, pd.solid_count, out["blockSize"], time.time() - t0), flush=True)
 
     def snap(tag, **f):
@@ -112,8 +139,8 @@ def run_sesph(steps):
 
 if __name__ == "__main__":
     which = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else (2 if which == "dfsph" else 1)
-    res = run_dfsph(steps) if which == "dfsph" else run_sesph(steps)
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else (2 if which.startswith("dfsph") else 1)
+    res = run_dfsph(steps, which == "dfsph_perturbed") if which.startswith("dfsph") else run_sesph(steps)
     path = os.path.join(HERE, "ref_%s_default_scene.npz" % which)
     np.savez_compressed(path, **res)
     print("wrote", path, os.path.getsize(path), "bytes")

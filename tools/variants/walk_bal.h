@@ -1,6 +1,10 @@
 // tools/variants/walk_bal.h -- EXPERIMENT, not part of the product build (profiles/r03b_balanced_walk_experiment.md).
 // The "segmented" form of the neighbour walk asked for by VERDICT r02 item 4: a lane walks only the part of its list that
 // 3/4 of its wave shares, the rest becomes work items of the whole workgroup (LDS map + LDS accumulators).
+// Needs ANCHORED stream blocks (every block's first delta relative to i / nhead[i].y instead of the previous block's last
+// entry: NbWriter::entry resets `run` at block boundaries, the decoders likewise) and a walk_range() that takes slot ranges;
+// both are in the same commit.  Anchoring alone costs the developed flow ~4 % (+4 hop slots per block that starts in another
+// outer tile plane, 128 k particles away once the liquid covers the floor).
 // Parity-green (61 GPU tests) and slower than the plain walk in both states; kept so that the measurement can be repeated:
 // paste below walk() in wcsph_amd/csrc/device.h and switch k_vel_from_k / k_drho_press / k_drho_div to it (the kernel
 // side of the experiment is in git history: commit "walk_bal experiment").

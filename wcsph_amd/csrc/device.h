@@ -312,20 +312,17 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
 // needs 4 bytes, its delta 2: the index stream is what a pass reads most of (tools/ablate.py), so this halves the
 // HBM traffic of every neighbour pass.  Deltas that do not fit (the jump to the neighbouring outer tile plane of a
 // large grid) are bridged by HOP slots, +-32767, which move the running index but are not entries.  Eight slots form one
-// 16-byte block; block b of particle i sits at [b * nbr_stride + i], so a wave loads 1 KB contiguous per trip.  The first
-// delta of every BLOCK is relative to the stream's anchor (i / nhead[i].y), see NbWriter.
+// 16-byte block; block b of particle i sits at [b * nbr_stride + i], so a wave loads 1 KB contiguous per trip.
 #define NB_HOP 32767
 #define NB_IS_ENTRY(dd) ((unsigned)((dd) + (NB_HOP - 1)) <= (unsigned)(2 * NB_HOP - 2))   // |dd| < NB_HOP
 
-// builder side: shift register of eight slots, flushed as whole blocks.  Every block is ANCHORED: its first delta is taken
-// from the stream's anchor (i for the liquid stream, the first solid entry for the solid stream), not from the last
-// entry of the previous block, so a block can be decoded on its own -- by any lane, in any order (walk_bal's tail).
+// builder side: shift register of eight slots, flushed as whole blocks
 struct NbWriter {
   uint4 *base;        // &stream[i]
   size_t stride;
-  int run, anchor, slots, cap;
+  int run, slots, cap;
   unsigned w0, w1, w2, w3;
-  __device__ __forceinline__ void init(uint4 *b, size_t st, int start, int cap_) { base = b; stride = st; run = anchor = start; slots = 0; cap = cap_; w0 = w1 = w2 = w3 = 0; }
+  __device__ __forceinline__ void init(uint4 *b, size_t st, int start, int cap_) { base = b; stride = st; run = start; slots = 0; cap = cap_; w0 = w1 = w2 = w3 = 0; }
   __device__ __forceinline__ void slot(int dd) {
     w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
     w2 = __builtin_amdgcn_alignbit(w3, w2, 16); w3 = (w3 >> 16) | ((unsigned)dd << 16);
@@ -333,13 +330,11 @@ struct NbWriter {
     if ((slots & 7) == 0 && slots <= cap) base[(size_t)((slots >> 3) - 1) * stride] = make_uint4(w0, w1, w2, w3);
   }
   __device__ __forceinline__ void entry(int j) {
-    for (;;) {
-      if ((slots & 7) == 0) run = anchor;   // a new block starts from the anchor
-      const int dd = j - run;
-      if (dd >= NB_HOP) { slot(NB_HOP); run += NB_HOP; }
-      else if (dd <= -NB_HOP) { slot(-NB_HOP); run -= NB_HOP; }
-      else { slot(dd); run = j; return; }
-    }
+    int dd = j - run;
+    while (dd >= NB_HOP) { slot(NB_HOP); dd -= NB_HOP; }
+    while (dd <= -NB_HOP) { slot(-NB_HOP); dd += NB_HOP; }
+    slot(dd);
+    run = j;
   }
   // pads the last block with zero deltas (valid indices, masked by the slot count); returns the slot count
   __device__ __forceinline__ int finish() {
@@ -390,11 +385,13 @@ __device__ __forceinline__ uint4 nb_stream(const uint4 *p) {
 // NT: the stream is loaded non-temporally.  For passes that run once per step it keeps the stream from displacing the
 // gather records in L2 / Infinity Cache; the solver-loop passes leave it off, because the velocity pass and the
 // density-change pass of an iteration read the SAME 180 MB stream 50 us apart and the second finds it cached.
-// walk_range: the liquid slots [kl0, kl1) and the solid slots [ks0, ks1) of particle i's streams (kl0, ks0 multiples of 8)
-template <int U, bool NT, class GL, class FL, class FS>
-__device__ __forceinline__ void walk_range(const Dev &d, int i, float3 xi, const float4 *P, int sbase, int kl0, int cl, int ks0, int cs, GL &&gl, FL &&fl, FS &&fs) {
+template <int U, bool NT = false, class GL, class FL, class FS>
+__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
   static_assert(U == 4 || U == 8, "U slots per trip");
+  const float3 xi = xyz(pi);
   const size_t st = (size_t)d.nbr_stride;
+  const int2 head = d.nhead[i];
+  const int cl = head.x & 0xffff, cs = (int)((unsigned)head.x >> 16);
   const uint4 *L = d.nbl + i;
   int run = i;
   // scalars, not indexed arrays: keeps the indices in VGPRs (an int j[U] lands in scratch here)
@@ -402,13 +399,14 @@ __device__ __forceinline__ void walk_range(const Dev &d, int i, float3 xi, const
 #define WALK_OK(u, dd) const bool ok##u = (k + u < cl) & NB_IS_ENTRY(dd);   /* a lane mask in SGPRs: the deltas die here */
   // the stream block of the NEXT trip is requested before this trip's gathers go out: its (HBM) latency hides behind
   // the gathers and the arithmetic instead of heading the next trip's dependency chain
-  uint4 en = cl > kl0 ? nb_stream<NT>(L + (size_t)(kl0 >> 3) * st) : make_uint4(0, 0, 0, 0);
-  for (int k = kl0; k < cl; k += U) {
+  uint4 en = cl > 0 ? nb_stream<NT>(L) : make_uint4(0, 0, 0, 0);
+  for (int k = 0; k < cl; k += U) {
     if (U == 8) {
       const uint4 e = en;
       if (k + 8 < cl) en = nb_stream<NT>(L + (size_t)((k >> 3) + 1) * st);
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
-      const int j0 = i + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;   // anchored block
+      const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
+      run = j7;
       WALK_OK(0, d0) WALK_OK(1, d1) WALK_OK(2, d2) WALK_OK(3, d3) WALK_OK(4, d4) WALK_OK(5, d5) WALK_OK(6, d6) WALK_OK(7, d7)
       float4 p0 = nb_ld(P, j0);
       const float4 p1 = nb_ld(P, j1), p2 = nb_ld(P, j2), p3 = nb_ld(P, j3);
@@ -421,7 +419,6 @@ __device__ __forceinline__ void walk_range(const Dev &d, int i, float3 xi, const
     } else {
       const uint2 e = (k & 4) ? make_uint2(en.z, en.w) : make_uint2(en.x, en.y);   // k is wave-uniform
       if ((k & 4) && k + 4 < cl) en = nb_stream<NT>(L + (size_t)((k >> 3) + 1) * st);
-      if (!(k & 4)) run = i;                                                       // anchored block
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3;
       run = j3;
@@ -436,11 +433,13 @@ __device__ __forceinline__ void walk_range(const Dev &d, int i, float3 xi, const
 #undef WALK_ONE
 #undef WALK_OK
   const uint4 *S = d.nbs + i;
+  run = head.y;
 #define WALK_SOL(u, dd, jj, pp) if (k + u < cs && NB_IS_ENTRY(dd)) { const float3 r = xi - xyz(pp); fs(jj, r, dot3(r, r)); }
-  for (int k = ks0; k < cs; k += 8) {
+  for (int k = 0; k < cs; k += 8) {
     const uint4 e = nb_stream<NT>(S + (size_t)(k >> 3) * st);
     const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
-    const int j0 = sbase + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;   // anchored block
+    const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
+    run = j7;
     float4 p0 = nb_ld(d.spos, j0);
     const float4 p1 = nb_ld(d.spos, j1), p2 = nb_ld(d.spos, j2), p3 = nb_ld(d.spos, j3), p4 = nb_ld(d.spos, j4), p5 = nb_ld(d.spos, j5), p6 = nb_ld(d.spos, j6), p7 = nb_ld(d.spos, j7);
     nb_pin(p0);
@@ -448,10 +447,4 @@ __device__ __forceinline__ void walk_range(const Dev &d, int i, float3 xi, const
     WALK_SOL(4, d4, j4, p4) WALK_SOL(5, d5, j5, p5) WALK_SOL(6, d6, j6, p6) WALK_SOL(7, d7, j7, p7)
   }
 #undef WALK_SOL
-}
-
-template <int U, bool NT = false, class GL, class FL, class FS>
-__device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
-  const int2 head = d.nhead[i];
-  walk_range<U, NT>(d, i, xyz(pi), P, head.y, 0, head.x & 0xffff, 0, (int)((unsigned)head.x >> 16), gl, fl, fs);
 }

@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   walk_cells(d, i, pi, liquid_too != 0,
              [&](int j, float3, float, float m) { for (int rep = (int)m; rep > 0; rep--) wl.entry(j); },
              [&](int j, float3, float, float m) {
-               if (sbase < 0) { sbase = j; ws.run = ws.anchor = j; }
+               if (sbase < 0) { sbase = j; ws.run = j; }
                for (int rep = (int)m; rep > 0; rep--) ws.entry(j);
              });
   int cl = liquid_too ? wl.finish() : (head.x & 0xffff), cs = ws.finish();

@@ -1509,7 +1509,6 @@ __global__ void k_compact_lists(Dev d, int i0, int n, int cap, int *counts, int 
   int w = 0, hops = 0, run = i;
   for (int k = 0; k < cl; k++) {
     const int dd = (int)(short)L[(size_t)(k >> 3) * st * 8 + (k & 7)];
-    if ((k & 7) == 0) run = i;          // every block is anchored (device.h NbWriter)
     run += dd;
     if (!NB_IS_ENTRY(dd)) { hops++; continue; }
     if (w < cap) row[w] = d.oid[run];
@@ -1519,7 +1518,6 @@ __global__ void k_compact_lists(Dev d, int i0, int n, int cap, int *counts, int 
   run = head.y;
   for (int k = 0; k < cs; k++) {
     const int dd = (int)(short)S[(size_t)(k >> 3) * st * 8 + (k & 7)];
-    if ((k & 7) == 0) run = head.y;
     run += dd;
     if (!NB_IS_ENTRY(dd)) { hops++; continue; }
     if (w < cap) row[w] = d.nl + __float_as_int(d.spos[run].w);
