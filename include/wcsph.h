@@ -344,6 +344,41 @@ int wcsph_set_acc_buffer(wcsph_ctx *ctx, void *device_doubles);
  * not cleared again).  Elementwise phases ignore it. */
 int wcsph_set_part(wcsph_ctx *ctx, int32_t mode, int32_t x_lo, int32_t x_hi);
 
+/* ---- the whole DFSPH step of one slab in ONE call (wcsph_comm_init / wcsph_halo_exchange) -----------------
+ * The choreography of the reference main-loop body (dfsph.py:606-617) on a slab -- every phase, the halo refresh of
+ * exactly the field the next phase reads from neighbours j, the overlap of that refresh with the slab interior, the
+ * solver loops and their stopping rules (dfsph.py:95-99, 141-144, 160-163), the dt rule (:116-129) -- runs in the
+ * library; the COMMUNICATOR stays the caller's: at every exchange point the library calls back.  A callback returns 0 or
+ * a negative error code (which wcsph_slab_step returns).  All device work of the callbacks must be ordered on the
+ * context's stream (wcsph_set_stream), as the library's own launches are.
+ *   halo_buffers(user, W, &send, &recv): device buffers for rows of W floats: send [n_send][W], recv [n_ghost][W]
+ *   halo_post(user, W):  send holds rows send_idx of the fields being refreshed: post the sends / receives (no wait)
+ *   halo_wait(user):     return when recv holds the neighbours' rows (as far as the stream is concerned)
+ *   allreduce_acc(user, slot): SUM over ranks of the 64 stripes of reduction slot `slot`, in place in the buffer given to
+ *                        wcsph_set_acc_buffer() (kernels launched next read the global total)
+ *   allreduce_max(user, &v): MAX over ranks of a host double (the CFL velocity maximum, dfsph.py:113-114)
+ *   allreduce_words(user, d_words, n): SUM over ranks of n int32 words on the device (the packed bucket histogram)
+ * world <= 1 or cb == NULL: no callback is made (one slab = the whole domain). */
+typedef struct wcsph_slab_callbacks {
+  void *user;
+  int32_t world;
+  int (*halo_buffers)(void *user, int32_t W, void **d_send, void **d_recv);
+  int (*halo_post)(void *user, int32_t W);
+  int (*halo_wait)(void *user);
+  int (*allreduce_acc)(void *user, int32_t slot);
+  int (*allreduce_max)(void *user, double *v);
+  int (*allreduce_words)(void *user, void *d_words, int64_t n);
+} wcsph_slab_callbacks;
+/* the rows this rank sends (original indices of OWNED rows, left neighbour's first) and the ghost rows it receives into,
+ * both device int32 arrays that stay valid until the next call; after every wcsph_load_state*() */
+int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_send, const int32_t *d_ghost_idx, int32_t n_ghost);
+/* n_global: liquid particles of ALL slabs (error thresholds are per global particle, dfsph.py:143, 162);
+ * interior [x_lo, x_hi): global cell columns whose particles have no ghost within reach (wcsph_set_part);
+ * flags: bit 0 = overlap halo refreshes with the interior, bit 1 = surface tension passes on.
+ * Afterwards: wcsph_get_scalar(DELTA_T), wcsph_get_iters(), stats[0] = halo exchanges, stats[1] = host waits of this step. */
+int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
+                    int32_t flags, int32_t stats[2]);
+
 /* gather / scatter `n` rows of a field by ORIGINAL liquid indices (device int32 array) into / from a
  * packed device buffer (rows of 3 f32 for vec3 fields, 1 f32 for scalar fields) for halo exchange */
 int wcsph_field_gather_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, void *d_dst);

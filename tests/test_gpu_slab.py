@@ -155,3 +155,29 @@ def test_overlapped_halo_exchange_changes_nothing(tmp_path):
     liquid, solid, bounds = slab_util.test_scene(n)
     cuts, _ = slab_util.split_scene(liquid, bounds, 2)
     assert cuts[1] - cuts[0] > 4 and cuts[2] - cuts[1] > 4
+
+
+@pytest.mark.parametrize("mode", ["clean", "faithful"])
+def test_native_slab_step_equals_the_python_phase_driver(tmp_path, mode):
+    """wcsph_slab_step (the whole choreography inside the library, the communicator reached through callbacks) against
+    SlabSim._step's phase-by-phase Python form (WCSPH_SLAB_NATIVE=0), two ranks: same launches in the same order, so the
+    same iteration counts, dt history and -- up to the order of the atomics -- the same rows."""
+    import slab_util
+    from test_slab_gloo import _free_port
+    n, outs = 10, []
+    os.environ["SLAB_TEST_MODE"] = mode
+    try:
+        for native in ("1", "0"):
+            out = os.path.join(str(tmp_path), "native" + native)
+            os.makedirs(out)
+            os.environ["WCSPH_SLAB_NATIVE"] = native
+            mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+            outs.append(out)
+    finally:
+        os.environ.pop("WCSPH_SLAB_NATIVE", None); os.environ.pop("SLAB_TEST_MODE", None)
+    rows = [np.concatenate([np.load(os.path.join(o, "hrows_w2_r%d.npy" % r)) for r in range(2)]) for o in outs]
+    logs = [np.load(os.path.join(o, "hlog_w2_r0.npy")) for o in outs]
+    np.testing.assert_array_equal(logs[0][:, :3], logs[1][:, :3])
+    np.testing.assert_allclose(logs[0][:, 3], logs[1][:, 3], rtol=1e-7)
+    dpos, dvel, _ = slab_util.match_rows(rows[0], rows[1])
+    assert dpos < 1e-6 and dvel < 1e-4

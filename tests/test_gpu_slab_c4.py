@@ -53,18 +53,25 @@ def _rank(rank, world, port, outdir, n):
                   comm_device=torch.device("cpu"), neighbor_mode="faithful", gid_local=gid, capacity_factor=1.8)
     del liquid
     log = []
+    trace = open(os.path.join(os.environ["C4_TRACE"], "trace_r%d.txt" % rank), "w") if os.environ.get("C4_TRACE") else None
     for k in range(STEPS):
-        if k == REBALANCE_AT:
+        if trace:
+            torch.cuda.synchronize(); trace.write("step %d begins (owned %d)\n" % (k, sim.n_owned if hasattr(sim, "n_owned") else -1)); trace.flush()
+        if k == REBALANCE_AT and not os.environ.get("C4_NO_REBALANCE"):
             owned_before = sim.n_owned
             assert sim.rebalance(force=True)
             assert sim.cuts == list(cuts0), (sim.cuts, cuts0)     # the lattice has barely moved: back to the balanced cuts
+            if trace:
+                torch.cuda.synchronize(); trace.write("rebalanced\n"); trace.flush()
         sim.step()
         log.append((sim.vs_iter, sim.dv_iter, sim.pr_iter, float(sim.dt), sim.n_owned))
     torch.cuda.synchronize()
-    assert sim.n_rebalanced == 1 and sim.n_owned != owned_before
+    if trace:
+        trace.write("steps done\n"); trace.flush()
+    assert os.environ.get("C4_NO_REBALANCE") or (sim.n_rebalanced == 1 and sim.n_owned != owned_before)
     rows = sim.rows
-    idx = torch.arange(sim.n_owned, dtype=torch.int32, device=dev)
-    with torch.cuda.stream(sim.stream):
+    with torch.cuda.stream(sim.stream):       # the index list must be written on the stream that reads it
+        idx = torch.arange(sim.n_owned, dtype=torch.int32, device=dev)
         rho = sim.B.gather_rows("rho", idx)
     torch.cuda.synchronize()
     out = np.concatenate([rows[:, 0:6].cpu().numpy(), rho.cpu().numpy(), rows[:, 14:15].cpu().numpy()], 1)   # pos vel rho gid

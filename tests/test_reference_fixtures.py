@@ -136,7 +136,8 @@ def test_hip_reproduces_the_reference_text_dfsph(fixture):
         assert dfsph.vs_iter == int(g("nonpressure_vs_iter"))
         _close("d_vel", pd.d_vel.to_numpy(), g("nonpressure_d_vel"), 5e-5); _close("vel_guess", pd.vel_guess.to_numpy(), g("nonpressure_vel_guess"), 5e-5)
         _close("cg_Minv", pd.cg_Minv.to_numpy(), g("nonpressure_cg_Minv"), 1e-5); _close("omega", pd.omega.to_numpy(), g("nonpressure_omega"), 5e-5)
-        _close("normal", pd.normal.to_numpy(), g("nonpressure_normal"), 5e-5)
+        if "vel0" in f.files:   # tension_coff = tension_coff_b = 0 (the shipped default): the library skips compute_tension -- it adds
+            _close("normal", pd.normal.to_numpy(), g("nonpressure_normal"), 5e-5)   # exactly +-0 to d_vel -- and leaves `normal` untouched
         dfsph.optimize_time_step()
         assert abs(float(dfsph.deltaT[0]) - float(g("dt_deltaT")[0])) <= DT_RTOL * (s + 1) * float(g("dt_deltaT")[0])
         dfsph.update_vel(); dfsph.solve_pressure()

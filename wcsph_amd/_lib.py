@@ -74,8 +74,22 @@ OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_c
          "wcsph_surface_anisotropic_kernel", "wcsph_dfsph_step_fixed", "wcsph_sample_surface", "wcsph_mc_tables",
          "wcsph_mc_setup", "wcsph_mc_surface_value", "wcsph_mc_value_to_host", "wcsph_mc_marching_cube", "wcsph_canvas_draw",
          "wcsph_set_owned_columns", "wcsph_set_global_liquid", "wcsph_grid_update_begin", "wcsph_grid_update_end", "wcsph_bucket_hist", "wcsph_bucket_hist_pack", "wcsph_bucket_hist_unpack",
-         "wcsph_halo_pack", "wcsph_halo_unpack", "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
+         "wcsph_halo_pack", "wcsph_halo_unpack", "wcsph_slab_set_halo", "wcsph_slab_step", "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
 ALL_SYMBOLS = CTX_ONLY + OTHER
+
+# include/wcsph.h: wcsph_slab_callbacks (the caller's communicator behind wcsph_slab_step)
+CB_BUFFERS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
+CB_POST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)
+CB_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p)
+CB_ACC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)
+CB_MAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+CB_WORDS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class SlabCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("world", C.c_int32), ("halo_buffers", CB_BUFFERS), ("halo_post", CB_POST),
+                ("halo_wait", CB_WAIT), ("allreduce_acc", CB_ACC), ("allreduce_max", CB_MAX), ("allreduce_words", CB_WORDS)]
+
 
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
           "WARM_PRESS_SCALE", "WARM_PRESS_VEL", "DRHO_PRESS_BEGIN", "MAKE_K_PRESS", "DRHO_PRESS_ITER", "END_PRESS", "CLEAR",
@@ -117,6 +131,8 @@ def load():
     lib.wcsph_neighbors_to_host.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     lib.wcsph_compact_lists_to_host.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     lib.wcsph_list_stats.argtypes = [vp, vp]
+    lib.wcsph_slab_set_halo.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
+    lib.wcsph_slab_step.argtypes = [vp, C.POINTER(SlabCallbacks), C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32 * 2)]
     lib.wcsph_time_kernel.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_float)]
     lib.wcsph_field_gather_rows.argtypes = [vp, C.c_int, vp, C.c_int32, vp]
     lib.wcsph_field_scatter_rows.argtypes = [vp, C.c_int, vp, C.c_int32, vp]

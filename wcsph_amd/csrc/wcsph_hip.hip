@@ -71,6 +71,7 @@ struct wcsph_ctx {
   int vs_iter = 0, dv_iter = 0, pr_iter = 0;
   int fix_dv = 0, fix_pr = 0, fix_vs = 0;  // > 0: run exactly that many iterations (wcsph_dfsph_step_fixed)
   int bs[3] = {0, 0, 0};
+  const int *halo_send = nullptr, *halo_ghost = nullptr; int n_halo_send = 0, n_halo_ghost = 0;   // wcsph_slab_set_halo
   int win_x0 = 0, win_x1 = -1;  // cell-x window (slab decomposition); x1 < 0 => whole box
   int capacity = 0;
   double grid_r = 0.0;
@@ -1734,6 +1735,163 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
   }
   return WCSPH_OK;
 }
+
+// ---- the slab step in one call (include/wcsph.h "the whole DFSPH step of one slab") ----------------------------------
+int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_send, const int32_t *d_ghost_idx, int32_t n_ghost) {
+  NEED_SETUP();
+  if (n_send < 0 || n_ghost < 0 || (n_send > 0 && !d_send_idx) || (n_ghost > 0 && !d_ghost_idx)) return WCSPH_EARG;
+  ctx->halo_send = d_send_idx; ctx->n_halo_send = n_send; ctx->halo_ghost = d_ghost_idx; ctx->n_halo_ghost = n_ghost;
+  return WCSPH_OK;
+}
+namespace {
+struct SlabRun {
+  wcsph_ctx *ctx;
+  const wcsph_slab_callbacks *cb;
+  bool multi, overlap;
+  int ilo, ihi, n_xchg = 0, n_wait = 0;
+  int ph(int p) { return wcsph_phase(ctx, p); }
+  // refresh the ghost rows of `fields`, then run `phase`, which reads them from neighbours j -- overlapped: the phase runs
+  // on the slab interior while the exchange is in flight, on the rest once it has landed (phase < 0: exchange only)
+  int xp(std::initializer_list<int32_t> fields, int phase) {
+    int rc;
+    if (!multi) return phase >= 0 ? ph(phase) : 0;
+    HaloFields h;
+    std::vector<int32_t> f(fields);
+    if ((rc = halo_fields(ctx, (int)f.size(), f.data(), &h))) return rc;
+    void *snd = nullptr, *rcv = nullptr;
+    if ((rc = cb->halo_buffers(cb->user, h.W, &snd, &rcv))) return ctx->fail(rc, "slab callback halo_buffers failed");
+    if (ctx->n_halo_send > 0) {
+      hipLaunchKernelGGL(k_halo_pack, dim3(nblk(ctx->n_halo_send * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_send, ctx->n_halo_send, (float *)snd);
+      LAUNCHCHK();
+    }
+    if ((rc = cb->halo_post(cb->user, h.W))) return ctx->fail(rc, "slab callback halo_post failed");
+    n_xchg++;
+    const bool split = overlap && phase >= 0;
+    if (split) { ctx->d.part_mode = 1; ctx->d.part_x0 = ilo; ctx->d.part_x1 = ihi > ilo ? ihi : ilo; if ((rc = ph(phase))) return rc; }
+    if ((rc = cb->halo_wait(cb->user))) return ctx->fail(rc, "slab callback halo_wait failed");
+    if (ctx->n_halo_ghost > 0) {
+      hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
+      LAUNCHCHK();
+      ctx->pr_valid = false;
+    }
+    if (phase < 0) return 0;
+    if (split) ctx->d.part_mode = 2;
+    rc = ph(phase);
+    ctx->d.part_mode = 0;
+    return rc;
+  }
+  // global total of a reduction slot: the stripes are all-reduced in place on the device; the host value costs one wait
+  int reduce(int slot, bool fetch, double *v) {
+    int rc;
+    if (multi && (rc = cb->allreduce_acc(cb->user, slot))) return ctx->fail(rc, "slab callback allreduce_acc failed");
+    if (!fetch) return 0;
+    if ((rc = pull_scalars(ctx))) return rc;
+    n_wait++;
+    *v = ctx->h_acc[slot];
+    return 0;
+  }
+};
+}  // namespace
+#define SRC(x) do { if ((rc = (x))) { ctx->d.part_mode = 0; return rc; } } while (0)
+int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
+                    int32_t flags, int32_t stats[2]) {
+  NEED_SETUP();
+  if (n_global < 1) return WCSPH_EARG;
+  SlabRun R{ctx, cb, cb && cb->world > 1, (flags & 1) != 0 && cb && cb->world > 1, interior_lo, interior_hi};
+  if (R.multi && (!cb->halo_buffers || !cb->halo_post || !cb->halo_wait || !cb->allreduce_acc || !cb->allreduce_max || !cb->allreduce_words)) return WCSPH_EARG;
+  int rc;
+  const double N = (double)n_global;
+  double v = 0.0;
+  // particle_data.hash_grid.update_grid(): with the reference's GLOBAL bucket table in faithful mode (HashGrid.py:108-114)
+  if (ctx->d.faithful && R.multi) {
+    void *words = nullptr; int64_t nw = 0;
+    SRC(wcsph_grid_update_begin(ctx));
+    SRC(wcsph_bucket_hist_pack(ctx, &words, &nw));
+    if ((rc = cb->allreduce_words(cb->user, words, nw))) return ctx->fail(rc, "slab callback allreduce_words failed");
+    SRC(wcsph_bucket_hist_unpack(ctx));
+    SRC(wcsph_grid_update_end(ctx));
+  } else SRC(wcsph_grid_update(ctx));
+  // compute_density(); compute_dfsph_coff(); solve_vel_divergence() (dfsph.py:131-146)
+  ctx->dv_iter = 0;
+  SRC(R.ph(WCSPH_PH_DENSITY_COFF_WARM));
+  SRC(R.xp({WCSPH_F_RHO, WCSPH_F_KAPPA_V}, WCSPH_PH_VEL_WARM));
+  double err = -0.1;
+  SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_DIV_BEGIN));
+  float dt = ctx->dt;
+  while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
+    SRC(R.ph(WCSPH_PH_MAKE_K_DIV));
+    SRC(R.xp({WCSPH_F_KBUF}, WCSPH_PH_VEL_ITER));
+    SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_DIV_ITER));
+    SRC(R.reduce(ACC_ERR, true, &v));
+    ctx->avg_density_err = (float)v;
+    err = 0.001 * N / (double)dt;
+    ctx->dv_iter++;
+  }
+  // compute_nonpressure_force() (dfsph.py:84-103)
+  SRC(R.ph(WCSPH_PH_END_DIV_BEGIN_NONPRESSURE));
+  if (flags & 2) { SRC(R.ph(WCSPH_PH_TENSION_NORMAL)); SRC(R.xp({WCSPH_F_NORMAL}, -1)); SRC(R.ph(WCSPH_PH_TENSION_ACCEL)); }
+  SRC(R.xp({WCSPH_F_VEL_GUESS}, WCSPH_PH_VISC_MINV_RESIDUAL_VORT));
+  SRC(R.reduce(ACC_DZERO, true, &v));
+  ctx->cg_delta_zero = (float)v;
+  ctx->cg_delta = ctx->cg_delta_zero;
+  ctx->vs_iter = 0;
+  while (ctx->vs_iter < 100) {
+    SRC(R.xp({WCSPH_F_CG_DIR}, WCSPH_PH_VISC_AD));
+    SRC(R.reduce(ACC_DAD, false, nullptr));        // k_visc_update reads the global dAd on the device
+    SRC(R.ph(WCSPH_PH_VISC_UPDATE));               // alpha = cg_delta / dAd (the delta this iteration started with)
+    SRC(R.reduce(ACC_DNEW, true, &v));             // k_visc_dir reads the global delta' on the device
+    const float delta_start = ctx->cg_delta;
+    ctx->cg_delta_old = delta_start;
+    ctx->cg_delta = (float)v;
+    ctx->vs_iter++;
+    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero || (double)ctx->cg_delta_zero < (double)ctx->p.eps) break;
+    ctx->cg_delta = delta_start;                   // beta = delta' / delta_old
+    rc = R.ph(WCSPH_PH_VISC_DIR);
+    ctx->cg_delta = (float)v;
+    if (rc) return rc;
+  }
+  SRC(R.ph(WCSPH_PH_VISC_END));
+  SRC(R.ph(WCSPH_PH_VORTICITY_INT));
+  // optimize_time_step() (dfsph.py:107-129) on the GLOBAL velocity maximum
+  SRC(wcsph_dfsph_cfl_reduce(ctx));
+  R.n_wait++;
+  double vmax = (double)ctx->vel_max0;
+  if (R.multi && (rc = cb->allreduce_max(cb->user, &vmax))) return ctx->fail(rc, "slab callback allreduce_max failed");
+  if ((float)vmax > ctx->p.eps) {
+    double time_step = 0.5 * 0.4 * ctx->p.cfl_radius * 2.0 / sqrt((double)(float)vmax);
+    if (time_step > ctx->p.user_max_t) time_step = ctx->p.user_max_t;
+    if (time_step < ctx->p.user_min_t) time_step = ctx->p.user_min_t;
+    const int it = ctx->vs_iter > ctx->pr_iter ? ctx->vs_iter : ctx->pr_iter;  // max(vs, max(pr, vs)), Q6
+    float d2 = ctx->dt;
+    if (it > 10) d2 = (float)((double)d2 * 0.9);
+    else if (it < 5) d2 = (float)((double)d2 * 1.1);
+    if ((double)d2 > time_step) d2 = (float)time_step;
+    ctx->dt = d2;
+  }
+  // update_vel(); solve_pressure() (dfsph.py:150-164; the warm start is a no-op in the reference, Q7)
+  SRC(R.ph(WCSPH_PH_UPDATE_VEL_WARM_SCALE));
+  SRC(R.ph(WCSPH_PH_WARM_PRESS_VEL));
+  ctx->pr_iter = 0;
+  err = 0.0;
+  SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_PRESS_BEGIN));
+  while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
+    const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
+    if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
+    SRC(R.ph(WCSPH_PH_MAKE_K_PRESS));
+    SRC(R.xp({WCSPH_F_KBUF}, WCSPH_PH_VEL_ITER));
+    SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_PRESS_ITER));
+    if (prof) { HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream)); ctx->prof_used += 2; }
+    ctx->pr_iter++;
+    if (ctx->pr_iter < 2) { err = 1.0; continue; }   // `pr_iter < 2` forces the second iteration whatever the first reports
+    SRC(R.reduce(ACC_ERR, true, &v));
+    ctx->avg_density_err = (float)v;
+    err = (double)ctx->avg_density_err / N;
+  }
+  SRC(R.ph(WCSPH_PH_END_PRESS_UPDATE_POS));
+  if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; }
+  return WCSPH_OK;
+}
+#undef SRC
 
 // ---- boundary sampler --------------------------------------------------------------------------------
 int wcsph_sample_surface(const float *tri_xyz, int32_t n_tri, double R, uint32_t seed, int32_t trials,

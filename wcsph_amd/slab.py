@@ -186,6 +186,34 @@ class HipBackend:
     def sync(self):
         self._chk(self.lib.wcsph_sync(self.ctx))
 
+    # ---- the whole step in one library call (include/wcsph.h wcsph_slab_step) --------------------------------------
+    def native_step(self, sim):
+        """The choreography of SlabSim._step inside the library; `sim` supplies the communicator through callbacks.
+        Returns (dt, vs_iter, dv_iter, pr_iter, avg_density_err)."""
+        lib, ctx = self.lib, self.ctx
+        if getattr(self, "_cbs_for", None) is not sim:
+            self._cbs, self._cbs_for = sim._make_callbacks(), sim
+        self._chk(lib.wcsph_slab_set_halo(ctx, C.c_void_p(sim.send_all.data_ptr()), int(sim.send_all.numel()),
+                                          C.c_void_p(sim.ghost_all.data_ptr()), int(sim.ghost_all.numel())))
+        self._chk(lib.wcsph_set_scalar(ctx, _lib.SCALAR_ID["deltaT"], float(sim.dt)))
+        self._chk(lib.wcsph_set_scalar(ctx, _lib.SCALAR_ID["avg_density_err"], float(sim.avg_density_err)))
+        self._chk(lib.wcsph_set_iters(ctx, int(sim.vs_iter), int(sim.dv_iter), int(sim.pr_iter)))
+        stats = (C.c_int32 * 2)()
+        flags = (1 if sim.overlap else 0) | (2 if sim.tension else 0)
+        sim._cb_exc = None
+        rc = lib.wcsph_slab_step(ctx, C.byref(self._cbs), int(sim.n_global), int(max(sim.interior[0], -(1 << 30))),
+                                 int(min(sim.interior[1], 1 << 30)), flags, C.byref(stats))
+        if sim._cb_exc is not None:
+            raise sim._cb_exc
+        self._chk(rc)
+        sim.n_exchanges += stats[0]; sim.n_host_waits += stats[1]
+        dt, err = C.c_float(), C.c_float()
+        vs, dv, pr = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(lib.wcsph_get_scalar(ctx, _lib.SCALAR_ID["deltaT"], C.byref(dt)))
+        self._chk(lib.wcsph_get_scalar(ctx, _lib.SCALAR_ID["avg_density_err"], C.byref(err)))
+        self._chk(lib.wcsph_get_iters(ctx, C.byref(vs), C.byref(dv), C.byref(pr)))
+        return np.float32(dt.value), vs.value, dv.value, pr.value, np.float32(err.value)
+
     def close(self):
         self.pd.close()
 
@@ -260,6 +288,10 @@ class SlabSim:
         self.user_max_t, self.user_min_t = 0.005, 0.0001
         self.tension = False
         self.n_exchanges = self.n_host_waits = 0
+        # WCSPH_SLAB_NATIVE=0: drive the step phase by phase from Python (the form the checker backend of the CPU tests
+        # runs, kept in step with wcsph_slab_step by tests/test_gpu_slab.py)
+        self.native = os.environ.get("WCSPH_SLAB_NATIVE", "1") != "0"
+        self._cb_exc = None
 
     def _set_cuts(self, cuts):
         """(re)build this rank's backend for the slab [cuts[rank], cuts[rank+1]): cell window, static boundary particles
@@ -477,6 +509,49 @@ class SlabSim:
             self.n_host_waits += 1
         return B.get_acc(slot) if fetch else None
 
+    def _make_callbacks(self):
+        """ctypes callbacks behind wcsph_slab_step: this rank's side of the communicator (torch.distributed)"""
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except BaseException as e:   # never let an exception unwind through the C frames
+                    self._cb_exc = e
+                    return -2
+            return run
+
+        def buffers(_u, W, p_send, p_recv):
+            out, inc = self._halo_buffers(int(W))
+            self._cb_buf = (out, inc)
+            p_send[0], p_recv[0] = out.data_ptr(), inc.data_ptr()
+
+        def post(_u, W):
+            out, inc = self._cb_buf
+            nl, ngl = self.send_l.numel(), self.ghost_l.numel()
+            self._cb_pending = self._post(out[:nl], out[nl:], inc[:ngl], inc[ngl:])
+
+        def wait(_u):
+            self._complete(self._cb_pending)
+            self._cb_pending = None
+
+        def acc(_u, slot):
+            self._allreduce_tensor(self.B.acc[slot * _lib.ACC_STRIPES:(slot + 1) * _lib.ACC_STRIPES])
+
+        def vmax(_u, p):
+            p[0] = self._allreduce(p[0], dist.ReduceOp.MAX)
+            self.n_host_waits -= 1          # counted by the library (the CFL wait)
+
+        def words(_u, ptr, n):
+            self._allreduce_tensor(torch.as_tensor(_DevArray(ptr, n), device=self.device))
+
+        cb = _lib.SlabCallbacks()
+        cb.user, cb.world = None, int(self.world)
+        self._cb_keep = [_lib.CB_BUFFERS(guard(buffers)), _lib.CB_POST(guard(post)), _lib.CB_WAIT(guard(wait)),
+                         _lib.CB_ACC(guard(acc)), _lib.CB_MAX(guard(vmax)), _lib.CB_WORDS(guard(words))]
+        cb.halo_buffers, cb.halo_post, cb.halo_wait, cb.allreduce_acc, cb.allreduce_max, cb.allreduce_words = self._cb_keep
+        return cb
+
     def allsum(self, v): return self._allreduce(v, dist.ReduceOp.SUM)   # noqa: E704
     def allmax(self, v): return self._allreduce(v, dist.ReduceOp.MAX)   # noqa: E704
 
@@ -607,6 +682,12 @@ class SlabSim:
         ACC_ERR, ACC_DAD, ACC_DNEW, ACC_DZERO = _lib.ACC_ERR, _lib.ACC_DAD, _lib.ACC_DNEW, _lib.ACC_DZERO
         N = float(self.n_global)
         self.redistribute()
+        if self.native and hasattr(B, "native_step"):
+            # the rest of the step -- every phase, halo refresh, solver loop and the dt rule below -- runs inside the
+            # library (wcsph_slab_step); this rank's communicator is reached through callbacks
+            self.dt, self.vs_iter, self.dv_iter, self.pr_iter, self.avg_density_err = B.native_step(self)
+            self.rows = B.store_state()
+            return float(self.dt)
         B.set_scalar("deltaT", self.dt)
         if self.neighbor_mode == "faithful" and self.world > 1:
             # particle_data.hash_grid.update_grid() with the reference's GLOBAL bucket table (HashGrid.py:108-114): every
@@ -663,11 +744,13 @@ class SlabSim:
             time_step = max(min(time_step, self.user_max_t), self.user_min_t)
             it = max(self.vs_iter, max(self.pr_iter, self.vs_iter))
             d = self.dt
+            # Python double on the float32 value, rounded once (dfsph.py:124-126 under the NumPy 1.x of the reference's time;
+            # NumPy >= 2 would form the product in float32: one ulp off)
             if it > 10:
-                d = np.float32(d * 0.9)
+                d = np.float32(float(d) * 0.9)
             elif it < 5:
-                d = np.float32(d * 1.1)
-            self.dt = np.float32(min(d, time_step))
+                d = np.float32(float(d) * 1.1)
+            self.dt = np.float32(min(float(d), time_step))
             B.set_scalar("deltaT", self.dt)
         # update_vel + solve_pressure()  (dfsph.py:150-164); the warm start is a no-op in the reference (Q7): its gate
         # adv_rho > rho_L0 never opens, so kappa_j of ghosts is not refreshed for it and it changes no velocity
