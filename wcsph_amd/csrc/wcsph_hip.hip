@@ -1743,21 +1743,33 @@ int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_sen
   ctx->halo_send = d_send_idx; ctx->n_halo_send = n_send; ctx->halo_ghost = d_ghost_idx; ctx->n_halo_ghost = n_ghost;
   return WCSPH_OK;
 }
+}  // extern "C" (templates below)
+// ghost rows' gather records: (pos, 0) -- their payload (.w) arrives with the halo refreshes, their positions do not
+// change during the step
+__global__ void k_ghost_records(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] < d.n_owned) return;
+  const float4 p = d.pos[i];
+  d.pk[i] = make_float4(p.x, p.y, p.z, 0.f);
+  d.pr[i] = make_float4(p.x, p.y, p.z, 0.f);
+}
 namespace {
 struct SlabRun {
   wcsph_ctx *ctx;
   const wcsph_slab_callbacks *cb;
   bool multi, overlap;
   int ilo, ihi, n_xchg = 0, n_wait = 0;
-  int ph(int p) { return wcsph_phase(ctx, p); }
-  // refresh the ghost rows of `fields`, then run `phase`, which reads them from neighbours j -- overlapped: the phase runs
-  // on the slab interior while the exchange is in flight, on the rest once it has landed (phase < 0: exchange only)
-  int xp(std::initializer_list<int32_t> fields, int phase) {
+  HaloFields h;
+  void hf_begin() { h.n = 0; h.W = 0; }
+  void hf_add(const void *ptr, int width, int stride) { h.ptr[h.n] = (const float *)ptr; h.width[h.n] = width; h.stride[h.n] = stride; h.W += width; h.n++; }
+  // refresh the ghost rows of the fields collected in `h`, then run `launch()`, a neighbour pass that reads them from
+  // neighbours j -- overlapped: the pass runs on the slab interior while the exchange is in flight, on the rest once it
+  // has landed.  launch == nullptr-like (no_pass): exchange only.
+  // also: a second set of destinations for the same received columns (rho lands in the field AND in the (pos, rho) records)
+  template <class F>
+  int xp(bool has_pass, F &&launch, const HaloFields *also = nullptr) {
     int rc;
-    if (!multi) return phase >= 0 ? ph(phase) : 0;
-    HaloFields h;
-    std::vector<int32_t> f(fields);
-    if ((rc = halo_fields(ctx, (int)f.size(), f.data(), &h))) return rc;
+    if (!multi) return has_pass ? launch() : 0;
     void *snd = nullptr, *rcv = nullptr;
     if ((rc = cb->halo_buffers(cb->user, h.W, &snd, &rcv))) return ctx->fail(rc, "slab callback halo_buffers failed");
     if (ctx->n_halo_send > 0) {
@@ -1766,44 +1778,45 @@ struct SlabRun {
     }
     if ((rc = cb->halo_post(cb->user, h.W))) return ctx->fail(rc, "slab callback halo_post failed");
     n_xchg++;
-    const bool split = overlap && phase >= 0;
-    if (split) { ctx->d.part_mode = 1; ctx->d.part_x0 = ilo; ctx->d.part_x1 = ihi > ilo ? ihi : ilo; if ((rc = ph(phase))) return rc; }
+    const bool split = overlap && has_pass;
+    if (split) { ctx->d.part_mode = 1; ctx->d.part_x0 = ilo; ctx->d.part_x1 = ihi > ilo ? ihi : ilo; if ((rc = launch())) return rc; }
     if ((rc = cb->halo_wait(cb->user))) return ctx->fail(rc, "slab callback halo_wait failed");
     if (ctx->n_halo_ghost > 0) {
       hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
+      if (also) hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, *also, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
       LAUNCHCHK();
-      ctx->pr_valid = false;
     }
-    if (phase < 0) return 0;
+    if (!has_pass) return 0;
     if (split) ctx->d.part_mode = 2;
-    rc = ph(phase);
+    rc = launch();
     ctx->d.part_mode = 0;
     return rc;
   }
-  // global total of a reduction slot: the stripes are all-reduced in place on the device; the host value costs one wait
-  int reduce(int slot, bool fetch, double *v) {
+  int allreduce(int slot) {   // the stripes of a reduction slot summed over the ranks, in place on the device
     int rc;
     if (multi && (rc = cb->allreduce_acc(cb->user, slot))) return ctx->fail(rc, "slab callback allreduce_acc failed");
-    if (!fetch) return 0;
-    if ((rc = pull_scalars(ctx))) return rc;
-    n_wait++;
-    *v = ctx->h_acc[slot];
     return 0;
   }
+  int fetch() { n_wait++; return pull_scalars(ctx); }   // one host wait: every slot total + the error flags
 };
 }  // namespace
+extern "C" {
 #define SRC(x) do { if ((rc = (x))) { ctx->d.part_mode = 0; return rc; } } while (0)
+#define SPASS_(kern, ...) [&]() -> int { PASS(kern, ##__VA_ARGS__); return 0; }
 int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
                     int32_t flags, int32_t stats[2]) {
   NEED_SETUP();
   if (n_global < 1) return WCSPH_EARG;
   SlabRun R{ctx, cb, cb && cb->world > 1, (flags & 1) != 0 && cb && cb->world > 1, interior_lo, interior_hi};
   if (R.multi && (!cb->halo_buffers || !cb->halo_post || !cb->halo_wait || !cb->allreduce_acc || !cb->allreduce_max || !cb->allreduce_words)) return WCSPH_EARG;
+  Dev &d = ctx->d;
   int rc;
   const double N = (double)n_global;
-  double v = 0.0;
-  // particle_data.hash_grid.update_grid(): with the reference's GLOBAL bucket table in faithful mode (HashGrid.py:108-114)
-  if (ctx->d.faithful && R.multi) {
+  const bool tension = (flags & 2) && !(d.tension == 0.0f && d.tension_b == 0.0f);
+  if (tension && ctx->p.tension_fixed == 0 && R.multi) return ctx->fail(WCSPH_EARG, "the literal compute_tension reads the reference's raw bucket rows, which span all slabs: tension_fixed = 1 on a decomposition");
+  auto no_pass = []() -> int { return 0; };
+  // ---- particle_data.hash_grid.update_grid(): with the reference's GLOBAL bucket table in faithful mode (HashGrid.py:108-114)
+  if (d.faithful && R.multi) {
     void *words = nullptr; int64_t nw = 0;
     SRC(wcsph_grid_update_begin(ctx));
     SRC(wcsph_bucket_hist_pack(ctx, &words, &nw));
@@ -1811,53 +1824,82 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
     SRC(wcsph_bucket_hist_unpack(ctx));
     SRC(wcsph_grid_update_end(ctx));
   } else SRC(wcsph_grid_update(ctx));
-  // compute_density(); compute_dfsph_coff(); solve_vel_divergence() (dfsph.py:131-146)
+  if (d.nl == 0) { if (stats) stats[0] = stats[1] = 0; return WCSPH_OK; }
+  if (d.n_owned < d.nl) ELEM(k_ghost_records);
+  // ---- compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146): they read
+  // pos_j / vel_j only, which the ghost rows brought with them
+  PASS(k_density_coff_warm, ctx->dt);
   ctx->dv_iter = 0;
-  SRC(R.ph(WCSPH_PH_DENSITY_COFF_WARM));
-  SRC(R.xp({WCSPH_F_RHO, WCSPH_F_KAPPA_V}, WCSPH_PH_VEL_WARM));
+  // rho_j (field and gather record) and the rescaled kappa_v_j (the payload of the warm-start velocity pass) in ONE message
+  R.hf_begin(); R.hf_add(d.rho, 1, 1); R.hf_add((const float *)d.pk + 3, 1, 4);
+  {
+    HaloFields also = R.h;                    // column 0 once more: -> pr.w
+    also.ptr[0] = (const float *)d.pr + 3; also.stride[0] = 4;
+    SRC(R.xp(false, no_pass, &also));
+  }
+  ctx->pr_valid = true;                       // (pos, rho) records of every row: own rows by the density pass, ghosts just now
+  SRC(SPASS_(k_vel_from_k<1>, (const float4 *)d.pk, ctx->dt)());      // warm-start velocities (dfsph.py:420-439); ghosts' kappa_v arrived above
   double err = -0.1;
-  SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_DIV_BEGIN));
-  float dt = ctx->dt;
+  const float dt = ctx->dt;
+  R.hf_begin(); R.hf_add(d.vel, 3, 4);
+  SRC(R.xp(true, SPASS_((k_drho_div<DRHO_BEGIN, true>), dt)));
+  const bool vort_div = d.n_owned >= 0;       // the vorticity sums ride on the last divergence iteration (k_drho_div_iter_vort)
   while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
-    SRC(R.ph(WCSPH_PH_MAKE_K_DIV));
-    SRC(R.xp({WCSPH_F_KBUF}, WCSPH_PH_VEL_ITER));
-    SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_DIV_ITER));
-    SRC(R.reduce(ACC_ERR, true, &v));
-    ctx->avg_density_err = (float)v;
+    R.hf_begin(); R.hf_add((const float *)d.pk + 3, 1, 4);           // k_j = b_j alpha_j, written by the density-change pass
+    SRC(R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dt, d.kappa_v)));
+    R.hf_begin(); R.hf_add(d.vel, 3, 4);
+    if (vort_div) SRC(R.xp(true, SPASS_(k_drho_div_iter_vort, dt)));
+    else SRC(R.xp(true, SPASS_((k_drho_div<DRHO_ITER, true>), dt)));
+    SRC(R.allreduce(ACC_ERR));
+    SRC(R.fetch());
+    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
     err = 0.001 * N / (double)dt;
     ctx->dv_iter++;
   }
-  // compute_nonpressure_force() (dfsph.py:84-103)
-  SRC(R.ph(WCSPH_PH_END_DIV_BEGIN_NONPRESSURE));
-  if (flags & 2) { SRC(R.ph(WCSPH_PH_TENSION_NORMAL)); SRC(R.xp({WCSPH_F_NORMAL}, -1)); SRC(R.ph(WCSPH_PH_TENSION_ACCEL)); }
-  SRC(R.xp({WCSPH_F_VEL_GUESS}, WCSPH_PH_VISC_MINV_RESIDUAL_VORT));
-  SRC(R.reduce(ACC_DZERO, true, &v));
-  ctx->cg_delta_zero = (float)v;
-  ctx->cg_delta = ctx->cg_delta_zero;
-  ctx->vs_iter = 0;
-  while (ctx->vs_iter < 100) {
-    SRC(R.xp({WCSPH_F_CG_DIR}, WCSPH_PH_VISC_AD));
-    SRC(R.reduce(ACC_DAD, false, nullptr));        // k_visc_update reads the global dAd on the device
-    SRC(R.ph(WCSPH_PH_VISC_UPDATE));               // alpha = cg_delta / dAd (the delta this iteration started with)
-    SRC(R.reduce(ACC_DNEW, true, &v));             // k_visc_dir reads the global delta' on the device
-    const float delta_start = ctx->cg_delta;
-    ctx->cg_delta_old = delta_start;
-    ctx->cg_delta = (float)v;
-    ctx->vs_iter++;
-    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero || (double)ctx->cg_delta_zero < (double)ctx->p.eps) break;
-    ctx->cg_delta = delta_start;                   // beta = delta' / delta_old
-    rc = R.ph(WCSPH_PH_VISC_DIR);
-    ctx->cg_delta = (float)v;
-    if (rc) return rc;
+  // ---- compute_nonpressure_force() (dfsph.py:84-103)
+  ELEM(k_end_div_begin_nonpressure, dt, vort_div ? 1 : 0);
+  if (tension) {
+    RPASS(k_tension_normal);
+    R.hf_begin(); R.hf_add(d.normal, 3, 4);
+    SRC(R.xp(true, SPASS_(k_tension_accel)));
   }
-  SRC(R.ph(WCSPH_PH_VISC_END));
-  SRC(R.ph(WCSPH_PH_VORTICITY_INT));
-  // optimize_time_step() (dfsph.py:107-129) on the GLOBAL velocity maximum
+  R.hf_begin(); R.hf_add(d.vel_guess, 3, 4);
+  if (vort_div) SRC(R.xp(true, SPASS_(k_visc_minv_residual, dt)));
+  else SRC(R.xp(true, SPASS_(k_visc_minv_residual_vort, dt)));
+  SRC(R.allreduce(ACC_DZERO));                  // the first k_visc_update takes delta_zero from the device
+  R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
+  SRC(R.xp(true, SPASS_(k_visc_Ad, dt)));
+  SRC(R.allreduce(ACC_DAD));
+  ELEM(k_visc_update, 0.0f, 1);
+  SRC(R.allreduce(ACC_DNEW));
+  SRC(R.fetch());
+  ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
+  ctx->cg_delta_old = ctx->cg_delta_zero;
+  ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+  ctx->vs_iter = 1;
+  while (ctx->vs_iter < 100) {
+    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero || (double)ctx->cg_delta_zero < (double)ctx->p.eps) break;
+    ELEM(k_visc_dir, ctx->cg_delta_old);        // beta = delta' (global, on the device) / delta the last iteration started with
+    R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
+    SRC(R.xp(true, SPASS_(k_visc_Ad, dt)));
+    SRC(R.allreduce(ACC_DAD));
+    ELEM(k_visc_update, ctx->cg_delta);
+    SRC(R.allreduce(ACC_DNEW));
+    SRC(R.fetch());
+    ctx->cg_delta_old = ctx->cg_delta;
+    ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+    ctx->vs_iter++;
+  }
+  // end_viscosity + the integration loop of compute_vorticity + the per-particle part of the CFL reduction
+  const bool cfl_here = !(d.faithful && d.nl <= 1);
+  if (cfl_here) { ELEM(k_finish_nonpressure, dt); ctx->cfl_done = true; }
+  else { ELEM(k_visc_end, dt); ELEM(k_vorticity_integrate, dt); }
+  // ---- optimize_time_step() (dfsph.py:107-129) on the GLOBAL velocity maximum
   SRC(wcsph_dfsph_cfl_reduce(ctx));
   R.n_wait++;
   double vmax = (double)ctx->vel_max0;
   if (R.multi && (rc = cb->allreduce_max(cb->user, &vmax))) return ctx->fail(rc, "slab callback allreduce_max failed");
-  if ((float)vmax > ctx->p.eps) {
+  if ((double)(float)vmax > (double)ctx->p.eps) {
     double time_step = 0.5 * 0.4 * ctx->p.cfl_radius * 2.0 / sqrt((double)(float)vmax);
     if (time_step > ctx->p.user_max_t) time_step = ctx->p.user_max_t;
     if (time_step < ctx->p.user_min_t) time_step = ctx->p.user_min_t;
@@ -1868,29 +1910,34 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
     if ((double)d2 > time_step) d2 = (float)time_step;
     ctx->dt = d2;
   }
-  // update_vel(); solve_pressure() (dfsph.py:150-164; the warm start is a no-op in the reference, Q7)
-  SRC(R.ph(WCSPH_PH_UPDATE_VEL_WARM_SCALE));
-  SRC(R.ph(WCSPH_PH_WARM_PRESS_VEL));
+  const float dtn = ctx->dt;
+  // ---- update_vel(); solve_pressure() (dfsph.py:150-164; the warm start changes no velocity in the reference, Q7)
+  ELEM(k_update_vel_warm_scale, dtn);
+  PASS(k_warm_press_vel, dtn);
   ctx->pr_iter = 0;
   err = 0.0;
-  SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_PRESS_BEGIN));
+  R.hf_begin(); R.hf_add(d.vel, 3, 4);
+  SRC(R.xp(true, SPASS_((k_drho_press<DRHO_BEGIN, true>), dtn)));
   while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
     const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
-    SRC(R.ph(WCSPH_PH_MAKE_K_PRESS));
-    SRC(R.xp({WCSPH_F_KBUF}, WCSPH_PH_VEL_ITER));
-    SRC(R.xp({WCSPH_F_VEL}, WCSPH_PH_DRHO_PRESS_ITER));
+    R.hf_begin(); R.hf_add((const float *)d.pk + 3, 1, 4);
+    SRC(R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dtn, d.kappa)));
+    R.hf_begin(); R.hf_add(d.vel, 3, 4);
+    SRC(R.xp(true, SPASS_((k_drho_press<DRHO_ITER, true>), dtn)));
     if (prof) { HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream)); ctx->prof_used += 2; }
     ctx->pr_iter++;
     if (ctx->pr_iter < 2) { err = 1.0; continue; }   // `pr_iter < 2` forces the second iteration whatever the first reports
-    SRC(R.reduce(ACC_ERR, true, &v));
-    ctx->avg_density_err = (float)v;
+    SRC(R.allreduce(ACC_ERR));
+    SRC(R.fetch());
+    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
     err = (double)ctx->avg_density_err / N;
   }
-  SRC(R.ph(WCSPH_PH_END_PRESS_UPDATE_POS));
+  ELEM(k_end_press_update_pos, dtn);
   if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; }
   return WCSPH_OK;
 }
+#undef SPASS_
 #undef SRC
 
 // ---- boundary sampler --------------------------------------------------------------------------------
