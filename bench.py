@@ -175,7 +175,11 @@ def _main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world > 1:
         from wcsph_amd import slab
-        return slab.bench_main(args)
+        out = slab.bench_main(args)
+        if out is not None and not args.no_cpu:     # rank 0, after the process group is gone: the same CPU leg as at N = 1
+            from wcsph_amd import scene
+            out["cpu_baseline"] = cpu_baseline(scene.CONFIGS.get(args.config) or int(args.config), args.cpu_n)
+        return out
 
     import __graft_entry__ as g
     g.build()

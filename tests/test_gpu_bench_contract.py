@@ -40,7 +40,8 @@ def test_two_rank_bench_line_over_gloo():
     for the whole job, weak scaling, faithful neighbour semantics across the ranks."""
     env = dict(os.environ, WCSPH_BENCH_COMM="gloo", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "24"],
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "24",
+                        "--cpu-n", "8"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
@@ -49,3 +50,7 @@ def test_two_rank_bench_line_over_gloo():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["neighbor_mode"] == "faithful" and sum(d["config"]["owned_per_rank"]) == d["config"]["n_liquid"]
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+    assert d["roofline"]["launches_timed"] >= 2 * d["steps"]            # HIP events around every pressure_iter of the timed steps
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0     # measured once, on rank 0's host
+    # 4 decision points inside the step (divergence, viscosity, CFL, pressure) + 2 in the migration / ghost rebuild (counts)
+    assert d["config"]["host_waits_per_step"] <= 6.5 and d["config"]["step_driver"].startswith("wcsph_slab_step")
