@@ -49,6 +49,51 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+# ---- HBM traffic of the north-star kernel pair, measured in THIS run -------------------------------------------------------
+def measure_traffic_live(n, mode, timeout=240):
+    """FETCH_SIZE and WRITE_SIZE of k_vel_from_k + k_drho_press<ITER> per launch, each counter in its OWN child
+    `rocprofv3 --pmc <counter> --kernel-trace` run of tools/run_kernel_group.py (the profiler cannot attach to this process;
+    separate passes and no other trace domain, as MI355X_MICROARCH.md "HBM" / "rocprofv3" prescribes).  Bytes per
+    pressure_iter launch = 2 x FETCH_SIZE (gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads; WRITE_SIZE is
+    taken as is, uncalibrated) in KB per dispatch.
+    Returns (bytes, note) or (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="wcsph_pmc_", dir="/tmp")
+    kb = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--kernel-include-regex", "k_vel_from_k|k_drho_press", "-d", out, "-o", "pmc",
+                   "--", sys.executable, os.path.join(ROOT, "tools", "run_kernel_group.py"), "pressure_iter", "10", str(n), mode]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s timed out" % counter
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            tot = 0.0
+            for kern in ("k_vel_from_k", "k_drho_press"):
+                rows = list(sqlite3.connect(dbs[0]).execute(
+                    "select avg(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", ("%" + kern + "%", counter)))
+                if not rows or rows[0][0] is None or rows[0][1] < 4:
+                    return None, "no %s samples for %s" % (counter, kern)
+                tot += float(rows[0][0])
+            kb[counter] = tot
+    except Exception as e:   # profiling is best effort: the bench line must come out
+        return None, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over "
+                                                                      "k_vel_from_k + k_drho_press<ITER>; 2 x FETCH + WRITE, KB per dispatch")
+
+
 # ---- CPU baseline (child process: the baseline build of the oracle, its own 17 GB of tables) -------------------------
 def _cpu_child(n, steps, sweep, single):
     import oracle
@@ -163,6 +208,7 @@ def _main():
     ap.add_argument("--mode", default="faithful", choices=["faithful", "clean"])
     ap.add_argument("--cpu-n", type=int, default=46, help="particleDim of the small CPU sample that rides along")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-clean", action="store_true", help="skip the companion legs (clean mode, fixed iterations, C2, C5)")
     ap.add_argument("--no-developed", action="store_true", help="skip the developed-flow leg (1200 untimed steps)")
     ap.add_argument("--developed-after", type=int, default=1200)
@@ -213,13 +259,13 @@ def _main():
         extra[name + "_us"] = round(m2.value * 1e3, 1)
     # HBM traffic of the pair from the PMC counters: recorded by tools/pmc_traffic.sh (rocprofv3 cannot run inside this
     # process); quoted only if it was taken on THIS kernel source and THIS workload, otherwise null
-    traffic, traffic_note = None, "no PMC record for this kernel source (tools/pmc_traffic.sh)"
+    traffic, traffic_note = (None, "skipped (--no-pmc)") if args.no_pmc else measure_traffic_live(n, args.mode)
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
+    if traffic is None and os.path.exists(tf):   # fall back to the committed record, only if it was taken on THIS kernel source
         try:
             t = json.load(open(tf))
             if t.get("n_liquid") == nl and t.get("kernel_source_sha16") == kernel_source_sha16():
-                traffic, traffic_note = t.get("pressure_iter_bytes_per_launch"), t.get("source")
+                traffic, traffic_note = t.get("pressure_iter_bytes_per_launch"), "%s (recorded; live pass: %s)" % (t.get("source"), traffic_note)
         except Exception:
             pass
     it = r["iters"]

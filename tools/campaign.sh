@@ -1,7 +1,7 @@
 #!/bin/bash
 # One measurement campaign on the GPU box: default bench line, kernel stats (rest / developed flow), PMC passes.
 # usage: tools/campaign.sh <tag>      (outputs under gpurun_out/<tag>_*)
-TAG=${1:-r02}; R=/root/repo; O=$R/gpurun_out
+TAG=${1:-r03}; R=/root/repo; O=$R/gpurun_out
 cd $R
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python tools/slab_overhead.py > $O/${TAG}_slab_overhead.txt 2>/dev/null

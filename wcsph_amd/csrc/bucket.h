@@ -19,7 +19,13 @@ struct BucketTab {
   int *item;      // [n_liquid + n_solid]
   int *cursor;    // [T] scatter cursors
   int *swhere;    // [n_solid] original solid index -> sorted solid index
+  // derived per step for the kernels that walk whole rows (compute_tension literally): the same items as SORTED indices
+  // (bit 31: boundary particle), and per cell of the grid the slice of its bucket -- so that a row walk is
+  // 25 short z-runs of (start, count) pairs + one indirection per entry instead of 125 hashes and three
+  int *item_s;    // [n_liquid + n_solid]
+  int2 *cellb;    // [ncell, plain (x, y, z) index] (first item, count) of bucket hash(cell); valid within 2 cells of the liquid
 };
+#define BK_SOLID 0x80000000u
 
 __global__ void k_bk_swhere(Dev d, BucketTab b) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,6 +58,48 @@ __global__ void k_bk_sort(Dev d, BucketTab b) {   // one thread per bucket: inse
     int k = a - 1;
     while (k >= lo && b.item[k] > v) { b.item[k + 1] = b.item[k]; k--; }
     b.item[k + 1] = v;
+  }
+}
+
+__global__ void k_bk_items_sorted(Dev d, BucketTab b) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= b.start[d.table_size]) return;
+  const int g = b.item[s];
+  b.item_s[s] = g < d.nl ? d.where[g] : (int)((unsigned)b.swhere[g - d.nl] | BK_SOLID);
+}
+__global__ void k_bk_cellstart(Dev d, BucketTab b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;   // plain index
+  if (c >= d.ncell) return;
+  const int *bb = d.bbox;
+  if (bb[3] < 0) return;
+  const int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
+  if (cx < bb[0] - 2 || cx > bb[3] + 2 || cy < bb[1] - 2 || cy > bb[4] + 2 || cz < bb[2] - 2 || cz > bb[5] + 2) return;
+  const int h = ref_hash(cx + d.x0, cy, cz, d.table_size);
+  const int lo = b.start[h];
+  b.cellb[c] = make_int2(lo, b.start[h + 1] - lo);
+}
+// the raw row of liquid particle i through the per-cell slices: f(js) for every entry in the reference's order (REV: in
+// exactly the reverse order; f returns false to stop), js = sorted index | BK_SOLID
+template <bool REV, class F>
+__device__ __forceinline__ void raw_row_s(const Dev &d, const BucketTab &b, int i, float4 pi, F &&f) {
+  const int cw = __float_as_int(pi.w);
+  if (cw < 0) return;
+  const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
+  const int za = max(cz - 2, 0), zb = min(cz + 2, d.nz - 1);
+#pragma unroll 1
+  for (int u = 0; u < 25; u++) {
+    const int q = REV ? 24 - u : u;
+    const int x = cx + q / 5 - 2, y = cy + q % 5 - 2;
+    if ((unsigned)x >= (unsigned)d.nx || (unsigned)y >= (unsigned)d.ny) continue;
+    const int2 *row = b.cellb + (size_t)(x * d.ny + y) * d.nz;
+    int2 sc[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) { const int z = REV ? zb - t : za + t; sc[t] = (REV ? z >= za : z <= zb) ? row[z] : make_int2(0, 0); }
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      if (REV) { for (int s = sc[t].x + sc[t].y - 1; s >= sc[t].x; s--) { const int js = b.item_s[s]; if (js != i && !f(js)) return; } }
+      else { for (int s = sc[t].x; s < sc[t].x + sc[t].y; s++) { const int js = b.item_s[s]; if (js != i && !f(js)) return; } }
+    }
   }
 }
 
@@ -109,22 +157,28 @@ __device__ __forceinline__ float3 bk_gradW(const Dev &d, float3 r) {
   return r * cubic_gradW_scale(d, r2);
 }
 // first loop (:266-279): normal_i = sum over the raw row; liquid entries add (m / rho_j) gradW, EVERY entry then scales the
-// running value by searchR (Q8)
+// running value by searchR (Q8): n = (...((t_0) h + t_1) h ...+ t_{K-1}) h = sum_p t_{K-1-p} h^{p+1}.  h = 0.1, so only the
+// END of the row survives: the sum is taken from the last entry backwards until h^{p+1} underflows to zero (p = 45 in
+// f32) -- the entries before that contribute exactly nothing to the reference's own f32 recurrence either.
+// Also leaves the (normal, rho) gather record of the second loop in cg_Ad (free until the viscosity solve).
 __global__ void __launch_bounds__(BLOCK) k_tension_normal_literal(Dev d, BucketTab b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || d.oid[i] >= d.n_owned) return;
   const float4 pi = d.pos[i];
   const float3 xi = xyz(pi);
   float3 n = f3(0, 0, 0);
-  raw_row(d, b, i, pi, [&](int g) {
-    if (g < d.nl) {
-      const int j = d.where[g];
-      const float3 gw = bk_gradW(d, xi - xyz(d.pos[j]));
-      n = n + gw * (d.mass / d.rho[j]);
+  float scale = d.h;
+  raw_row_s<true>(d, b, i, pi, [&](int js) -> bool {
+    if (js >= 0) {
+      const float4 pj = d.pos[js];
+      const float3 gw = bk_gradW(d, xi - xyz(pj));
+      n = n + gw * (d.mass / d.rho[js] * scale);
     }
-    n = n * d.h;
+    scale *= d.h;
+    return scale > 0.0f;
   });
   d.normal[i] = f4(n, 0);
+  d.cg_Ad[i] = f4(n, d.rho[i]);
 }
 // second loop (:281-305): every raw liquid entry adds k_ij * (-gamma (n_i - n_j)) (the cohesion value is overwritten, Q9);
 // solid entries: adhesion inside the scene's 0.26 gate
@@ -136,14 +190,13 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel_literal(Dev d, BucketTa
   const float3 xi = xyz(pi), ni = xyz(d.normal[i]);
   const float rhoi = d.rho[i];
   float3 dv = xyz(d.d_vel[i]);
-  raw_row(d, b, i, pi, [&](int g) {
-    if (g < d.nl) {
-      const int j = d.where[g];
-      const float kij = 2.0f * d.rho_L0 / (rhoi + d.rho[j]);
-      const float3 accel = (ni - xyz(d.normal[j])) * (-d.tension);
-      dv = dv + accel * kij;
+  raw_row_s<false>(d, b, i, pi, [&](int js) -> bool {
+    if (js >= 0) {
+      const float4 nr = d.cg_Ad[js];        // (normal_j, rho_j)
+      const float kij = 2.0f * d.rho_L0 / (rhoi + nr.w);
+      dv = dv + (ni - xyz(nr)) * (-d.tension * kij);
     } else {
-      const float3 pj = xyz(d.spos[b.swhere[g - d.nl]]);
+      const float3 pj = xyz(d.spos[js & 0x7fffffff]);
       const float3 r = xi - pj, c = pj - f3(0.0f, 0.5f, 0.0f);
       const float len2 = dot3(r, r), dis = sqrtf(dot3(c, c));
       if (len2 > d.eps && dis < 0.26f) {
@@ -151,6 +204,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel_literal(Dev d, BucketTa
         dv = dv + r * (1.0f / rl) * (-d.tension_b * d.rho_S0 * d.VS0 * adhesion_W(d, rl));
       }
     }
+    return true;
   });
   d.d_vel[i] = f4(dv, 0);
 }

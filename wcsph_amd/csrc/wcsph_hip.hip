@@ -40,8 +40,8 @@ struct wcsph_ctx {
   unsigned char *bcount8 = nullptr;
   int *region_occ = nullptr;      // neighborCount regions that hold particles: flagged by k_cell_assign, cleared by k_ncount_box
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ
-  BucketTab bk = {nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
-  bool bk_valid = false;
+  BucketTab bk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
+  bool bk_valid = false, bk_rows_valid = false;
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats
@@ -527,6 +527,19 @@ static int bucket_build(wcsph_ctx *ctx) {
   hipLaunchKernelGGL(k_bk_sort, dim3(nblk(T)), dim3(BLOCK), 0, s, d, ctx->bk);
   LAUNCHCHK();
   ctx->bk_valid = true;
+  ctx->bk_rows_valid = false;
+  return 0;
+}
+// + what the whole-row walks of the literal compute_tension use (bucket.h raw_row_s)
+static int bucket_build_rows(wcsph_ctx *ctx) {
+  int rc = bucket_build(ctx);
+  if (rc || ctx->bk_rows_valid) return rc;
+  Dev &d = ctx->d;
+  if (!ctx->bk.item_s) { DALLOC(ctx->bk.item_s, (size_t)ctx->capacity + d.ns + 1); DALLOC(ctx->bk.cellb, (size_t)d.ncell); }
+  hipLaunchKernelGGL(k_bk_items_sorted, dim3(nblk(d.nl + d.ns)), dim3(BLOCK), 0, ctx->stream, d, ctx->bk);
+  hipLaunchKernelGGL(k_bk_cellstart, dim3(nblk(d.ncell)), dim3(BLOCK), 0, ctx->stream, d, ctx->bk);
+  LAUNCHCHK();
+  ctx->bk_rows_valid = true;
   return 0;
 }
 int wcsph_hashgrid_count_to_host(wcsph_ctx *ctx, int32_t *dst, int64_t n) {   // HashGrid.gridCount
@@ -904,7 +917,7 @@ int wcsph_dfsph_tension(wcsph_ctx *ctx) {
   // dependent garbage in the reference, Q8) is then left untouched.
   if (ctx->d.tension == 0.0f && ctx->d.tension_b == 0.0f) return WCSPH_OK;
   if (ctx->p.tension_fixed == 0) {   // the reference loop literally, over the raw bucket rows (bucket.h)
-    int rc = bucket_build(ctx);
+    int rc = bucket_build_rows(ctx);
     if (rc) return rc;
     ELEM(k_tension_normal_literal, ctx->bk);
     ELEM(k_tension_accel_literal, ctx->bk);
@@ -1710,11 +1723,11 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     // tension_fixed = 0: the reference loop literally, over its raw bucket rows (bucket.h).  On a slab window the table
     // spans all ranks (far aliased entries name particles of other slabs): bucket_build refuses with a message.
     case WCSPH_PH_TENSION_NORMAL:
-      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build(ctx))) return rc; ELEM(k_tension_normal_literal, ctx->bk); }
+      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build_rows(ctx))) return rc; ELEM(k_tension_normal_literal, ctx->bk); }
       else RPASS(k_tension_normal);
       break;
     case WCSPH_PH_TENSION_ACCEL:
-      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build(ctx))) return rc; ELEM(k_tension_accel_literal, ctx->bk); }
+      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build_rows(ctx))) return rc; ELEM(k_tension_accel_literal, ctx->bk); }
       else PASS(k_tension_accel);
       break;
     case WCSPH_PH_VISC_GUESS: ELEM(k_visc_guess); break;
