@@ -163,7 +163,7 @@ __device__ __forceinline__ float3 bk_gradW(const Dev &d, float3 r) {
 // Also leaves the (normal, rho) gather record of the second loop in cg_Ad (free until the viscosity solve).
 __global__ void __launch_bounds__(BLOCK) k_tension_normal_literal(Dev d, BucketTab b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   const float4 pi = d.pos[i];
   const float3 xi = xyz(pi);
   float3 n = f3(0, 0, 0);
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(BLOCK) k_tension_normal_literal(Dev d, BucketT
 __device__ __forceinline__ float adhesion_W(const Dev &d, float r);
 __global__ void __launch_bounds__(BLOCK) k_tension_accel_literal(Dev d, BucketTab b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   const float4 pi = d.pos[i];
   const float3 xi = xyz(pi), ni = xyz(d.normal[i]);
   const float rhoi = d.rho[i];

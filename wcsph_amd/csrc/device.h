@@ -61,7 +61,8 @@ struct Dev {
   // compact per-step neighbour lists: 16-bit delta streams, 8 slots per 16-byte block, block b of particle i at
   // [b * nbr_stride + i] (see "neighbour streams" below)
   uint4 *nbl, *nbs;                       // liquid / solid streams
-  int2 *nhead;                            // x = liquid slots | solid slots << 16, y = sorted solid index the solid stream starts from
+  int *nhead;                             // liquid slots | solid slots << 16
+  int *nsbase;                            // sorted solid index the solid stream starts from (read only by particles that have solid entries)
   int nbr_stride, nbr_cap;
   float list_r2;                          // squared support radius the lists are built with
   int *bbox;                              // [6] {xmin,ymin,zmin,xmax,ymax,zmax} of the in-box liquid cells of this step
@@ -145,6 +146,9 @@ __device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int
   r.hi1 = CS[bB + (tB > tA ? z1 - (tB << T2B) : 0)];
   return r;
 }
+
+// does this context own row i?  Without a decomposition every row is owned (n_owned == nl, wave-uniform): no oid read.
+__device__ __forceinline__ bool owned(const Dev &d, int i) { return d.n_owned >= d.nl || d.oid[i] < d.n_owned; }
 
 // which owned particles a neighbour pass computes in this launch (Dev::part_mode); particles outside the grid box
 // have no neighbours and count as interior
@@ -308,7 +312,7 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
 // ---- neighbour streams ---------------------------------------------------------------------------------
 // The compact list of particle i (the in-support subset of the reference's HashGrid.neighbor row, duplicates
 // included) is stored as a stream of int16 DELTAS: slot k holds j_k - j_{k-1}, the liquid stream starting from
-// j_{-1} = i (neighbours are near i in the cell-sorted order), the solid stream from nhead[i].y.  A sorted index
+// j_{-1} = i (neighbours are near i in the cell-sorted order), the solid stream from nsbase[i].  A sorted index
 // needs 4 bytes, its delta 2: the index stream is what a pass reads most of (tools/ablate.py), so this halves the
 // HBM traffic of every neighbour pass.  Deltas that do not fit (the jump to the neighbouring outer tile plane of a
 // large grid) are bridged by HOP slots, +-32767, which move the running index but are not entries.  Eight slots form one
@@ -390,8 +394,8 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   static_assert(U == 4 || U == 8, "U slots per trip");
   const float3 xi = xyz(pi);
   const size_t st = (size_t)d.nbr_stride;
-  const int2 head = d.nhead[i];
-  const int cl = head.x & 0xffff, cs = (int)((unsigned)head.x >> 16);
+  const int head = d.nhead[i];
+  const int cl = head & 0xffff, cs = (int)((unsigned)head >> 16);
   const uint4 *L = d.nbl + i;
   int run = i;
   // scalars, not indexed arrays: keeps the indices in VGPRs (an int j[U] lands in scratch here)
@@ -432,8 +436,9 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   }
 #undef WALK_ONE
 #undef WALK_OK
+  if (cs == 0) return;
   const uint4 *S = d.nbs + i;
-  run = head.y;
+  run = d.nsbase[i];
 #define WALK_SOL(u, dd, jj, pp) if (k + u < cs && NB_IS_ENTRY(dd)) { const float3 r = xi - xyz(pp); fs(jj, r, dot3(r, r)); }
   for (int k = 0; k < cs; k += 8) {
     const uint4 e = nb_stream<NT>(S + (size_t)(k >> 3) * st);

@@ -9,7 +9,7 @@
   const int i = sorted_index();                       \
   const bool live = i < d.nl;                         \
   const float4 pi = live ? d.pos[i] : make_float4(0, 0, 0, __int_as_float(-1)); \
-  const bool own = live && d.oid[i] < d.n_owned && part_ok(d, pi);
+  const bool own = live && owned(d, i) && part_ok(d, pi);   /* one context owning every row (uniform): no oid read */
 
 // ref: dfsph.py:248-262 compute_density
 __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
@@ -173,14 +173,23 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
 }
 
 // ref: dfsph.py:394-412 update_drho_pressure, inlined at :513 (BEGIN), :545 (ITER)
+// Fused ITER launches take the geometry -- the particle's own position and the gathered ones -- from the (pos, k) records
+// the previous density-change pass wrote and store only the record's k: the solver loop then never touches `pos`, and
+// its working set (streams + records + vel + five scalars, ~230 MB at C3) stays inside the 256 MB Infinity Cache across
+// the V / D launches of an iteration instead of cycling through it (DESIGN.md 4 "working set").  Gathers read xyz only,
+// the epilogue writes w only: no launch reads a word another thread of the same launch writes.
 template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
-  LOAD_I
+  constexpr bool REC = FUSEK && MODE == DRHO_ITER;
+  const int i = sorted_index();
+  const bool live = i < d.nl;
+  const float4 pi = live ? (REC ? d.pk[i] : d.pos[i]) : make_float4(0, 0, 0, __int_as_float(-1));
+  const bool own = live && owned(d, i) && (REC ? (d.part_mode == 0 || part_ok(d, d.pos[i])) : part_ok(d, pi));
   float e = 0.f;
   if (own) {
     const float3 vi = xyz(d.vel[i]);
     float t = 0.f;
-    walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+    walk<8>(d, i, pi, REC ? d.pk : d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
             [&](int, float3 r, float r2, float4 vj) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
             [&](int, float3 r, float r2) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
@@ -188,7 +197,8 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
     e = a - 1.0f;
     float al = d.alpha[i];
     if (MODE == DRHO_BEGIN) { al = al / dt / dt; d.alpha[i] = al; d.kappa[i] = 0.0f; }
-    if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, e * al);
+    if (REC) reinterpret_cast<float *>(d.pk + i)[3] = e * al;
+    else if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, e * al);
   }
   if (MODE == DRHO_ITER) block_accumulate(ACC_SLOT(d, ACC_ERR), e);  // ref: dfsph.py:546
 }
@@ -202,7 +212,7 @@ __global__ void k_make_k(Dev d, float *kap, float bias) {
   d.kbuf[i] = k;
   float4 p = d.pos[i];
   d.pk[i] = make_float4(p.x, p.y, p.z, k);  // (pos, k) record: one 16-byte gather per neighbour in k_vel_from_k
-  if (d.oid[i] < d.n_owned) kap[i] += k;
+  if (owned(d, i)) kap[i] += k;
 }
 
 // (pos.xyz, rho) records for the viscosity / vorticity / tension walks, for every row (ghosts included), when rho did not
@@ -228,10 +238,16 @@ __global__ void k_pack_k(Dev d, const float *kb) {
 template <int COND>
 __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, float dt, float *kap = nullptr) {
   if (kap) acc_clear(ACC_SLOT(d, ACC_ERR));   // fused solver loops: the density-change pass launched next sums into it
-  LOAD_I
-  if (!own) return;
+  // The pass is HBM-bound on its own inputs: the particle's position comes with its (pos, k) record, and
+  // pos[i] / oid[i] are read only where ownership is not trivial (slab decomposition) -- 40 B per particle less.
+  const int i = sorted_index();
+  if (i >= d.nl) return;
+  if (d.n_owned < d.nl || d.part_mode != 0) {
+    if (!(owned(d, i) && part_ok(d, d.pos[i]))) return;
+  }
   if (COND == 1 && !(d.adv_rho[i] > 0.0f)) return;
-  const float ki = pk[i].w;
+  const float4 pi = pk[i];
+  const float ki = pi.w;
   if (kap) kap[i] += ki;
   float3 acc = f3(0, 0, 0);
   const bool ks = fabsf(ki) > d.eps;
@@ -253,7 +269,7 @@ __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, f
 // opens; the solid branch reads kappa_v).  kappa is rescaled first (:490).
 __global__ void k_warm_press_scale(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   d.kappa[i] = fmaxf(d.kappa[i] / dt / dt, -0.5f * d.rho_L0 * d.rho_L0);
 }
 __global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
@@ -278,13 +294,13 @@ __global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
 // ref: dfsph.py:480-484, 549-552
 __global__ void k_end_div(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   d.kappa_v[i] *= dt;
   d.alpha[i] *= dt;
 }
 __global__ void k_end_press(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   d.kappa[i] *= dt * dt;
 }
 
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta, int f
   float part = 0.f;
   const double dAd = acc_total(ACC_SLOT(d, ACC_DAD));
   if (from_dzero) delta = (float)acc_total(ACC_SLOT(d, ACC_DZERO));
-  if (i < d.nl && d.oid[i] < d.n_owned) {
+  if (i < d.nl && owned(d, i)) {
     const float alpha = delta / (float)((double)d.eps + dAd);
     float3 dir = xyz(d.cg_dir[i]);
     d.vel_guess[i] = f4(xyz(d.vel_guess[i]) + dir * alpha, 0);
@@ -568,14 +584,14 @@ __global__ void k_visc_dir(Dev d, float delta_old, int from_dzero = 0) {
   const double dnew = acc_total(ACC_SLOT(d, ACC_DNEW));
   if (from_dzero) delta_old = (float)acc_total(ACC_SLOT(d, ACC_DZERO));
   acc_clear(ACC_SLOT(d, ACC_DAD));     // read by k_visc_update (finished); the next k_visc_Ad sums into it
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   const float beta = (float)dnew / delta_old;
   d.cg_dir[i] = f4(xyz(d.cg_s[i]) + xyz(d.cg_dir[i]) * beta, 0);
 }
 // ref: dfsph.py:339-343 end_viscosity
 __global__ void k_visc_end(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float3 g = xyz(d.vel_guess[i]), v = xyz(d.vel[i]);
   float3 a = xyz(d.d_vel[i]) + (g - v) * (1.0f / dt);
   d.d_vel[i] = f4(a, 0);
@@ -617,7 +633,7 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
 // second loop of compute_vorticity (ref: dfsph.py:329-330); separate launch: omega_j is read above
 __global__ void k_vorticity_integrate(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float4 w = d.omega[i], dw = d.d_omega[i];
   d.omega[i] = make_float4(w.x + dw.x * dt, w.y + dw.y * dt, w.z + dw.z * dt, 0);
 }
@@ -697,13 +713,13 @@ __global__ void __launch_bounds__(BLOCK) k_finish_nonpressure(Dev d, float dt) {
 // ref: dfsph.py:572-580
 __global__ void k_update_vel(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float4 v = d.vel[i], a = d.d_vel[i];
   d.vel[i] = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);
 }
 __global__ void k_update_pos(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float4 p = d.pos[i], v = d.vel[i];
   d.pos[i] = make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w);
 }
@@ -717,7 +733,7 @@ __global__ void k_end_div_begin_nonpressure(Dev d, float dt, int vort) {
   acc_clear(ACC_SLOT(d, ACC_DAD));
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl) return;
-  if (d.oid[i] < d.n_owned) { d.kappa_v[i] *= dt; d.alpha[i] *= dt; }
+  if (owned(d, i)) { d.kappa_v[i] *= dt; d.alpha[i] *= dt; }
   float4 a = make_float4(d.gx, d.gy, d.gz, 0);
   if (vort) { const float4 dv = d.cg_s[i]; a.x += dv.x; a.y += dv.y; a.z += dv.z; }
   d.d_vel[i] = a;
@@ -727,7 +743,7 @@ __global__ void k_end_div_begin_nonpressure(Dev d, float dt, int vort) {
 // update_vel (dfsph.py:572-575) + the kappa rescale that opens warmstart_pressure (:490)
 __global__ void k_update_vel_warm_scale(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float4 v = d.vel[i], a = d.d_vel[i];
   d.vel[i] = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);
   d.kappa[i] = fmaxf(d.kappa[i] / dt / dt, -0.5f * d.rho_L0 * d.rho_L0);
@@ -735,7 +751,7 @@ __global__ void k_update_vel_warm_scale(Dev d, float dt) {
 // end of solve_pressure (dfsph.py:549-552) + update_pos (:577-580)
 __global__ void k_end_press_update_pos(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   d.kappa[i] *= dt * dt;
   float4 p = d.pos[i], v = d.vel[i];
   d.pos[i] = make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w);
@@ -791,7 +807,7 @@ __global__ void __launch_bounds__(BLOCK) k_ss_force(Dev d) {
 }
 __global__ void k_ss_integrate(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float4 v = d.vel[i], a = d.d_vel[i], p = d.pos[i];
   v = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);
   d.vel[i] = v;

@@ -476,8 +476,8 @@ __global__ void k_ncount_clean(Dev d) {
 __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
   const int i = sorted_index();
   if (i >= d.nl) return;
-  int2 head = d.nhead[i];
-  if (d.oid[i] >= d.n_owned) { d.nhead[i] = make_int2(liquid_too ? 0 : (head.x & 0xffff), 0); return; }  // ghosts never run a neighbour loop
+  const int head = liquid_too ? 0 : d.nhead[i];
+  if (!owned(d, i)) { d.nhead[i] = head & 0xffff; return; }  // ghosts never run a neighbour loop
   const float4 pi = d.pos[i];
   const size_t st = (size_t)d.nbr_stride;
   const int cap = d.nbr_cap;
@@ -491,9 +491,10 @@ __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
                if (sbase < 0) { sbase = j; ws.run = j; }
                for (int rep = (int)m; rep > 0; rep--) ws.entry(j);
              });
-  int cl = liquid_too ? wl.finish() : (head.x & 0xffff), cs = ws.finish();
+  int cl = liquid_too ? wl.finish() : (head & 0xffff), cs = ws.finish();
   if (cl > cap || cs > cap) { atomicOr(&d.flags[FLAG_ERR], ERRBIT_LISTCAP); cl = min(cl, cap); cs = min(cs, cap); }
-  d.nhead[i] = make_int2(cl | (cs << 16), max(sbase, 0));
+  d.nhead[i] = cl | (cs << 16);
+  if (cs > 0) d.nsbase[i] = sbase;
 }
 
 // ---- slab decomposition: whole-state load / store in original (row) order -----------------------

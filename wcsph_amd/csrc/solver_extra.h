@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(BLOCK) k_pc_pressure_force(Dev d) {
 // ref: pcisph.py:281-285
 __global__ void k_pc_update_pos(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float3 v = xyz(d.vel[i]) + (xyz(d.d_vel[i]) + xyz(d.d_vel_pre[i])) * dt;
   float4 p = d.pos[i];
   d.vel[i] = f4(v, 0);
@@ -87,7 +87,7 @@ __global__ void k_pc_update_pos(Dev d, float dt) {
 // ref: iisph.py:270-274
 __global__ void k_ii_combine(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl || d.oid[i] >= d.n_owned) return;
+  if (i >= d.nl || !owned(d, i)) return;
   float3 g = xyz(d.vel_guess[i]), v = xyz(d.vel[i]);
   d.d_vel[i] = f4(f3(d.gx, d.gy, d.gz) + (g - v) * (1.0f / dt), 0);
   d.vel_guess[i] = f4(g - v, 0);

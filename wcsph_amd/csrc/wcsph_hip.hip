@@ -245,7 +245,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(d.cg_r, nl); DALLOC(d.cg_dir, nl); DALLOC(d.cg_Ad, nl); DALLOC(d.cg_s, nl);
   DALLOC(d.minv0, nl); DALLOC(d.minv1, nl); DALLOC(d.minv2, nl);
   DALLOC(d.rho, nl); DALLOC(d.adv_rho, nl); DALLOC(d.pressure, nl); DALLOC(d.vel_max, nl); DALLOC(d.alpha, nl); DALLOC(d.kbuf, nl);
-  DALLOC(d.ncount, nl); DALLOC(d.nhead, nl); DALLOC(d.pk, nl); DALLOC(d.pr, nl);
+  DALLOC(d.ncount, nl); DALLOC(d.nhead, nl); DALLOC(d.nsbase, nl); DALLOC(d.pk, nl); DALLOC(d.pr, nl);
   DALLOC(d.d_vel_pre, nl); DALLOC(d.pos_star, nl); DALLOC(d.vel_star, nl); DALLOC(d.d_ii, nl); DALLOC(d.dij_pj, nl);
   DALLOC(d.a_ii, nl); DALLOC(d.pressure_pre, nl);
   d.nbr_stride = (int)((nl + 63) / 64 * 64);
@@ -1516,8 +1516,8 @@ __global__ void k_compact_lists(Dev d, int i0, int n, int cap, int *counts, int 
   if (t >= n) return;
   const int i = d.where[i0 + t];
   int *row = lists + (size_t)t * cap;
-  const int2 head = d.nhead[i];
-  const int cl = head.x & 0xffff, cs = (int)((unsigned)head.x >> 16);
+  const int head = d.nhead[i];
+  const int cl = head & 0xffff, cs = (int)((unsigned)head >> 16);
   const size_t st = (size_t)d.nbr_stride;
   const unsigned short *L = reinterpret_cast<const unsigned short *>(d.nbl + i), *S = reinterpret_cast<const unsigned short *>(d.nbs + i);
   int w = 0, hops = 0, run = i;
@@ -1529,7 +1529,7 @@ __global__ void k_compact_lists(Dev d, int i0, int n, int cap, int *counts, int 
     w++;
   }
   counts[3 * t] = w;
-  run = head.y;
+  run = cs > 0 ? d.nsbase[i] : 0;
   for (int k = 0; k < cs; k++) {
     const int dd = (int)(short)S[(size_t)(k >> 3) * st * 8 + (k & 7)];
     run += dd;
@@ -1560,8 +1560,8 @@ int wcsph_compact_lists_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t c
 __global__ void __launch_bounds__(BLOCK) k_list_stats(Dev d, unsigned long long *hist) {
   const int i = sorted_index();
   const bool own = i < d.nl && d.oid[i] < d.n_owned;
-  const int2 head = own ? d.nhead[i] : make_int2(0, 0);
-  const int nbl = min(((head.x & 0xffff) + 7) >> 3, 63), nbs = min((int)(((unsigned)head.x >> 16) + 7) >> 3, 63);
+  const int head = own ? d.nhead[i] : 0;
+  const int nbl = min(((head & 0xffff) + 7) >> 3, 63), nbs = min((int)(((unsigned)head >> 16) + 7) >> 3, 63);
   if (own) { atomicAdd(&hist[nbl], 1ull); atomicAdd(&hist[64 + nbs], 1ull); }
   int ml = nbl, ms = nbs;
 #pragma unroll
