@@ -27,6 +27,9 @@ struct Dev {
   // slab halo/compute overlap: 0 = every owned particle; 1 = only those in global cell columns [part_x0, part_x1)
   // (the interior: no ghost within their 5^3 cells); 2 = only the others (see part_ok)
   int part_mode, part_x0, part_x1;
+  // traversal direction of this launch (sorted_index): consecutive neighbour passes alternate, so that a pass starts on
+  // the data the previous one touched last -- the part of it that is still in the 256 MB Infinity Cache
+  int rev;
   int table_size;  // reference hash table size (HashGrid.py:114)
   int faithful;
   int cfl_prefix;  // Q5: CFL max covers original indices [0, cfl_prefix)
@@ -163,9 +166,13 @@ __device__ __forceinline__ bool part_ok(const Dev &d, float4 pi) {
 // dispatch"); give every XCD one CONTIGUOUS eighth of the cell-sorted particle range so that its
 // private L2 holds one spatial region instead of a 1/8 sample of all of them.  gridDim.x is a
 // multiple of 8 by construction (grid_for()).
-__device__ __forceinline__ int sorted_index() {
-  int per = gridDim.x >> 3;
-  int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+__device__ __forceinline__ int sorted_index(const Dev &d) {
+  const int per = gridDim.x >> 3;
+  int q = blockIdx.x >> 3;
+#ifndef WCSPH_NO_ALT
+  if (d.rev) q = per - 1 - q;   // every XCD walks its eighth backwards
+#endif
+  const int blk = (blockIdx.x & 7) * per + q;
   return blk * BLOCK + threadIdx.x;
 }
 

@@ -6,7 +6,7 @@
 
 #define WAVES6
 #define LOAD_I                                        \
-  const int i = sorted_index();                       \
+  const int i = sorted_index(d);                       \
   const bool live = i < d.nl;                         \
   const float4 pi = live ? d.pos[i] : make_float4(0, 0, 0, __int_as_float(-1)); \
   const bool own = live && owned(d, i) && part_ok(d, pi);   /* one context owning every row (uniform): no oid read */
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
 template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
   constexpr bool REC = FUSEK && MODE == DRHO_ITER;
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   const bool live = i < d.nl;
   const float4 pi = live ? (REC ? d.pk[i] : d.pos[i]) : make_float4(0, 0, 0, __int_as_float(-1));
   const bool own = live && owned(d, i) && (REC ? (d.part_mode == 0 || part_ok(d, d.pos[i])) : part_ok(d, pi));
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, f
   if (kap) acc_clear(ACC_SLOT(d, ACC_ERR));   // fused solver loops: the density-change pass launched next sums into it
   // The pass is HBM-bound on its own inputs: the particle's position comes with its (pos, k) record, and
   // pos[i] / oid[i] are read only where ownership is not trivial (slab decomposition) -- 40 B per particle less.
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   if (i >= d.nl) return;
   if (d.n_owned < d.nl || d.part_mode != 0) {
     if (!(owned(d, i) && part_ok(d, d.pos[i]))) return;

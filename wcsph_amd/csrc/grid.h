@@ -474,7 +474,7 @@ __global__ void k_ncount_clean(Dev d) {
 // from a runtime loop over the pieces -- 375 us against 327 us for this form at C3: the kernel issues ~160 M VALU
 // wave-instructions either way and half-empty 4-wide chunks add more than the shorter dependency chains save.)
 __global__ void __launch_bounds__(BLOCK) k_build_lists(Dev d, int liquid_too) {
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   if (i >= d.nl) return;
   const int head = liquid_too ? 0 : d.nhead[i];
   if (!owned(d, i)) { d.nhead[i] = head & 0xffff; return; }  // ghosts never run a neighbour loop

@@ -9,7 +9,7 @@ struct SurfDev { float *color; float4 *color_grad, *pos_avr, *g0, *g1, *g2; floa
 
 // ref: ParticleData.py:188-201
 __global__ void __launch_bounds__(BLOCK) k_surf_color(Dev d, SurfDev s) {
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   if (i >= d.nl) return;
   const float4 pi = d.pos[i];
   float cl = 0.f, cs = 0.f;
@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(BLOCK) k_surf_color(Dev d, SurfDev s) {
 }
 // ref: ParticleData.py:203-215
 __global__ void __launch_bounds__(BLOCK) k_surf_color_grad(Dev d, SurfDev s) {
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   if (i >= d.nl) return;
   const float4 pi = d.pos[i];
   float3 g = f3(0, 0, 0);
@@ -35,7 +35,7 @@ __device__ __forceinline__ float aniso_w(float r2, float R2) {
 }
 // ref: ParticleData.py:222-241  (d.list_r2 = R2^2 for this launch)
 __global__ void __launch_bounds__(BLOCK) k_surf_pos_avr(Dev d, SurfDev s) {
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   if (i >= d.nl) return;
   const float4 pi = d.pos[i];
   float sw = 0.f;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void aniso_G(float sw, float c00, float c01, float c0
 }
 // ref: ParticleData.py:244-280
 __global__ void __launch_bounds__(BLOCK) k_surf_aniso(Dev d, SurfDev s) {
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   if (i >= d.nl) return;
   const float kn = 0.5f, ne = 25.0f;
   float4 r0 = make_float4(kn, 0, 0, 0), r1 = make_float4(0, kn, 0, 0), r2v = make_float4(0, 0, kn, 0);

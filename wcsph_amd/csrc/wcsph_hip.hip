@@ -460,6 +460,7 @@ static int grid_end(wcsph_ctx *ctx) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
   }
   if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
+  ctx->d.rev ^= 1;
   LAUNCHCHK();
   ctx->hist_dirty = false;   // k_bucket_sum / k_ncount_box have left the histogram and the region flags zeroed
   ctx->grid_valid = true;
@@ -793,6 +794,7 @@ int wcsph_set_iters(wcsph_ctx *ctx, int32_t vs, int32_t dv, int32_t pr) {
 #define PASS(kern, ...)                                                                           \
   do {                                                                                            \
     if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk8(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
+    ctx->d.rev ^= 1;   /* the next neighbour pass walks the particles the other way round (device.h sorted_index) */ \
     LAUNCHCHK();                                                                                  \
   } while (0)
 /* walks over the (pos, rho) records: packed first unless this context's own density pass just wrote them for every row */
@@ -1558,7 +1560,7 @@ int wcsph_compact_lists_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t c
 }
 
 __global__ void __launch_bounds__(BLOCK) k_list_stats(Dev d, unsigned long long *hist) {
-  const int i = sorted_index();
+  const int i = sorted_index(d);
   const bool own = i < d.nl && d.oid[i] < d.n_owned;
   const int head = own ? d.nhead[i] : 0;
   const int nbl = min(((head & 0xffff) + 7) >> 3, 63), nbs = min((int)(((unsigned)head >> 16) + 7) >> 3, 63);
