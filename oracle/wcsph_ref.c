@@ -5,12 +5,15 @@
  * file; it is used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * as the CHECKER (and as the reported CPU baseline), never as the product path.
  *
- * PARITY UNPINNED: the reference is Python+Taichi, ships no tests / golden vectors and
- * cannot be imported in the build container (no taichi wheel).  This file follows the
- * reference sources line by line (citations "ref: file:line" are into /root/reference)
- * and is pinned only by the analytic known-answers in tests/test_oracle_known_answers.py
- * (kernel normalisation, lattice density 799.978, alpha, gradW samples, int32-wrap hash
- * values, default-scene blockSize).
+ * PARITY UNPINNED by the real reference: it is Python+Taichi, ships no tests / golden vectors and cannot be imported in
+ * the build container (no taichi wheel).  This file follows the reference sources line by line (citations
+ * "ref: file:line" are into /root/reference) and is pinned by
+ *   - the analytic known-answers in tests/test_oracle_known_answers.py (kernel normalisation, lattice density 799.978,
+ *     alpha, gradW samples, int32-wrap hash values, default-scene blockSize);
+ *   - round 3: golden vectors produced by the reference's UNMODIFIED text (dfsph.py, sesph.py imported from
+ *     /root/reference on a serial Taichi stand-in, tests/golden/make_reference_fixtures.py -> tests/golden/ref_*.npz;
+ *     tests/test_reference_fixtures.py).  That pins formulas, constants, list order and host control flow; it does not
+ *     pin Taichi's execution semantics, so the label above stays.
  *
  * Semantics encoded: f32 / i32 arithmetic, float->int truncation
  * toward zero, int32 wrap-around multiply in the hash, every top-level Taichi `for` is
