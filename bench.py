@@ -202,8 +202,8 @@ def main():
 def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", help="C2 | C3 | default | an integer particleDim")
     ap.add_argument("--mode", default="faithful", choices=["faithful", "clean"])
     ap.add_argument("--cpu-n", type=int, default=46, help="particleDim of the small CPU sample that rides along")
