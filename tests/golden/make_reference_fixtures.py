@@ -4,6 +4,8 @@
     python tests/golden/make_reference_fixtures.py dfsph            ->  tests/golden/ref_dfsph_default_scene.npz
     python tests/golden/make_reference_fixtures.py dfsph_perturbed  ->  tests/golden/ref_dfsph_perturbed_default_scene.npz
     python tests/golden/make_reference_fixtures.py sesph            ->  tests/golden/ref_sesph_default_scene.npz
+    python tests/golden/make_reference_fixtures.py iisph            ->  tests/golden/ref_iisph_default_scene.npz    (squeezed state)
+    python tests/golden/make_reference_fixtures.py pcisph           ->  tests/golden/ref_pcisph_default_scene.npz   (squeezed state)
 
 `dfsph` starts from the script's own rest state, where most neighbour sums are identically zero for the first steps
 (v = 0, omega = 0).  `dfsph_perturbed` is the same imported script with a non-trivial STATE written into its fields
@@ -137,10 +139,100 @@ def run_sesph(steps):
     return out
 
 
+def squeeze(ref, pd, out, factor=0.92, vel_field=None):
+    """a compressed, jittered liquid block with a smooth velocity field, written through the fields' own from_numpy():
+    rho > rho0, so the pressure loops of iisph.py / pcisph.py do real work (from their rest lattice rho = 800 < rho0 and
+    every pressure stays 0)"""
+    rng = np.random.default_rng(20240902)
+    nl = pd.liquid_count
+    pos = pd.pos.to_numpy()
+    c = pos[:nl].mean(0, dtype=np.float64)
+    pos[:nl] = (c + factor * (pos[:nl].astype(np.float64) - c) + rng.uniform(-0.1, 0.1, (nl, 3)) * ref.particleRadius).astype(np.float32)
+    pd.pos.from_numpy(pos)
+    x, y, z = (pos[:nl, k].astype(np.float64) for k in range(3))
+    vel = 0.3 * np.stack([np.sin(3.0 * y), np.cos(2.0 * x + z) - 0.3, np.sin(x - 2.0 * z)], 1)
+    (vel_field if vel_field is not None else ref.vel).from_numpy(vel.astype(np.float32))
+    out["vel0"] = vel.astype(np.float32)
+    out["squeeze"] = np.float64(factor)
+
+
+def run_iisph(steps):
+    os.chdir(REF)
+    import taichi as ti
+    t0 = time.time()
+    import iisph as ref                 # builds the scene (8000 + model/box_boundry.obj), reset_param()
+    pd = ref.particle_data
+    _name_fields(ti, ref, pd, pd.hash_grid)
+    out = {}
+    squeeze(ref, pd, out)
+    out.update({"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
+                "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()})
+    print("scene: %d liquid + %d solid (%.0f s)" % (pd.liquid_count, pd.solid_count, time.time() - t0), flush=True)
+    for step in range(steps):
+        def snap(tag, **f):
+            for k, v in f.items():
+                out["s%d_%s_%s" % (step, tag, k)] = v.to_numpy() if hasattr(v, "to_numpy") else np.asarray(v)
+            print("  step %d %-12s %.0f s" % (step, tag, time.time() - t0), flush=True)
+        # ---- iisph.py:419-427 ----
+        pd.hash_grid.update_grid()
+        snap("grid", neighborCount=pd.hash_grid.neighborCount)
+        ref.compute_density()
+        snap("density", rho=ref.rho)
+        ref.compute_nonpressure_force()
+        snap("nonpressure", d_vel=ref.d_vel, vel_guess=ref.vel_guess, vs_iter=np.int32(ref.vs_iter), cg_delta=ref.cg_delta, cg_delta_zero=ref.cg_delta_zero)
+        ref.compute_advection()
+        snap("advection", d_ii=ref.d_ii, a_ii=ref.a_ii, adv_rho=ref.adv_rho, vel=ref.vel)
+        ref.solve_pressure()
+        snap("pressure", pressure=ref.pressure, dij_pj=ref.dij_pj, pr_iter=np.int32(ref.pr_iter), avg_density_err=ref.avg_density_err)
+        ref.update_pos()
+        snap("end", pos=pd.pos, vel=ref.vel, d_vel=ref.d_vel, deltaT=ref.deltaT)
+    out["steps"] = np.int32(steps)
+    out["oob_reads"] = np.array(["%s=%d" % kv for kv in sorted(ti.oob_reads.items())] or ["none"])
+    return out
+
+
+def run_pcisph(steps):
+    os.chdir(REF)
+    import taichi as ti
+    t0 = time.time()
+    import pcisph as ref                # builds its own scene (20^3 lattice + 40^3 lattice shell), GetPciCoff(), reset_param()
+    pd = ref.particle_data
+    _name_fields(ti, ref, pd, pd.hash_grid)
+    out = {"pci_coff": np.float64(ref.pci_coff)}
+    squeeze(ref, pd, out)
+    out.update({"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
+                "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()})
+    print("scene: %d liquid + %d solid, pci_coff %r (%.0f s)" % (pd.liquid_count, pd.solid_count, ref.pci_coff, time.time() - t0), flush=True)
+    for step in range(steps):
+        def snap(tag, **f):
+            for k, v in f.items():
+                out["s%d_%s_%s" % (step, tag, k)] = v.to_numpy() if hasattr(v, "to_numpy") else np.asarray(v)
+            print("  step %d %-12s %.0f s" % (step, tag, time.time() - t0), flush=True)
+        # ---- pcisph.py:307-311 ----
+        pd.hash_grid.update_grid()
+        snap("grid", neighborCount=pd.hash_grid.neighborCount)
+        ref.compute_nonpressure_force()
+        snap("nonpressure", rho=ref.rho, d_vel=ref.d_vel)
+        ref.sovel_pressure()
+        snap("pressure", adv_rho=ref.adv_rho, pressure=ref.pressure, d_vel_pre=ref.d_vel_pre, rho_err=ref.rho_err, pr_iter=np.int32(ref.pr_iter))
+        ref.update_pos()
+        snap("end", pos=pd.pos, vel=ref.vel, deltaT=ref.deltaT)
+    out["steps"] = np.int32(steps)
+    out["oob_reads"] = np.array(["%s=%d" % kv for kv in sorted(ti.oob_reads.items())] or ["none"])
+    return out
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else (2 if which.startswith("dfsph") else 1)
-    res = run_dfsph(steps, which == "dfsph_perturbed") if which.startswith("dfsph") else run_sesph(steps)
+    if which.startswith("dfsph"):
+        res = run_dfsph(steps, which == "dfsph_perturbed")
+    elif which == "iisph":
+        res = run_iisph(steps)
+    elif which == "pcisph":
+        res = run_pcisph(steps)
+    else:
+        res = run_sesph(steps)
     path = os.path.join(HERE, "ref_%s_default_scene.npz" % which)
     np.savez_compressed(path, **res)
     print("wrote", path, os.path.getsize(path), "bytes")
