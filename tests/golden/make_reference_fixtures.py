@@ -5,7 +5,6 @@
     python tests/golden/make_reference_fixtures.py dfsph_perturbed  ->  tests/golden/ref_dfsph_perturbed_default_scene.npz
     python tests/golden/make_reference_fixtures.py sesph            ->  tests/golden/ref_sesph_default_scene.npz
     python tests/golden/make_reference_fixtures.py iisph            ->  tests/golden/ref_iisph_default_scene.npz    (squeezed state)
-    python tests/golden/make_reference_fixtures.py pcisph           ->  tests/golden/ref_pcisph_default_scene.npz   (squeezed state)
 
 `dfsph` starts from the script's own rest state, where most neighbour sums are identically zero for the first steps
 (v = 0, omega = 0).  `dfsph_perturbed` is the same imported script with a non-trivial STATE written into its fields
@@ -191,36 +190,10 @@ def run_iisph(steps):
     return out
 
 
-def run_pcisph(steps):
-    os.chdir(REF)
-    import taichi as ti
-    t0 = time.time()
-    import pcisph as ref                # builds its own scene (20^3 lattice + 40^3 lattice shell), GetPciCoff(), reset_param()
-    pd = ref.particle_data
-    _name_fields(ti, ref, pd, pd.hash_grid)
-    out = {"pci_coff": np.float64(ref.pci_coff)}
-    squeeze(ref, pd, out)
-    out.update({"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
-                "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()})
-    print("scene: %d liquid + %d solid, pci_coff %r (%.0f s)" % (pd.liquid_count, pd.solid_count, ref.pci_coff, time.time() - t0), flush=True)
-    for step in range(steps):
-        def snap(tag, **f):
-            for k, v in f.items():
-                out["s%d_%s_%s" % (step, tag, k)] = v.to_numpy() if hasattr(v, "to_numpy") else np.asarray(v)
-            print("  step %d %-12s %.0f s" % (step, tag, time.time() - t0), flush=True)
-        # ---- pcisph.py:307-311 ----
-        pd.hash_grid.update_grid()
-        snap("grid", neighborCount=pd.hash_grid.neighborCount)
-        ref.compute_nonpressure_force()
-        snap("nonpressure", rho=ref.rho, d_vel=ref.d_vel)
-        ref.sovel_pressure()
-        snap("pressure", adv_rho=ref.adv_rho, pressure=ref.pressure, d_vel_pre=ref.d_vel_pre, rho_err=ref.rho_err, pr_iter=np.int32(ref.pr_iter))
-        ref.update_pos()
-        snap("end", pos=pd.pos, vel=ref.vel, deltaT=ref.deltaT)
-    out["steps"] = np.int32(steps)
-    out["oob_reads"] = np.array(["%s=%d" % kv for kv in sorted(ti.oob_reads.items())] or ["none"])
-    return out
-
+# pcisph.py cannot be pinned this way: its compute_nonpressure_force divides by rho[j] inside the loop that is still
+# writing rho (pcisph.py:212-213, Q19) -- serially rho[j] is 0 for every j > i and the sums become inf / NaN, under Taichi
+# it is a data race -- and update_iter_info stores to rho_err[i] for every i of a shape-(1) field (pcisph.py:234).  Tried
+# in round 3; the library's pcisph stays checked against the oracle only (tests/test_gpu_pcisph_iisph.py).
 
 if __name__ == "__main__":
     which = sys.argv[1]
@@ -229,8 +202,6 @@ if __name__ == "__main__":
         res = run_dfsph(steps, which == "dfsph_perturbed")
     elif which == "iisph":
         res = run_iisph(steps)
-    elif which == "pcisph":
-        res = run_pcisph(steps)
     else:
         res = run_sesph(steps)
     path = os.path.join(HERE, "ref_%s_default_scene.npz" % which)
