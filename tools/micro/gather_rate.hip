@@ -21,7 +21,7 @@ __device__ inline int pat(int P, int lane, int it, int nrec) {
   else r = lane;
   return r & (nrec - 1);
 }
-template <int W, int STRIDE, int P, bool LDS>
+template <int W, int STRIDE, int P, bool LDS, int ACTIVE = 64>
 __global__ void __launch_bounds__(256) k(const char *buf, float *out, int iters) {
   __shared__ __attribute__((aligned(16))) char sh[8192];
   const int nrec = 8192 / STRIDE >= 512 ? 512 : 256;   // records in the region (power of two)
@@ -29,6 +29,9 @@ __global__ void __launch_bounds__(256) k(const char *buf, float *out, int iters)
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
   typedef typename Vec<W>::T T;
+  // ACTIVE < 64: only lanes whose (lane * 37 & 63) < ACTIVE run the loop (scattered over the wave, like short lists among long ones);
+  // ACTIVE < 0: the first -ACTIVE lanes (a contiguous prefix)
+  if (ACTIVE > 0 ? ((lane * 37) & 63) >= ACTIVE : lane >= -ACTIVE) iters = 0;
   for (int it = 0; it < iters; it++) {
     T v[8];
 #pragma unroll
@@ -42,14 +45,14 @@ __global__ void __launch_bounds__(256) k(const char *buf, float *out, int iters)
   }
   if (acc == 12345.678f) out[0] = acc;
 }
-template <int W, int STRIDE, int P, bool LDS>
+template <int W, int STRIDE, int P, bool LDS, int ACTIVE = 64>
 void run(const char *name, const char *buf, float *out) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 2000, blocks = 256 * 8;
   float ms = 0;
   for (int rep = 0; rep < 2; rep++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<W, STRIDE, P, LDS>), dim3(blocks), dim3(256), 0, 0, buf, out, iters);
+    hipLaunchKernelGGL((k<W, STRIDE, P, LDS, ACTIVE>), dim3(blocks), dim3(256), 0, 0, buf, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
@@ -73,6 +76,16 @@ int main() {
   R(1, 4, 2, false, "L1 x1 stride 4  scattered");
   R(3, 16, 2, false, "L1 x3 stride 16 scattered");
   R(4, 16, 2, false, "L1 x4 stride 16 scattered");
+#define RA(W, S, P, L, A, n) run<W, S, P, L, A>(n, buf, out)
+  RA(4, 16, 1, false, 48, "L1 x4 brick, 48 lanes active (scattered)");
+  RA(4, 16, 1, false, 32, "L1 x4 brick, 32 lanes active (scattered)");
+  RA(4, 16, 1, false, 16, "L1 x4 brick, 16 lanes active (scattered)");
+  RA(4, 16, 1, false, 4, "L1 x4 brick,  4 lanes active (scattered)");
+  RA(4, 16, 1, false, -32, "L1 x4 brick, lanes 0..31 active");
+  RA(4, 16, 1, false, -16, "L1 x4 brick, lanes 0..15 active");
+  RA(4, 16, 2, false, 32, "L1 x4 scattered, 32 lanes active (scattered)");
+  RA(4, 16, 2, false, 16, "L1 x4 scattered, 16 lanes active (scattered)");
+  RA(4, 16, 1, true, 32, "LDS b128 brick, 32 lanes active (scattered)");
   R(1, 4, 0, true, "LDS b32  contiguous");
   R(2, 8, 0, true, "LDS b64  contiguous");
   R(3, 16, 0, true, "LDS b96  stride 16 contiguous");
