@@ -150,6 +150,64 @@ __device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int
   return r;
 }
 
+// ---- "once" accesses: data a launch touches exactly once and nobody gathers afterwards ---------------------------------
+// Non-temporal loads and stores do NOT allocate in the 256 MB Infinity Cache (tools/micro/mall_policy.hip,
+// profiles/r03n_mall_policy.txt: a 96 MB buffer survives a 900 MB nt sweep and is gone after a 320 MB plain one), so the
+// elementwise traffic of a step -- scratch vectors of the PCG, per-particle scalars, the sort's copies -- is kept from
+// displacing what the neighbour passes come back to launch after launch: the 16-bit neighbour streams and the gather
+// records.  Arrays that a following pass GATHERS (pos, vel, pk, pr, vel_guess, cg_dir, omega) stay on plain accesses.
+#ifndef WCSPH_ONCE
+#define WCSPH_ONCE 1
+#endif
+#ifndef WCSPH_ONCE_ST
+#define WCSPH_ONCE_ST WCSPH_ONCE
+#endif
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_once(const float4 *p) {
+#if WCSPH_ONCE
+  const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ float ld_once(const float *p) {
+#if WCSPH_ONCE
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ int ld_once(const int *p) {
+#if WCSPH_ONCE
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_once(float4 *p, float4 v) {
+#if WCSPH_ONCE_ST
+  v4f_nt w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<v4f_nt *>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_once(float *p, float v) {
+#if WCSPH_ONCE_ST
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_once(int *p, int v) {
+#if WCSPH_ONCE_ST
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // does this context own row i?  Without a decomposition every row is owned (n_owned == nl, wave-uniform): no oid read.
 __device__ __forceinline__ bool owned(const Dev &d, int i) { return d.n_owned >= d.nl || d.oid[i] < d.n_owned; }
 
@@ -384,19 +442,23 @@ __device__ __forceinline__ T nb_ld(const T *base, int j) {
   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)j * (unsigned)sizeof(T));
 }
 // a stream block, optionally non-temporal (see walk<.., NT>)
-template <bool NT>
+#ifndef WCSPH_STREAM_NT
+#define WCSPH_STREAM_NT 0   /* 1: the once-per-step passes load the stream non-temporally (rounds 1-2) */
+#endif
+template <int NT>
 __device__ __forceinline__ uint4 nb_stream(const uint4 *p) {
-  if (!NT) return *p;
+  if (!(NT == 2 || (NT == 1 && WCSPH_STREAM_NT))) return *p;
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 #define NB_LO(w) ((int)(short)((w) & 0xffffu))
 #define NB_HI(w) ((int)(w) >> 16)
-// NT: the stream is loaded non-temporally.  For passes that run once per step it keeps the stream from displacing the
-// gather records in L2 / Infinity Cache; the solver-loop passes leave it off, because the velocity pass and the
-// density-change pass of an iteration read the SAME 180 MB stream 50 us apart and the second finds it cached.
-template <int U, bool NT = false, class GL, class FL, class FS>
+// NT = 2: the stream is loaded non-temporally (the density pass, the first walk after the list build: measured 7 us
+// faster that way); NT = 1: only in builds with -DWCSPH_STREAM_NT=1 (rounds 1-2 loaded the stream of every once-per-step
+// pass non-temporally, to keep it from displacing the gather records; since round 3 the elementwise traffic is what
+// stays out of the Infinity Cache -- ld_once / st_once -- and every walk after the first finds the stream there).
+template <int U, int NT = 0, class GL, class FL, class FS>
 __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
   static_assert(U == 4 || U == 8, "U slots per trip");
   const float3 xi = xyz(pi);

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
   LOAD_I
   if (!own) return;
   float sl = 0.f, ss = 0.f;
-  walk<8, true>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
+  walk<8, 2>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
           [&](int, float3, float r2) { ss += cubic_W(d, r2); });
   const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
   d.rho[i] = rho;
@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(BLOCK) k_coff(Dev d) {
   if (!own) return;
   float3 sg = f3(0, 0, 0);
   float sq = 0.f;
-  walk<8, true>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8, 2>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             float g = cubic_gradW_scale(d, r2) * d.VL0;
             sq += g * g * r2;
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
   if (!own) return;
   float sl = 0.f, ss = 0.f, sq = 0.f;
   float3 sg = f3(0, 0, 0);
-  walk<8, true>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8, 2>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             sl += cubic_W(d, r2);
             float g = cubic_gradW_scale(d, r2) * d.VL0;
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
   float sl = 0.f, ss = 0.f, sq = 0.f, a = 0.f;
   float3 sg = f3(0, 0, 0);
   const float3 vi = xyz(d.vel[i]);
-  walk<8, true>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+  walk<8, 2>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
           [&](int, float3 r, float r2, float4 vj) {
             sl += cubic_W(d, r2);
             const float gw = cubic_gradW_scale(d, r2);
@@ -89,15 +89,15 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
             a += d.VS0 * gw * dot3(vi, r);
           });
   const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
-  d.rho[i] = rho;
+  st_once(d.rho + i, rho);
   d.pr[i] = make_float4(pi.x, pi.y, pi.z, rho);
   sq += dot3(sg, sg);
-  d.alpha[i] = (sq > d.eps) ? -1.0f / sq : 0.0f;
-  const float kv = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
-  d.kappa_v[i] = kv;
+  st_once(d.alpha + i, (sq > d.eps) ? -1.0f / sq : 0.0f);
+  const float kv = 0.5f * fmaxf(ld_once(d.kappa_v + i) / dt, -0.5f * d.rho_L0 * d.rho_L0);
+  st_once(d.kappa_v + i, kv);
   a = fmaxf(a, 0.0f);
-  if (d.ncount[i] < 20) a = 0.0f;  // raw list length, Q2
-  d.adv_rho[i] = a;
+  if (ld_once(d.ncount + i) < 20) a = 0.0f;  // raw list length, Q2
+  st_once(d.adv_rho + i, a);
   d.pk[i] = make_float4(pi.x, pi.y, pi.z, kv);
 }
 
@@ -113,16 +113,16 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_div(Dev d, float dt) {
   LOAD_I
   float a = 0.f;
   if (own) {
-    if (MODE == DRHO_WARM) d.kappa_v[i] = 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0);
+    if (MODE == DRHO_WARM) st_once(d.kappa_v + i, 0.5f * fmaxf(ld_once(d.kappa_v + i) / dt, -0.5f * d.rho_L0 * d.rho_L0));
     const float3 vi = xyz(d.vel[i]);
     walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
             [&](int, float3 r, float r2, float4 vj) { a += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
             [&](int, float3 r, float r2) { a += d.VS0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
     a = fmaxf(a, 0.0f);
-    if (d.ncount[i] < 20) a = 0.0f;  // raw list length, Q2
-    d.adv_rho[i] = a;
-    float al = d.alpha[i];
-    if (MODE == DRHO_BEGIN) { al = al / dt; d.alpha[i] = al; d.kappa_v[i] = 0.0f; }
+    if (ld_once(d.ncount + i) < 20) a = 0.0f;  // raw list length, Q2
+    st_once(d.adv_rho + i, a);
+    float al = ld_once(d.alpha + i);
+    if (MODE == DRHO_BEGIN) { al = al / dt; st_once(d.alpha + i, al); st_once(d.kappa_v + i, 0.0f); }
     if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * al);
   }
   if (MODE == DRHO_ITER) block_accumulate(ACC_SLOT(d, ACC_ERR), a);  // ref: dfsph.py:476 avg_density_err += adv_rho
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
   float a = 0.f;
   if (own) {
     const float3 vi = xyz(d.vel[i]), wi = xyz(d.omega[i]);
-    const float rhoi = d.rho[i];
+    const float rhoi = ld_once(d.rho + i);
     float3 dom = f3(0, 0, 0), dv = f3(0, 0, 0);
     const float c1 = -1.0f / dt * d.vort_init * d.visc_omega * d.mass;
     const float c2 = d.vort_coff / rhoi * d.mass;
@@ -160,14 +160,14 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
               dv = dv + cross3(wi, r) * (d.vort_coff / rhoi * d.rho_L0 * d.VS0 * g);
               dom = dom + cross3(vi, r) * (d.vort_coff / rhoi * d.vort_init * d.rho_L0 * d.VL0 * g);
             });
-    const int nc = d.ncount[i];
+    const int nc = ld_once(d.ncount + i);
     a = fmaxf(a, 0.0f);
     if (nc < 20) a = 0.0f;  // raw list length, Q2
-    d.adv_rho[i] = a;
-    d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * d.alpha[i]);
+    st_once(d.adv_rho + i, a);
+    d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * ld_once(d.alpha + i));
     dom = dom + wi * (-2.0f * d.vort_init * d.vort_coff * (float)nc);
-    d.d_omega[i] = f4(dom, 0);
-    d.cg_s[i] = f4(dv, 0);
+    st_once(d.d_omega + i, f4(dom, 0));
+    st_once(d.cg_s + i, f4(dv, 0));
   }
   block_accumulate(ACC_SLOT(d, ACC_ERR), a);  // ref: dfsph.py:476 avg_density_err += adv_rho
 }
@@ -192,11 +192,13 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
     walk<8>(d, i, pi, REC ? d.pk : d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
             [&](int, float3 r, float r2, float4 vj) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi - xyz(vj), r); },
             [&](int, float3 r, float r2) { t += d.VL0 * cubic_gradW_scale(d, r2) * dot3(vi, r); });
-    float a = fmaxf(1.0f, d.rho[i] / d.rho_L0 + dt * t);
-    d.adv_rho[i] = a;
+    // REC (the solver loop): rho, alpha, adv_rho belong to the loop's cache-resident working set; elsewhere they are
+    // touched once
+    float a = fmaxf(1.0f, (REC ? d.rho[i] : ld_once(d.rho + i)) / d.rho_L0 + dt * t);
+    if (REC) d.adv_rho[i] = a; else st_once(d.adv_rho + i, a);
     e = a - 1.0f;
-    float al = d.alpha[i];
-    if (MODE == DRHO_BEGIN) { al = al / dt / dt; d.alpha[i] = al; d.kappa[i] = 0.0f; }
+    float al = REC ? d.alpha[i] : ld_once(d.alpha + i);
+    if (MODE == DRHO_BEGIN) { al = al / dt / dt; d.alpha[i] = al; st_once(d.kappa + i, 0.0f); }
     if (REC) reinterpret_cast<float *>(d.pk + i)[3] = e * al;
     else if (FUSEK) d.pk[i] = make_float4(pi.x, pi.y, pi.z, e * al);
   }
@@ -245,10 +247,10 @@ __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, f
   if (d.n_owned < d.nl || d.part_mode != 0) {
     if (!(owned(d, i) && part_ok(d, d.pos[i]))) return;
   }
-  if (COND == 1 && !(d.adv_rho[i] > 0.0f)) return;
+  if (COND == 1 && !(ld_once(d.adv_rho + i) > 0.0f)) return;
   const float4 pi = pk[i];
   const float ki = pi.w;
-  if (kap) kap[i] += ki;
+  if (kap) st_once(kap + i, ld_once(kap + i) + ki);
   float3 acc = f3(0, 0, 0);
   const bool ks = fabsf(ki) > d.eps;
   walk<8>(d, i, pi, pk, [](int, float4 p) { return p.w; },
@@ -368,12 +370,12 @@ __global__ void __launch_bounds__(BLOCK) k_tension_accel(Dev d) {
 // ref: dfsph.py:181-195 get_viscosity_Ax
 __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const float4 *x, float dt) {
   const float3 xi = xyz(x[i]);
-  const float rhoi = d.rho[i];
+  const float rhoi = ld_once(d.rho + i);
   const float e = 0.01f * d.h2;
   float3 ret = f3(0, 0, 0);
   const float cl = d.dim_coff * d.visc * d.mass;
   const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
-  walk<8, true>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(x, j); xj.w = p.w; return xj; },
+  walk<8, 1>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(x, j); xj.w = p.w; return xj; },
           [&](int, float3 r, float r2, float4 xj) {
             float s = cl * dot3(xi - xyz(xj), r) * frcp(xj.w * (r2 + e));
             ret = ret + r * (s * cubic_gradW_scale(d, r2));
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
     m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
     m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
   };
-  walk<8, true>(d, i, pi, d.pr, [](int, float4 p) { return p.w; },
+  walk<8, 1>(d, i, pi, d.pr, [](int, float4 p) { return p.w; },
           [&](int, float3 r, float r2, float rhoj) { accum(r, cl * frcp(rhoj * (r2 + e)) * cubic_gradW_scale(d, r2)); },
           [&](int, float3 r, float r2) { accum(r, cs * frcp(r2 + e) * cubic_gradW_scale(d, r2)); });
   const float f = dt / rhoi;
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
   d.minv2[i] = make_float4(C * id, i12, i22, 0);
 }
 __device__ __forceinline__ float3 minv_mul(const Dev &d, int i, float3 v) {
-  float4 r0 = d.minv0[i], r1 = d.minv1[i], r2 = d.minv2[i];
+  float4 r0 = ld_once(d.minv0 + i), r1 = ld_once(d.minv1 + i), r2 = ld_once(d.minv2 + i);
   return f3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
 }
 // ref: dfsph.py:217-223: r = v - A(v_guess); d = Minv r; delta_zero = sum r.d
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
   LOAD_I
   float part = 0.f;
   if (own) {
-    const float rhoi = d.rho[i];
+    const float rhoi = ld_once(d.rho + i);
     const float e = 0.01f * d.h2;
     const float cl = d.dim_coff * d.visc * d.mass;
     const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
       m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
       m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
     };
-    walk<8, true>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(d.vel_guess, j); xj.w = p.w; return xj; },
+    walk<8, 1>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(d.vel_guess, j); xj.w = p.w; return xj; },
             [&](int, float3 r, float r2, float4 xj) {
               const float c = cl * cubic_gradW_scale(d, r2) * frcp(xj.w * (r2 + e));
               accum(r, c);
@@ -471,11 +473,11 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
     float id = 1.0f / (a * A + b * B + c * C);
     float i11 = (a * ff - c * c) * id, i12 = -(a * ee - c * b) * id, i22 = (a * dd - b * b) * id;
     const float4 r0 = make_float4(A * id, B * id, C * id, 0), r1 = make_float4(B * id, i11, i12, 0), r2 = make_float4(C * id, i12, i22, 0);
-    d.minv0[i] = r0; d.minv1[i] = r1; d.minv2[i] = r2;
-    const float3 res = xyz(d.vel[i]) - (xi - ret * f);
+    st_once(d.minv0 + i, r0); st_once(d.minv1 + i, r1); st_once(d.minv2 + i, r2);
+    const float3 res = xyz(ld_once(d.vel + i)) - (xi - ret * f);
     const float3 dir = f3(r0.x * res.x + r0.y * res.y + r0.z * res.z, r1.x * res.x + r1.y * res.y + r1.z * res.z,
                           r2.x * res.x + r2.y * res.y + r2.z * res.z);
-    d.cg_r[i] = f4(res, 0);
+    st_once(d.cg_r + i, f4(res, 0));
     d.cg_dir[i] = f4(dir, 0);
     part = dot3(res, dir);
   }
@@ -506,7 +508,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float 
     const float c2 = d.vort_coff / rhoi * d.mass;
     const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
     struct XVW { float4 x, v, w; };
-    walk<4, true>(d, i, pi, d.pr, [&](int j, float4 p) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = p.w; q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
+    walk<4, 1>(d, i, pi, d.pr, [&](int j, float4 p) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = p.w; q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
             [&](int, float3 r, float r2, XVW q) {
               const float g = cubic_gradW_scale(d, r2);
               const float irho = frcp(q.x.w);
@@ -553,7 +555,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
   float part = 0.f;
   if (own) {
     float3 ad = visc_Ax(d, i, pi, d.cg_dir, dt);
-    d.cg_Ad[i] = f4(ad, 0);
+    st_once(d.cg_Ad + i, f4(ad, 0));
     part = dot3(xyz(d.cg_dir[i]), ad);
   }
   block_accumulate(ACC_SLOT(d, ACC_DAD), part);
@@ -569,11 +571,11 @@ __global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta, int f
   if (i < d.nl && owned(d, i)) {
     const float alpha = delta / (float)((double)d.eps + dAd);
     float3 dir = xyz(d.cg_dir[i]);
-    d.vel_guess[i] = f4(xyz(d.vel_guess[i]) + dir * alpha, 0);
-    float3 r = xyz(d.cg_r[i]) - xyz(d.cg_Ad[i]) * alpha;
+    st_once(d.vel_guess + i, f4(xyz(ld_once(d.vel_guess + i)) + dir * alpha, 0));
+    float3 r = xyz(ld_once(d.cg_r + i)) - xyz(ld_once(d.cg_Ad + i)) * alpha;
     float3 s = minv_mul(d, i, r);
-    d.cg_r[i] = f4(r, 0);
-    d.cg_s[i] = f4(s, 0);
+    st_once(d.cg_r + i, f4(r, 0));
+    st_once(d.cg_s + i, f4(s, 0));
     part = dot3(r, s);
   }
   block_accumulate(ACC_SLOT(d, ACC_DNEW), part);
@@ -586,7 +588,7 @@ __global__ void k_visc_dir(Dev d, float delta_old, int from_dzero = 0) {
   acc_clear(ACC_SLOT(d, ACC_DAD));     // read by k_visc_update (finished); the next k_visc_Ad sums into it
   if (i >= d.nl || !owned(d, i)) return;
   const float beta = (float)dnew / delta_old;
-  d.cg_dir[i] = f4(xyz(d.cg_s[i]) + xyz(d.cg_dir[i]) * beta, 0);
+  d.cg_dir[i] = f4(xyz(ld_once(d.cg_s + i)) + xyz(d.cg_dir[i]) * beta, 0);
 }
 // ref: dfsph.py:339-343 end_viscosity
 __global__ void k_visc_end(Dev d, float dt) {
@@ -611,7 +613,7 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
   const float c2 = d.vort_coff / rhoi * d.mass;
   const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
   struct WV { float4 w, v; };
-  walk<4, true>(d, i, pi, d.pr, [&](int j, float4 q) { WV p; p.w = nb_ld(d.omega, j); p.w.w = q.w; p.v = nb_ld(d.vel, j); return p; },
+  walk<4, 1>(d, i, pi, d.pr, [&](int j, float4 q) { WV p; p.w = nb_ld(d.omega, j); p.w.w = q.w; p.v = nb_ld(d.vel, j); return p; },
        [&](int, float3 r, float r2, WV pj) {
          float3 dw = wi - xyz(pj.w);
          float g = cubic_gradW_scale(d, r2);
@@ -682,20 +684,20 @@ __global__ void __launch_bounds__(BLOCK) k_finish_nonpressure(Dev d, float dt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float vm = 0.f;
   if (i < d.nl) {
-    const int o = d.oid[i];
-    const float3 v = xyz(d.vel[i]);
-    float3 a = xyz(d.d_vel[i]);
+    const int o = ld_once(d.oid + i);
+    const float3 v = xyz(ld_once(d.vel + i));
+    float3 a = xyz(ld_once(d.d_vel + i));
     if (o < d.n_owned) {
-      const float3 g = xyz(d.vel_guess[i]);
+      const float3 g = xyz(ld_once(d.vel_guess + i));
       a = a + (g - v) * (1.0f / dt);
-      d.d_vel[i] = f4(a, 0);
-      d.vel_guess[i] = f4(g - v, 0);
-      const float4 w = d.omega[i], dw = d.d_omega[i];
-      d.omega[i] = make_float4(w.x + dw.x * dt, w.y + dw.y * dt, w.z + dw.z * dt, 0);
+      st_once(d.d_vel + i, f4(a, 0));
+      st_once(d.vel_guess + i, f4(g - v, 0));
+      const float4 w = ld_once(d.omega + i), dw = ld_once(d.d_omega + i);
+      st_once(d.omega + i, make_float4(w.x + dw.x * dt, w.y + dw.y * dt, w.z + dw.z * dt, 0));
     }
     const float3 vn = v + a * dt;
     const float m = fmaxf(dot3(vn, vn), 0.1f);
-    d.vel_max[i] = m;
+    st_once(d.vel_max + i, m);
     if (o < d.n_owned && (d.gid ? d.gid[o] : o) < d.cfl_prefix) vm = m;
   }
 #pragma unroll
@@ -733,28 +735,28 @@ __global__ void k_end_div_begin_nonpressure(Dev d, float dt, int vort) {
   acc_clear(ACC_SLOT(d, ACC_DAD));
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl) return;
-  if (owned(d, i)) { d.kappa_v[i] *= dt; d.alpha[i] *= dt; }
+  if (owned(d, i)) { st_once(d.kappa_v + i, ld_once(d.kappa_v + i) * dt); st_once(d.alpha + i, ld_once(d.alpha + i) * dt); }
   float4 a = make_float4(d.gx, d.gy, d.gz, 0);
-  if (vort) { const float4 dv = d.cg_s[i]; a.x += dv.x; a.y += dv.y; a.z += dv.z; }
-  d.d_vel[i] = a;
-  float4 g = d.vel_guess[i], v = d.vel[i];
-  d.vel_guess[i] = make_float4(g.x + v.x, g.y + v.y, g.z + v.z, 0);
+  if (vort) { const float4 dv = ld_once(d.cg_s + i); a.x += dv.x; a.y += dv.y; a.z += dv.z; }
+  st_once(d.d_vel + i, a);
+  float4 g = ld_once(d.vel_guess + i), v = d.vel[i];
+  d.vel_guess[i] = make_float4(g.x + v.x, g.y + v.y, g.z + v.z, 0);   // gathered by the viscosity walk launched next
 }
 // update_vel (dfsph.py:572-575) + the kappa rescale that opens warmstart_pressure (:490)
 __global__ void k_update_vel_warm_scale(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || !owned(d, i)) return;
-  float4 v = d.vel[i], a = d.d_vel[i];
-  d.vel[i] = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);
-  d.kappa[i] = fmaxf(d.kappa[i] / dt / dt, -0.5f * d.rho_L0 * d.rho_L0);
+  float4 v = ld_once(d.vel + i), a = ld_once(d.d_vel + i);
+  d.vel[i] = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);   // gathered by the pressure solve
+  st_once(d.kappa + i, fmaxf(ld_once(d.kappa + i) / dt / dt, -0.5f * d.rho_L0 * d.rho_L0));
 }
 // end of solve_pressure (dfsph.py:549-552) + update_pos (:577-580)
 __global__ void k_end_press_update_pos(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || !owned(d, i)) return;
-  d.kappa[i] *= dt * dt;
-  float4 p = d.pos[i], v = d.vel[i];
-  d.pos[i] = make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w);
+  st_once(d.kappa + i, ld_once(d.kappa + i) * (dt * dt));
+  float4 p = ld_once(d.pos + i), v = ld_once(d.vel + i);
+  st_once(d.pos + i, make_float4(p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt, p.w));   // the sort reads it once
 }
 
 // ---- sesph.py (ref: sesph.py:130-196); Dev.h/ml_h3/mk_h3 hold the script's private kernel constants --

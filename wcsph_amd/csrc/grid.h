@@ -48,14 +48,14 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
   if (i < n) {
-    float4 p = pos[i];
+    float4 p = ld_once(pos + i);
     int lin;
     bool finite;
     int w = cell_packed(d, xyz(p), &lin, &finite);
     // the reference's only failure check is a NaN position (dfsph.py:645-647, one particle); here every particle, every step
     if (!finite) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NONFINITE);
-    pw[i] = w;
-    slot[i] = atomicAdd(&cnt[lin], 1);
+    st_once(pw + i, w);
+    st_once(slot + i, atomicAdd(&cnt[lin], 1));
     if (w >= 0) {
       // reference bucket occupancy: every particle is counted ONCE across the ranks of a slab decomposition -- liquid
       // particles by their owner (ghost rows sit behind the owned ones before the sort), boundary particles by the rank
@@ -126,18 +126,21 @@ struct SortBuffers {
 __global__ void k_scatter_liquid(Dev d, SortBuffers b, const int *cs, const int *pw, const int *slot) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl) return;
-  int w = pw[i];
-  int dst = cs[lin_of(d, w)] + slot[i];
-  float4 p = b.pos[i];
+  int w = ld_once(pw + i);
+  int dst = cs[lin_of(d, w)] + ld_once(slot + i);
+  float4 p = ld_once(b.pos + i);
   p.w = __int_as_float(w);
+  // the sources are read once, in order: non-temporal.  The destinations are scattered (a particle that changed its
+  // cell lands elsewhere): plain stores, which the L2 merges into whole lines -- non-temporal ones cost this kernel
+  // +60 % in the developed flow (profiles/r03n_ab_once.md)
   b.pos_o[dst] = p;
-  b.vel_o[dst] = b.vel[i];
-  b.vel_guess_o[dst] = b.vel_guess[i];
-  b.omega_o[dst] = b.omega[i];
-  b.kappa_o[dst] = b.kappa[i];
-  b.kappa_v_o[dst] = b.kappa_v[i];
-  b.pressure_o[dst] = b.pressure[i];
-  int o = b.oid[i];
+  b.vel_o[dst] = ld_once(b.vel + i);
+  b.vel_guess_o[dst] = ld_once(b.vel_guess + i);
+  b.omega_o[dst] = ld_once(b.omega + i);
+  b.kappa_o[dst] = ld_once(b.kappa + i);
+  b.kappa_v_o[dst] = ld_once(b.kappa_v + i);
+  b.pressure_o[dst] = ld_once(b.pressure + i);
+  int o = ld_once(b.oid + i);
   b.oid_o[dst] = o;
   b.where[o] = dst;
 }
