@@ -19,11 +19,14 @@ struct BucketTab {
   int *item;      // [n_liquid + n_solid]
   int *cursor;    // [T] scatter cursors
   int *swhere;    // [n_solid] original solid index -> sorted solid index
-  // derived per step for the kernels that walk whole rows (compute_tension literally): the same items as SORTED indices
-  // (bit 31: boundary particle), and per cell of the grid the slice of its bucket -- so that a row walk is
-  // 25 short z-runs of (start, count) pairs + one indirection per entry instead of 125 hashes and three
-  int *item_s;    // [n_liquid + n_solid]
-  int2 *cellb;    // [ncell, plain (x, y, z) index] (first item, count) of bucket hash(cell); valid within 2 cells of the liquid
+  // derived per step for the kernels that walk whole rows (compute_tension literally): the items of every cell's bucket
+  // once more, as SORTED indices (bit 31: boundary particle), laid out in plain (x, y, z) CELL order -- the five cells of
+  // one (x, y) column of a row are then ONE contiguous run [coff[c(za)], coff[c(zb) + 1]), neighbouring lanes read
+  // neighbouring runs, and a row walk is 25 runs + one record gather per entry instead of 125 hashes, 125 slices
+  // scattered all over the table by the hash, and two dependent look-ups per entry
+  int *coff;      // [ncell + 1] exclusive offsets into citem; cells further than 2 from the liquid's box are empty
+  int *citem;     // [citem_cap]
+  int citem_cap;
 };
 #define BK_SOLID 0x80000000u
 
@@ -61,44 +64,79 @@ __global__ void k_bk_sort(Dev d, BucketTab b) {   // one thread per bucket: inse
   }
 }
 
-__global__ void k_bk_items_sorted(Dev d, BucketTab b) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= b.start[d.table_size]) return;
-  const int g = b.item[s];
-  b.item_s[s] = g < d.nl ? d.where[g] : (int)((unsigned)b.swhere[g - d.nl] | BK_SOLID);
-}
-__global__ void k_bk_cellstart(Dev d, BucketTab b) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;   // plain index
-  if (c >= d.ncell) return;
+// coff (before its scan): the length of cell c's bucket, for the cells within 2 of the liquid's box (plain cell index)
+__device__ __forceinline__ int bk_cell_bucket(const Dev &d, int c, bool *inbox) {
   const int *bb = d.bbox;
-  if (bb[3] < 0) return;
   const int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
-  if (cx < bb[0] - 2 || cx > bb[3] + 2 || cy < bb[1] - 2 || cy > bb[4] + 2 || cz < bb[2] - 2 || cz > bb[5] + 2) return;
-  const int h = ref_hash(cx + d.x0, cy, cz, d.table_size);
-  const int lo = b.start[h];
-  b.cellb[c] = make_int2(lo, b.start[h + 1] - lo);
+  *inbox = bb[3] >= 0 && !(cx < bb[0] - 2 || cx > bb[3] + 2 || cy < bb[1] - 2 || cy > bb[4] + 2 || cz < bb[2] - 2 || cz > bb[5] + 2);
+  return ref_hash(cx + d.x0, cy, cz, d.table_size);
 }
-// the raw row of liquid particle i through the per-cell slices: f(js) for every entry in the reference's order (REV: in
-// exactly the reverse order; f returns false to stop), js = sorted index | BK_SOLID
-template <bool REV, class F>
-__device__ __forceinline__ void raw_row_s(const Dev &d, const BucketTab &b, int i, float4 pi, F &&f) {
+__global__ void k_bk_cellcount(Dev d, BucketTab b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > d.ncell) return;
+  int n = 0;
+  if (c < d.ncell) {
+    bool in;
+    const int h = bk_cell_bucket(d, c, &in);
+    if (in) n = b.start[h + 1] - b.start[h];
+  }
+  b.coff[c] = n;
+}
+// after the scan: copy every cell's bucket behind its offset, as sorted indices
+__global__ void k_bk_cellfill(Dev d, BucketTab b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.ncell) return;
+  bool in;
+  const int h = bk_cell_bucket(d, c, &in);
+  if (!in) return;
+  const int lo = b.start[h], n = b.start[h + 1] - lo, o = b.coff[c];
+  if (n > 0 && o + n > b.citem_cap) { atomicOr(&d.flags[FLAG_ERR], ERRBIT_ROWITEMS); return; }
+  for (int k = 0; k < n; k++) {
+    const int g = b.item[lo + k];
+    b.citem[o + k] = g < d.nl ? d.where[g] : (int)((unsigned)b.swhere[g - d.nl] | BK_SOLID);
+  }
+}
+// the raw row of liquid particle i through the cell-ordered item runs, in the reference's order (REV: in exactly the
+// reverse order): use(js, ld(js)) for every entry but the particle itself, js = sorted index | BK_SOLID; use returns
+// false to stop.  Per (x, y) column: one run, walked B entries at a time -- B item loads in flight, then B record loads
+// ld(js), then the B bodies in order -- and the bounds of the NEXT column's run are requested before the current one is
+// walked.  Loads past the end of a run re-read its first item and are discarded: no branch between the loads of a chunk.
+template <bool REV, int B, class LD, class F>
+__device__ __forceinline__ void raw_row_s(const Dev &d, const BucketTab &b, int i, float4 pi, LD &&ld, F &&use) {
   const int cw = __float_as_int(pi.w);
   if (cw < 0) return;
   const int cx = cw & 1023, cy = (cw >> 10) & 1023, cz = cw >> 20;
   const int za = max(cz - 2, 0), zb = min(cz + 2, d.nz - 1);
-#pragma unroll 1
-  for (int u = 0; u < 25; u++) {
+  auto column = [&](int u, int &lo, int &hi) {
     const int q = REV ? 24 - u : u;
     const int x = cx + q / 5 - 2, y = cy + q % 5 - 2;
-    if ((unsigned)x >= (unsigned)d.nx || (unsigned)y >= (unsigned)d.ny) continue;
-    const int2 *row = b.cellb + (size_t)(x * d.ny + y) * d.nz;
-    int2 sc[5];
+    const bool in = u < 25 && (unsigned)x < (unsigned)d.nx && (unsigned)y < (unsigned)d.ny;
+    const int *col = b.coff + (size_t)((in ? x : cx) * d.ny + (in ? y : cy)) * d.nz;   // outside the grid: any valid address, emptied below
+    lo = col[za]; hi = col[zb + 1];
+    if (!in) hi = lo;
+  };
+  int nlo, nhi;
+  column(0, nlo, nhi);
+#pragma unroll 1
+  for (int u = 0; u < 25; u++) {
+    const int lo = nlo, hi = nhi, tot = hi - lo;
+    column(u + 1, nlo, nhi);
+#pragma unroll 1
+    for (int e0 = 0; e0 < tot; e0 += B) {
+      int js[B];
 #pragma unroll
-    for (int t = 0; t < 5; t++) { const int z = REV ? zb - t : za + t; sc[t] = (REV ? z >= za : z <= zb) ? row[z] : make_int2(0, 0); }
+      for (int k = 0; k < B; k++) {
+        const int e = e0 + k;
+        const int v = b.citem[REV ? hi - 1 - (e < tot ? e : e0) : lo + (e < tot ? e : e0)];
+        js[k] = e < tot ? v : i;   // i: skipped like the particle itself
+      }
+      decltype(ld(0)) rec[B];
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-      if (REV) { for (int s = sc[t].x + sc[t].y - 1; s >= sc[t].x; s--) { const int js = b.item_s[s]; if (js != i && !f(js)) return; } }
-      else { for (int s = sc[t].x; s < sc[t].x + sc[t].y; s++) { const int js = b.item_s[s]; if (js != i && !f(js)) return; } }
+      for (int k = 0; k < B; k++) rec[k] = ld(js[k]);   // unconditional (i is a valid index)
+#pragma unroll
+      for (int k = 0; k < B; k++) nb_pin(rec[k]);       // keep LLVM from sinking a load into the body that consumes it
+#pragma unroll
+      for (int k = 0; k < B; k++) if (js[k] != i && !use(js[k], rec[k])) return;
     }
   }
 }
@@ -162,21 +200,22 @@ __device__ __forceinline__ float3 bk_gradW(const Dev &d, float3 r) {
 // f32) -- the entries before that contribute exactly nothing to the reference's own f32 recurrence either.
 // Also leaves the (normal, rho) gather record of the second loop in cg_Ad (free until the viscosity solve).
 __global__ void __launch_bounds__(BLOCK) k_tension_normal_literal(Dev d, BucketTab b) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = sorted_index(d);   // XCD-aware: every L2 serves one spatial eighth (launched with PASS)
   if (i >= d.nl || !owned(d, i)) return;
   const float4 pi = d.pos[i];
   const float3 xi = xyz(pi);
   float3 n = f3(0, 0, 0);
   float scale = d.h;
-  raw_row_s<true>(d, b, i, pi, [&](int js) -> bool {
-    if (js >= 0) {
-      const float4 pj = d.pos[js];
-      const float3 gw = bk_gradW(d, xi - xyz(pj));
-      n = n + gw * (d.mass / d.rho[js] * scale);
-    }
-    scale *= d.h;
-    return scale > 0.0f;
-  });
+  raw_row_s<true, 8>(d, b, i, pi,
+    [&](int js) { float4 pj = make_float4(0, 0, 0, 1); if (js >= 0) { pj = nb_ld(d.pos, js); pj.w = nb_ld(d.rho, js); } return pj; },   // (pos_j, rho_j)
+    [&](int js, float4 pj) -> bool {
+      if (js >= 0) {
+        const float3 gw = bk_gradW(d, xi - xyz(pj));
+        n = n + gw * (d.mass / pj.w * scale);
+      }
+      scale *= d.h;
+      return scale > 0.0f;
+    });
   d.normal[i] = f4(n, 0);
   d.cg_Ad[i] = f4(n, d.rho[i]);
 }
@@ -184,19 +223,22 @@ __global__ void __launch_bounds__(BLOCK) k_tension_normal_literal(Dev d, BucketT
 // solid entries: adhesion inside the scene's 0.26 gate
 __device__ __forceinline__ float adhesion_W(const Dev &d, float r);
 __global__ void __launch_bounds__(BLOCK) k_tension_accel_literal(Dev d, BucketTab b) {
+  // plain block order (ELEM): the boundary entries are expensive and sit in one region -- with the XCD-contiguous order of
+  // the walks one XCD gets them all (817 -> 979 us at C5)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || !owned(d, i)) return;
   const float4 pi = d.pos[i];
   const float3 xi = xyz(pi), ni = xyz(d.normal[i]);
   const float rhoi = d.rho[i];
   float3 dv = xyz(d.d_vel[i]);
-  raw_row_s<false>(d, b, i, pi, [&](int js) -> bool {
+  raw_row_s<false, 8>(d, b, i, pi,
+    [&](int js) { return js >= 0 ? nb_ld(d.cg_Ad, js) : nb_ld(d.spos, js & 0x7fffffff); },   // (normal_j, rho_j) | boundary position
+    [&](int js, float4 nr) -> bool {
     if (js >= 0) {
-      const float4 nr = d.cg_Ad[js];        // (normal_j, rho_j)
       const float kij = 2.0f * d.rho_L0 / (rhoi + nr.w);
       dv = dv + (ni - xyz(nr)) * (-d.tension * kij);
     } else {
-      const float3 pj = xyz(d.spos[js & 0x7fffffff]);
+      const float3 pj = xyz(nr);
       const float3 r = xi - pj, c = pj - f3(0.0f, 0.5f, 0.0f);
       const float len2 = dot3(r, r), dis = sqrtf(dot3(c, c));
       if (len2 > d.eps && dis < 0.26f) {

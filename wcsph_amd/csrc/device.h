@@ -83,7 +83,7 @@ struct Dev {
 
 enum { ACC_ERR = 0, ACC_DAD = 1, ACC_DNEW = 2, ACC_DZERO = 3 };
 enum { FLAG_ERR = 0, FLAG_VMAX = 1 };
-enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2, ERRBIT_LISTCAP = 4, ERRBIT_NONFINITE = 8 };
+enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2, ERRBIT_LISTCAP = 4, ERRBIT_NONFINITE = 8, ERRBIT_ROWITEMS = 16 };
 
 __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
 __device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }

@@ -122,6 +122,7 @@ static int check_flags(wcsph_ctx *ctx) {
   if (f & ERRBIT_BUCKET) return ctx->fail(WCSPH_EBUCKET, "more than maxInGrid particles in one hash bucket (ref: HashGrid.py:72-74)");
   if (f & ERRBIT_NEIGH) return ctx->fail(WCSPH_ENEIGH, "more than maxNeighbour neighbour-list entries (ref: HashGrid.py:100-103)");
   if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "compact neighbour list capacity (wcsph_params.list_cap, default 256 slots of one kind) exceeded");
+  if (f & ERRBIT_ROWITEMS) return ctx->fail(WCSPH_EBUCKET, "raw-row item table of the literal compute_tension full (more than 2 bucket entries per grid cell on average)");
   if (f & ERRBIT_NONFINITE) return ctx->fail(WCSPH_ENONFINITE, "non-finite particle position (ref: dfsph.py:645-647)");
   return 0;
 }
@@ -536,9 +537,16 @@ static int bucket_build_rows(wcsph_ctx *ctx) {
   int rc = bucket_build(ctx);
   if (rc || ctx->bk_rows_valid) return rc;
   Dev &d = ctx->d;
-  if (!ctx->bk.item_s) { DALLOC(ctx->bk.item_s, (size_t)ctx->capacity + d.ns + 1); DALLOC(ctx->bk.cellb, (size_t)d.ncell); }
-  hipLaunchKernelGGL(k_bk_items_sorted, dim3(nblk(d.nl + d.ns)), dim3(BLOCK), 0, ctx->stream, d, ctx->bk);
-  hipLaunchKernelGGL(k_bk_cellstart, dim3(nblk(d.ncell)), dim3(BLOCK), 0, ctx->stream, d, ctx->bk);
+  if (!ctx->bk.coff) {
+    // every cell within 2 of the liquid's box holds a copy of its bucket: ~one item per cell while the table has about as
+    // many buckets as there are particles; twice the cell count is the cap (ERRBIT_ROWITEMS beyond)
+    ctx->bk.citem_cap = (int)std::min<size_t>((size_t)2 * d.ncell + 1024, (size_t)0x7ffffff0);
+    DALLOC(ctx->bk.coff, (size_t)d.ncell + SCAN_TILE + 2); DALLOC(ctx->bk.citem, (size_t)ctx->bk.citem_cap);
+  }
+  hipLaunchKernelGGL(k_bk_cellcount, dim3(nblk(d.ncell + 1)), dim3(BLOCK), 0, ctx->stream, d, ctx->bk);
+  rc = run_scan(ctx, ctx->bk.coff, d.ncell + 1, ctx->bk.coff, nullptr, 0);   // in place: a thread reads its eight counts before it writes them
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bk_cellfill, dim3(nblk(d.ncell)), dim3(BLOCK), 0, ctx->stream, d, ctx->bk);
   LAUNCHCHK();
   ctx->bk_rows_valid = true;
   return 0;
@@ -921,7 +929,7 @@ int wcsph_dfsph_tension(wcsph_ctx *ctx) {
   if (ctx->p.tension_fixed == 0) {   // the reference loop literally, over the raw bucket rows (bucket.h)
     int rc = bucket_build_rows(ctx);
     if (rc) return rc;
-    ELEM(k_tension_normal_literal, ctx->bk);
+    PASS(k_tension_normal_literal, ctx->bk);
     ELEM(k_tension_accel_literal, ctx->bk);
     return WCSPH_OK;
   }
@@ -1725,7 +1733,7 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     // tension_fixed = 0: the reference loop literally, over its raw bucket rows (bucket.h).  On a slab window the table
     // spans all ranks (far aliased entries name particles of other slabs): bucket_build refuses with a message.
     case WCSPH_PH_TENSION_NORMAL:
-      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build_rows(ctx))) return rc; ELEM(k_tension_normal_literal, ctx->bk); }
+      if (ctx->p.tension_fixed == 0) { if ((rc = bucket_build_rows(ctx))) return rc; PASS(k_tension_normal_literal, ctx->bk); }
       else RPASS(k_tension_normal);
       break;
     case WCSPH_PH_TENSION_ACCEL:
