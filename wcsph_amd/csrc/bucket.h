@@ -99,8 +99,8 @@ __global__ void k_bk_cellfill(Dev d, BucketTab b) {
 // the raw row of liquid particle i through the cell-ordered item runs, in the reference's order (REV: in exactly the
 // reverse order): use(js, ld(js)) for every entry but the particle itself, js = sorted index | BK_SOLID; use returns
 // false to stop.  Per (x, y) column: one run, walked B entries at a time -- B item loads in flight, then B record loads
-// ld(js), then the B bodies in order -- and the bounds of the NEXT column's run are requested before the current one is
-// walked.  Loads past the end of a run re-read its first item and are discarded: no branch between the loads of a chunk.
+// ld(js), then the B bodies in order.  Loads past the end of a run re-read its first item and are discarded: no branch
+// between the loads of a chunk.
 template <bool REV, int B, class LD, class F>
 __device__ __forceinline__ void raw_row_s(const Dev &d, const BucketTab &b, int i, float4 pi, LD &&ld, F &&use) {
   const int cw = __float_as_int(pi.w);
@@ -115,21 +115,33 @@ __device__ __forceinline__ void raw_row_s(const Dev &d, const BucketTab &b, int 
     lo = col[za]; hi = col[zb + 1];
     if (!in) hi = lo;
   };
-  int nlo, nhi;
-  column(0, nlo, nhi);
+  // software pipeline over the columns: while column u's records are in flight, the items of column u + 1 and the run
+  // bounds of column u + 2 are requested -- one exposed memory latency per column instead of three
+  auto items = [&](int lo, int hi, int e0, int (&js)[B]) {
+    const int tot = hi - lo;
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      const int e = e0 + k;
+      const int ec = e < tot ? e : (e0 < tot ? e0 : 0);          // past the end: a valid address (the run's first item, or
+      const int idx = tot > 0 ? (REV ? hi - 1 - ec : lo + ec) : 0;   // the table's first when the run is empty), discarded
+      const int v = b.citem[idx];
+      js[k] = e < tot ? v : i;   // i: skipped like the particle itself
+    }
+  };
+  int lo, hi, nlo, nhi;
+  column(0, lo, hi);
+  column(1, nlo, nhi);
+  int js[B], jn[B];
+  items(lo, hi, 0, js);
 #pragma unroll 1
   for (int u = 0; u < 25; u++) {
-    const int lo = nlo, hi = nhi, tot = hi - lo;
-    column(u + 1, nlo, nhi);
+    int n2lo, n2hi;
+    column(u + 2, n2lo, n2hi);
+    items(nlo, nhi, 0, jn);
+    const int tot = hi - lo;
 #pragma unroll 1
     for (int e0 = 0; e0 < tot; e0 += B) {
-      int js[B];
-#pragma unroll
-      for (int k = 0; k < B; k++) {
-        const int e = e0 + k;
-        const int v = b.citem[REV ? hi - 1 - (e < tot ? e : e0) : lo + (e < tot ? e : e0)];
-        js[k] = e < tot ? v : i;   // i: skipped like the particle itself
-      }
+      if (e0 > 0) items(lo, hi, e0, js);   // a run longer than one chunk (crowded cells): the rest is not pipelined
       decltype(ld(0)) rec[B];
 #pragma unroll
       for (int k = 0; k < B; k++) rec[k] = ld(js[k]);   // unconditional (i is a valid index)
@@ -138,6 +150,9 @@ __device__ __forceinline__ void raw_row_s(const Dev &d, const BucketTab &b, int 
 #pragma unroll
       for (int k = 0; k < B; k++) if (js[k] != i && !use(js[k], rec[k])) return;
     }
+    lo = nlo; hi = nhi; nlo = n2lo; nhi = n2hi;
+#pragma unroll
+    for (int k = 0; k < B; k++) js[k] = jn[k];
   }
 }
 
