@@ -458,6 +458,9 @@ __device__ __forceinline__ uint4 nb_stream(const uint4 *p) {
 // faster that way); NT = 1: only in builds with -DWCSPH_STREAM_NT=1 (rounds 1-2 loaded the stream of every once-per-step
 // pass non-temporally, to keep it from displacing the gather records; since round 3 the elementwise traffic is what
 // stays out of the Infinity Cache -- ld_once / st_once -- and every walk after the first finds the stream there).
+#ifndef WCSPH_TAIL4
+#define WCSPH_TAIL4 1   /* 0: rounds 1-3 form (every trip eight slots); the same for the solid stream measured no gain */
+#endif
 template <int U, int NT = 0, class GL, class FL, class FS>
 __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
   static_assert(U == 4 || U == 8, "U slots per trip");
@@ -474,7 +477,19 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   // the gathers and the arithmetic instead of heading the next trip's dependency chain
   uint4 en = cl > 0 ? nb_stream<NT>(L) : make_uint4(0, 0, 0, 0);
   for (int k = 0; k < cl; k += U) {
-    if (U == 8) {
+    if (U == 8 && WCSPH_TAIL4 && __builtin_amdgcn_ballot_w64(k + 4 < cl) == 0) {
+      // last trip of the wave and no lane's list reaches the block's second half: four slots instead of eight (a gather
+      // instruction costs its 16+ cycles whether or not a lane takes part, profiles/r03l_gather_rate.txt)
+      const uint4 e = en;
+      const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y);
+      const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3;
+      WALK_OK(0, d0) WALK_OK(1, d1) WALK_OK(2, d2) WALK_OK(3, d3)
+      float4 p0 = nb_ld(P, j0);
+      const float4 p1 = nb_ld(P, j1), p2 = nb_ld(P, j2), p3 = nb_ld(P, j3);
+      auto b0 = gl(j0, p0); const auto b1 = gl(j1, p1); const auto b2 = gl(j2, p2); const auto b3 = gl(j3, p3);
+      nb_pin(p0); nb_pin(b0);
+      WALK_ONE(0, ok0, j0, p0, b0) WALK_ONE(1, ok1, j1, p1, b1) WALK_ONE(2, ok2, j2, p2, b2) WALK_ONE(3, ok3, j3, p3, b3)
+    } else if (U == 8) {
       const uint4 e = en;
       if (k + 8 < cl) en = nb_stream<NT>(L + (size_t)((k >> 3) + 1) * st);
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
