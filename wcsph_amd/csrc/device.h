@@ -76,6 +76,8 @@ struct Dev {
   int *cs_s;          // [ncell_p+2] solid cell start
   int *cell_info;     // [ncell_p] bit0: solids within the 5^3 walk; bits1..: alias slot + 1
   uint16_t *alias;    // [n_alias][ALIAS_STRIDE]
+  // speculative launches (wcsph_hip.hip k_publish): a kernel launched with pred != nullptr does nothing when *pred == 0
+  const int *pred;
   // reductions
   double *acc;        // [8 slots][ACC_STRIPES]
   int *flags;         // [4] error bits, vmax bits
@@ -207,6 +209,9 @@ __device__ __forceinline__ void st_once(int *p, int v) {
   *p = v;
 #endif
 }
+
+// first statement of a kernel that may be launched speculatively (grid-uniform: taken by every thread or by none)
+#define PRED_GATE(d) do { if ((d).pred && *(d).pred == 0) return; } while (0)
 
 // does this context own row i?  Without a decomposition every row is owned (n_owned == nl, wave-uniform): no oid read.
 __device__ __forceinline__ bool owned(const Dev &d, int i) { return d.n_owned >= d.nl || d.oid[i] < d.n_owned; }

@@ -442,6 +442,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_residual(Dev d, float dt) {
 // fused dfsph.py:202-223: one neighbour walk builds the preconditioner block AND A(v_guess) (both read rho_j,
 // the second also v_guess_j); used by the fused host path, the split kernels above stay for the per-phase API
 __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
+  PRED_GATE(d);
   LOAD_I
   float part = 0.f;
   if (own) {
@@ -486,6 +487,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
 
 // wcsph_dfsph_step only: k_visc_minv_residual + k_vorticity in one walk
 __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float dt) {
+  PRED_GATE(d);
   LOAD_I
   float part = 0.f;
   if (own) {
@@ -550,6 +552,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float 
 
 // ref: dfsph.py:227-230: Ad = A(dir); dAd = eps + sum dir.Ad
 __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
+  PRED_GATE(d);
   acc_clear(ACC_SLOT(d, ACC_DNEW));    // k_visc_update (next) sums into it; its last reader, k_visc_dir, has finished
   LOAD_I
   float part = 0.f;
@@ -564,6 +567,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_Ad(Dev d, float dt) {
 // from_dzero (first iteration of the fused host loop): delta = delta_zero is still on the device (ACC_DZERO), the host
 // has not waited for it
 __global__ void __launch_bounds__(BLOCK) k_visc_update(Dev d, float delta, int from_dzero = 0) {
+  PRED_GATE(d);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float part = 0.f;
   const double dAd = acc_total(ACC_SLOT(d, ACC_DAD));
@@ -667,6 +671,7 @@ __global__ void __launch_bounds__(BLOCK) k_cfl(Dev d, float dt) {
 }
 // one wave: max over the stripes -> flags[FLAG_VMAX] and slot 0 of the reference's vel_max field; stripes cleared
 __global__ void k_cfl_store(Dev d) {
+  PRED_GATE(d);
   int v = d.flags[4 + threadIdx.x];
   d.flags[4 + threadIdx.x] = 0;
 #pragma unroll
@@ -681,6 +686,7 @@ __global__ void k_cfl_store(Dev d) {
 // per-particle part of the CFL reduction (:555-568) in one elementwise launch -- all three touch only particle i and
 // nothing reads their outputs from a neighbour before the next launch
 __global__ void __launch_bounds__(BLOCK) k_finish_nonpressure(Dev d, float dt) {
+  PRED_GATE(d);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float vm = 0.f;
   if (i < d.nl) {
@@ -731,6 +737,7 @@ __global__ void k_update_pos(Dev d, float dt) {
 // end of solve_divergence (dfsph.py:480-484) + clear_nonpressure (:333-336) + the v_guess update of init_viscosity_para (:199-200)
 // vort != 0: k_drho_div_iter_vort parked the vorticity acceleration in cg_s
 __global__ void k_end_div_begin_nonpressure(Dev d, float dt, int vort) {
+  PRED_GATE(d);
   acc_clear(ACC_SLOT(d, ACC_DZERO));   // as k_visc_guess
   acc_clear(ACC_SLOT(d, ACC_DAD));
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -752,6 +759,7 @@ __global__ void k_update_vel_warm_scale(Dev d, float dt) {
 }
 // end of solve_pressure (dfsph.py:549-552) + update_pos (:577-580)
 __global__ void k_end_press_update_pos(Dev d, float dt) {
+  PRED_GATE(d);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || !owned(d, i)) return;
   st_once(d.kappa + i, ld_once(d.kappa + i) * (dt * dt));

@@ -22,6 +22,9 @@
 #include "canvas.h"
 #include "bucket.h"
 
+#ifndef WCSPH_SPECULATE
+#define WCSPH_SPECULATE 1
+#endif
 struct wcsph_ctx {
   wcsph_params p;
   Dev d;          // DFSPH view (CubicKernel with h = HashGrid.searchR)
@@ -49,6 +52,12 @@ struct wcsph_ctx {
   double *h_acc_raw = nullptr;    // pinned [8][ACC_STRIPES]
   double h_acc[8] = {0};          // stripe totals of the last pull_scalars()
   unsigned long long mail_seq = 0;
+  int h_pred = 0;                 // the device's stopping decision that came with the last collected mail (k_publish)
+  int *pred_dev = nullptr;        // [4] predicate words of the speculative launches (Dev::pred points at one of them)
+  bool in_step_spec = false;      // inside wcsph_dfsph_step's divergence solve: the continuation may be queued speculatively
+  bool speculate = WCSPH_SPECULATE != 0;   // -DWCSPH_SPECULATE=0: the rounds 1-3 control flow (one host wait per decision), for A/B builds
+  unsigned long long spec_visc_seq = 0;   // != 0: solve_divergence queued the opening of compute_nonpressure_force behind its decision; its mail
+  unsigned long long spec_cfl_seq = 0;    // != 0: ... and the end of it + the CFL reduction behind the viscosity decision; its mail
   McDev mc = {};                  // MarchingCubeGrid (lazily set up)
   int *mc_tables = nullptr;       // device: edge[256] + tri[256][MC_TRI_ROW]
   size_t mc_nodes = 0;
@@ -134,13 +143,38 @@ static int check_flags(wcsph_ctx *ctx) {
 // HOST ONCE: no grid update clears them, k_publish clears the word it has just published.  A step that never waits for
 // a reduction (wcsph_sesph_step, a bare update_grid()) therefore reports at the next synchronisation point -- the next
 // wcsph_sync(), solver decision or field transfer -- instead of losing the condition to the following grid update.
-struct HostMail { double acc[8]; int flags[4]; unsigned long long seq; };
-__global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned long long seq) {
+// Speculation (wcsph_dfsph_step): the kernel that publishes a solver's error sum also takes the solver's stopping decision
+// ON THE DEVICE -- the same IEEE double expressions the host loops evaluate (dfsph.py:141-144, 160-163) -- and leaves it in
+// a predicate word; the kernels that follow in the common case (the solver stops) are already in the stream behind it,
+// gated by that word (Dev::pred), so the GPU runs on while the mail travels to the host.  The host takes the decision
+// FROM THE MAIL (one source of truth) and, when the solver has to go on, finds the gated kernels to have done nothing.
+enum { PRED_NONE = 0, PRED_PRESS = 1, PRED_DIV = 2, PRED_VISC = 3, PRED_PASS = 4 };
+// gate: the publish itself is speculative -- when *gate == 0 it publishes nothing (the host, which knows from the mail that
+// set the gate, does not wait for it) and CLOSES its own predicate, so that a chain of gated segments stops as a whole
+struct PredSpec { int kind; double thr, n; int *out; const int *gate; };
+#define MAIL_RING 8   /* publishes that may be in flight before the host reads the first of them */
+struct HostMail { double acc[8]; int flags[4]; unsigned long long seq; int pred; int pad_; };
+__global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned long long seq, PredSpec ps) {
   const int t = threadIdx.x;
+  if (ps.gate && *ps.gate == 0) { if (t == 0 && ps.out) *ps.out = 0; return; }
   if (t < 8) {
     double v = 0.0;
     for (int k = 0; k < ACC_STRIPES; k++) v += acc[t * ACC_STRIPES + k];
     m->acc[t] = v;
+    if (t == ACC_ERR) {
+      int stop = 0;
+      const double e = (double)(float)v;                       // avg_density_err is a float32 field
+      if (ps.kind == PRED_PRESS) stop = !(e / ps.n > ps.thr);   // dfsph.py:160-161: while err > 0.001, err = avg_density_err / N
+      else if (ps.kind == PRED_DIV) stop = !(e > ps.thr);       // dfsph.py:141: while avg_density_err > err
+      else if (ps.kind == PRED_VISC) {                          // dfsph.py:96-97 after the first compute_viscosity_force
+        double dz = 0.0, dn = 0.0;
+        for (int k = 0; k < ACC_STRIPES; k++) { dz += acc[ACC_DZERO * ACC_STRIPES + k]; dn += acc[ACC_DNEW * ACC_STRIPES + k]; }
+        const double dzero = (double)(float)dz, delta = (double)(float)dn;   // cg_delta_zero, cg_delta: float32 fields
+        stop = (delta <= ps.thr * dzero) || (dzero < ps.n);
+      } else if (ps.kind == PRED_PASS) stop = 1;
+      m->pred = stop;
+      if (ps.out) *ps.out = stop;
+    }
   } else if (t < 12) {
     m->flags[t - 8] = flags[t - 8];
     if (t - 8 == FLAG_ERR) flags[FLAG_ERR] = 0;   // handed over: reported exactly once
@@ -148,17 +182,17 @@ __global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned l
   __syncthreads();
   if (t == 0) { __threadfence_system(); __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
-static int publish_async(wcsph_ctx *ctx) {
-  HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw);
+static int publish_async(wcsph_ctx *ctx, PredSpec ps = {PRED_NONE, 0.0, 1.0, nullptr, nullptr}) {
   const unsigned long long seq = ++ctx->mail_seq;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->d.acc, ctx->d.flags, m, seq);
+  HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw) + seq % MAIL_RING;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->d.acc, ctx->d.flags, m, seq, ps);
   LAUNCHCHK();
   return 0;
 }
-// waits for the mail of the last publish_async(); check_acc: also refuse non-finite reduction totals
-static int collect_mail(wcsph_ctx *ctx, bool check_acc) {
-  HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw);
-  const unsigned long long seq = ctx->mail_seq;
+// waits for the mail of publish number `seq` (0: the last publish_async()); check_acc: also refuse non-finite reduction totals
+static int collect_mail(wcsph_ctx *ctx, bool check_acc, unsigned long long seq = 0) {
+  if (seq == 0) seq = ctx->mail_seq;
+  HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw) + seq % MAIL_RING;
   volatile unsigned long long *flag = &m->seq;
   for (unsigned long spins = 0; *flag != seq; spins++) {
     if ((spins & 0xfffff) == 0xfffff) {   // every ~1 M polls: is the stream still alive?
@@ -170,6 +204,7 @@ static int collect_mail(wcsph_ctx *ctx, bool check_acc) {
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int s = 0; s < 8; s++) ctx->h_acc[s] = m->acc[s];
   for (int s = 0; s < 4; s++) ctx->h_flags[s] = m->flags[s];
+  ctx->h_pred = m->pred;
   int rc = check_flags(ctx);
   if (rc || !check_acc) return rc;
   // a NaN error sum makes every `err > tol` test of the reference's host loops false, i.e. "converged" (dfsph.py:141-163)
@@ -261,6 +296,9 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(ctx->pw, nmax); DALLOC(ctx->slot, nmax);
   size_t stage_n = (nl + d.ns) * 3 > nl * 9 ? (nl + d.ns) * 3 : nl * 9;
   DALLOC(ctx->stage, stage_n);
+  DALLOC(ctx->pred_dev, 4);
+  HIPCHK(hipMemsetAsync(ctx->pred_dev, 0, 4 * sizeof(int), ctx->stream));
+  static_assert(MAIL_RING * sizeof(HostMail) <= 8 * ACC_STRIPES * sizeof(double), "mail ring fits the pinned buffer");
   HIPCHK(hipHostMalloc((void **)&ctx->h_acc_raw, 8 * ACC_STRIPES * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&ctx->h_flags, 4 * sizeof(int)));
   memset(ctx->h_acc_raw, 0, 8 * ACC_STRIPES * sizeof(double)); memset(ctx->h_flags, 0, 4 * sizeof(int));
@@ -974,12 +1012,18 @@ int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx) {
   // ref: dfsph.py:108-111 `while size < particleLiquidNum`: with a single liquid particle the reference launches
   // nothing, vel_max[0] keeps its initial 0 and the time step is never adapted
   if (ctx->d.faithful && ctx->d.nl <= 1) { ctx->vel_max0 = 0.0f; return WCSPH_OK; }
-  if (ctx->cfl_done) ctx->cfl_done = false;   // k_finish_nonpressure already took the per-particle maxima
-  else ELEM(k_cfl, ctx->dt);
-  hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d);
-  LAUNCHCHK();
-  int rc = pull_scalars(ctx);
-  if (rc) return rc;
+  int rc;
+  if (ctx->spec_cfl_seq) {   // queued behind the viscosity decision by solve_divergence, and that decision was "stop": only the mail is left
+    const unsigned long long seq = ctx->spec_cfl_seq;
+    ctx->spec_cfl_seq = 0; ctx->cfl_done = false;
+    if ((rc = collect_mail(ctx, true, seq))) return rc;
+  } else {
+    if (ctx->cfl_done) ctx->cfl_done = false;   // k_finish_nonpressure already took the per-particle maxima
+    else ELEM(k_cfl, ctx->dt);
+    hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d);
+    LAUNCHCHK();
+    if ((rc = pull_scalars(ctx))) return rc;
+  }
   int bits = ctx->h_flags[FLAG_VMAX];
   memcpy(&ctx->vel_max0, &bits, 4);
   return WCSPH_OK;
@@ -992,27 +1036,53 @@ int wcsph_dfsph_update_pos(wcsph_ctx *ctx) {
 }
 
 // ---- host-side control ------------------------------------------------------------------------
+// init_viscosity_para + the first compute_viscosity_force, up to the publish of their sums (dfsph.py:90-97).  gate != nullptr:
+// queued speculatively behind the decision that sets *gate (solve_divergence), every launch gated by it.
+static int nonpressure_visc_open(wcsph_ctx *ctx, const int *gate, PredSpec ps) {
+  const bool vort_taken = ctx->vort_in_div;   // by the last divergence iteration: only the viscosity part is left
+  ctx->vort_in_div = false;
+  ctx->d.pred = gate;
+  if (ctx->vort_fuse && !vort_taken) RPASS(k_visc_minv_residual_vort, ctx->dt); else RPASS(k_visc_minv_residual, ctx->dt);
+  RPASS(k_visc_Ad, ctx->dt);
+  ELEM(k_visc_update, 0.0f, 1);
+  ctx->d.pred = nullptr;
+  return publish_async(ctx, ps);
+}
+// can the fused step queue its common-case continuation behind a solver decision (see k_publish)?
+static bool spec_ok(const wcsph_ctx *ctx) {
+  return ctx->fuse_elem && ctx->in_step_spec && ctx->fix_dv == 0 && ctx->fix_vs == 0 && ctx->fix_pr == 0 && ctx->pr_valid &&
+         ctx->d.tension == 0.0f && ctx->d.tension_b == 0.0f && !(ctx->d.faithful && ctx->d.nl <= 1);
+}
+
 int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84-103
   NEED_GRID();
   int rc;
   const bool begun = ctx->nonp_begun;   // solve_divergence's last launch already cleared d_vel and advanced v_guess
   ctx->nonp_begun = false;
-  if (!begun && (rc = wcsph_dfsph_clear_nonpressure(ctx))) return rc;
-  if ((rc = wcsph_dfsph_tension(ctx))) return rc;
-  // init_viscosity_para + the first compute_viscosity_force with ONE host wait: the loop below always runs once, and
-  // its first iteration can take delta_zero from the device (the reference waits after each, dfsph.py:86-91)
-  if (!begun) ELEM(k_visc_guess);
   const bool fuse_vort = ctx->vort_fuse;
-  const bool vort_taken = ctx->vort_in_div;   // by the last divergence iteration: only the viscosity part is left
-  ctx->vort_in_div = false;
-  if (fuse_vort && !vort_taken) RPASS(k_visc_minv_residual_vort, ctx->dt); else RPASS(k_visc_minv_residual, ctx->dt);
-  RPASS(k_visc_Ad, ctx->dt);
-  ELEM(k_visc_update, 0.0f, 1);
-  if ((rc = pull_scalars(ctx))) return rc;
+  if (ctx->spec_visc_seq) {
+    // solve_divergence queued everything up to the first mail behind its own decision, and the END of this function + the
+    // CFL reduction behind the viscosity decision (the common case: one PCG iteration)
+    const unsigned long long seq = ctx->spec_visc_seq;
+    ctx->spec_visc_seq = 0;
+    if ((rc = collect_mail(ctx, true, seq))) { ctx->spec_cfl_seq = 0; return rc; }
+  } else {
+    if (!begun && (rc = wcsph_dfsph_clear_nonpressure(ctx))) return rc;
+    if ((rc = wcsph_dfsph_tension(ctx))) return rc;
+    // init_viscosity_para + the first compute_viscosity_force with ONE host wait: the loop below always runs once, and
+    // its first iteration can take delta_zero from the device (the reference waits after each, dfsph.py:86-91)
+    if (!begun) ELEM(k_visc_guess);
+    if ((rc = nonpressure_visc_open(ctx, nullptr, {PRED_NONE, 0.0, 1.0, nullptr, nullptr}))) return rc;
+    if ((rc = collect_mail(ctx, true))) return rc;
+    ctx->h_pred = 0;
+  }
+  const bool spec_finished = ctx->spec_cfl_seq != 0 && ctx->h_pred != 0;   // the device stopped the PCG and ran the gated end
+  if (!spec_finished) ctx->spec_cfl_seq = 0;                               // (otherwise: those launches did nothing)
   ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
   ctx->cg_delta_old = ctx->cg_delta_zero;
   ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
   ctx->vs_iter = 1;
+  if (spec_finished) { ctx->cfl_done = true; return WCSPH_OK; }
   // the search direction of the NEXT iteration (dfsph.py:243-246) is only formed if there is one: with the usual single
   // iteration k_visc_dir never runs (cg_dir is scratch of this loop, rebuilt by the next init_viscosity_para)
   while (ctx->vs_iter < 100) {
@@ -1074,6 +1144,40 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
   const float dt = ctx->dt;
   while (ctx->fix_dv > 0 ? ctx->dv_iter < ctx->fix_dv : ((double)ctx->avg_density_err > err && ctx->dv_iter < 10)) {
     if ((rc = divergence_iter_fused(ctx))) return rc;
+    if (spec_ok(ctx) && ctx->dv_iter + 1 < 10) {
+      // Speculation: the loop's next test is taken on the device (mail A) and the common-case continuation is queued behind
+      // it in three gated segments: [end of this solver + opening of compute_nonpressure_force up to its first mail B] gated
+      // by A; [end of compute_nonpressure_force + CFL reduction, mail C] gated by B's own decision (one PCG iteration
+      // suffices).  The GPU runs from here to the CFL mail without waiting for the host; a decision that falls the other
+      // way leaves the gated launches as no-ops and the host continues as before.
+      int *pA = ctx->pred_dev + 1, *pB = ctx->pred_dev + 2;
+      const double thr = 0.001 * (double)ctx->d.n_owned / (double)dt;
+      if ((rc = publish_async(ctx, {PRED_DIV, thr, 1.0, pA, nullptr}))) return rc;
+      const unsigned long long seqA = ctx->mail_seq;
+      const bool vort = ctx->vort_in_div;
+      ctx->d.pred = pA;
+      ELEM(k_end_div_begin_nonpressure, ctx->dt, vort ? 1 : 0);
+      ctx->d.pred = nullptr;
+      if ((rc = nonpressure_visc_open(ctx, pA, {PRED_VISC, (double)ctx->p.viscosity_err, (double)ctx->p.eps, pB, pA}))) return rc;
+      const unsigned long long seqB = ctx->mail_seq;
+      ctx->d.pred = pB;
+      ELEM(k_finish_nonpressure, ctx->dt);
+      hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d);
+      ctx->d.pred = nullptr;
+      if ((rc = publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pB}))) return rc;
+      const unsigned long long seqC = ctx->mail_seq;
+      if ((rc = collect_mail(ctx, true, seqA))) return rc;
+      ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+      err = thr;
+      ctx->dv_iter++;
+      if (ctx->h_pred) {   // the device left the loop: the continuation is running
+        ctx->spec_visc_seq = seqB; ctx->spec_cfl_seq = seqC;
+        ctx->nonp_begun = true;
+        return WCSPH_OK;
+      }
+      ctx->vort_in_div = vort;   // nothing of the continuation ran
+      continue;
+    }
     if ((rc = fused_iter_sync(ctx))) return rc;
     err = 0.001 * (double)ctx->d.n_owned / (double)dt;
     ctx->dv_iter++;
@@ -1101,6 +1205,20 @@ int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
     // the reference reads the error after every iteration, but `pr_iter < 2` forces the second one whatever the
     // first reports: the host only has to wait where the value can change the control flow
     if (ctx->fix_pr == 0 && ctx->pr_iter < 2 && fusek) { err = 1.0; continue; }
+    if (ctx->fix_pr == 0 && ctx->fuse_elem && ctx->speculate && ctx->pr_iter < 100) {
+      // speculation: the stopping decision is taken on the device by the kernel that publishes the error sum, and the
+      // step's last kernel (end_pressure_iter + update_pos) is already queued behind it, gated by that decision -- in the
+      // common case (two iterations suffice) the GPU finishes the step while the mail travels
+      if ((rc = publish_async(ctx, {PRED_PRESS, 0.001, (double)ctx->d.n_owned, ctx->pred_dev + 0, nullptr}))) return rc;
+      ctx->d.pred = ctx->pred_dev + 0;
+      ELEM(k_end_press_update_pos, ctx->dt);
+      ctx->d.pred = nullptr;
+      if ((rc = collect_mail(ctx, true))) return rc;
+      ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+      err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
+      if (ctx->h_pred) return WCSPH_OK;      // the device stopped the solver and has run the gated kernel
+      continue;                              // err > 0.001 by the device's own evaluation: the gated kernel did nothing
+    }
     if ((rc = fused_iter_sync(ctx))) return rc;
     err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
   }
@@ -1119,9 +1237,10 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   } else PASS(k_density_coff);           // compute_density + compute_dfsph_coff in one walk
   const bool fuse = ctx->d.n_owned == ctx->d.nl;
   ctx->fuse_elem = fuse;
+  ctx->in_step_spec = fuse && ctx->speculate;
   rc = wcsph_dfsph_solve_divergence(ctx);
-  ctx->fuse_elem = false;
-  if (rc) { ctx->nonp_begun = false; ctx->vort_in_div = false; return rc; }
+  ctx->fuse_elem = false; ctx->in_step_spec = false;
+  if (rc) { ctx->nonp_begun = false; ctx->vort_in_div = false; ctx->spec_visc_seq = ctx->spec_cfl_seq = 0; return rc; }
   ctx->in_step = true;
   rc = wcsph_dfsph_compute_nonpressure_force(ctx);
   ctx->in_step = false;
