@@ -5,7 +5,7 @@ streams with hop slots in a disordered particle order, list lengths near their c
 its persistent state -- pos, vel, omega, vel_guess, kappa, kappa_v, deltaT, pr_iter, the stale avg_density_err
 (ref: dfsph.py:36-41 module globals and the fields that survive update_grid) -- is loaded into the oracle, and both take
 one step (ref: dfsph.py:606-617).  Compared: exact raw list lengths (HashGrid.neighborCount), equal iteration counts,
-density to the north star's 1e-4, positions to 2e-6 (but for at most two warm-start gate flips, see below), every other per-step field to the tolerances of the at-rest tests.
+density to the north star's 1e-4, positions to 2e-6 and velocities to 1e-3 m/s (but for at most three warm-start gate flips, see below), every other per-step field to the tolerances of the at-rest tests.
 """
 import ctypes as C
 
@@ -65,21 +65,26 @@ def test_one_step_from_a_developed_state(mode, n, steps):
     assert abs(dt - o.deltaT) <= 1e-6 * o.deltaT
     rho = pd.rho.to_numpy()
     assert np.abs(rho - o.rho).max() / o.rho.max() < 1e-4                     # north star: per-particle density error
+    # velocities and positions: tight for every particle -- but for at most three gate flips.  The reference's warm start
+    # kicks particle i with dt * sum (kappa_v_i + kappa_v_j) V gradW only `if adv_rho[i] > 0.0` (dfsph.py:421): a particle
+    # whose clipped divergence is zero to rounding gets the whole kick or none, depending on the order its ~35 terms were
+    # summed in (the library's list order is the sort's, the oracle's the reference's).  The state under test differs from
+    # run to run (the sort's slot order inside a cell comes from atomics), and in about one run in ten ONE particle of
+    # 110 k sits on that gate: its velocity then differs by 5e-3 ... 2e-2 (everybody else: ~5e-5), its position by dt
+    # times that.  tools/diag_developed_parity.py prints the distribution (56 runs: profiles/r03p_developed_parity.txt).
     v = pd.vel.to_numpy()
-    assert np.abs(v - o.vel).max() < 2e-3 * np.abs(o.vel).max()
-    # positions: 2e-6 (a few ulp at |x| ~ 2) for every particle -- but for at most two gate flips.  The reference's warm
-    # start kicks particle i with dt * sum (kappa_v_i + kappa_v_j) V gradW only `if adv_rho[i] > 0.0` (dfsph.py:421): a
-    # particle whose clipped divergence is zero to rounding gets the whole kick or none, depending on the order its ~35
-    # terms were summed in (the library's list order is the sort's, the oracle's the reference's).  The state under test
-    # differs from run to run (the sort's slot order inside a cell comes from atomics), and in about one run in ten ONE
-    # particle of 110 k sits on that gate: its velocity then differs by ~5e-3 (inside the velocity tolerance above), its
-    # position by dt times that.  tools/diag_developed_parity.py prints the distribution.
+    vmax = np.abs(o.vel).max()
+    dvel = np.abs(v - o.vel).max(axis=1)
+    assert (dvel >= 1e-3).sum() <= 3, "%d particles beyond 1e-3 m/s" % (dvel >= 1e-3).sum()
+    assert dvel.max() < 2e-2 * vmax
     dpos = np.abs(pd.pos.to_numpy()[:nl] - o.pos[:nl]).max(axis=1)
-    assert (dpos >= 2e-6).sum() <= 2, "%d particles beyond 2e-6" % (dpos >= 2e-6).sum()
-    assert dpos.max() < 2e-3 * np.abs(o.vel).max() * dt
+    assert (dpos >= 2e-6).sum() <= 3, "%d particles beyond 2e-6" % (dpos >= 2e-6).sum()
+    assert dpos.max() < 2e-2 * vmax * dt
     for name, a, b in (("kappa", dfsph.kappa.to_numpy(), o.kappa), ("kappa_v", dfsph.kappa_v.to_numpy(), o.kappa_v),
                        ("omega", pd.omega.to_numpy(), o.omega), ("vel_guess", pd.vel_guess.to_numpy(), o.vel_guess)):
-        assert np.abs(a - b).max() <= 2e-3 * max(np.abs(b).max(), 1e-6), name
+        dd = np.abs(a - b).reshape(len(a), -1).max(axis=1)
+        tol = 2e-3 * max(np.abs(b).max(), 1e-6)
+        assert (dd > tol).sum() <= 3 and dd.max() <= 20 * tol, name      # the same at most three particles as above
     # the compact streams of the crowded state decode to the in-support part of the oracle's rows (a sample of rows)
     rng = np.random.default_rng(5)
     for i in rng.integers(0, nl, 64):

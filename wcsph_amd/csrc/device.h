@@ -78,13 +78,16 @@ struct Dev {
   uint16_t *alias;    // [n_alias][ALIAS_STRIDE]
   // speculative launches (wcsph_hip.hip k_publish): a kernel launched with pred != nullptr does nothing when *pred == 0
   const int *pred;
+  // ... and takes the time step from *dtp instead of its dt argument when dtp != nullptr: the kernels queued behind the
+  // CFL reduction run before the host has seen the new deltaT (k_cfl_store forms it on the device, DtRule)
+  const float *dtp;
   // reductions
   double *acc;        // [8 slots][ACC_STRIPES]
   int *flags;         // [4] error bits, vmax bits
 };
 
 enum { ACC_ERR = 0, ACC_DAD = 1, ACC_DNEW = 2, ACC_DZERO = 3 };
-enum { FLAG_ERR = 0, FLAG_VMAX = 1 };
+enum { FLAG_ERR = 0, FLAG_VMAX = 1, FLAG_DT = 2 };   // FLAG_DT: bits of the deltaT k_cfl_store formed (speculative steps)
 enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2, ERRBIT_LISTCAP = 4, ERRBIT_NONFINITE = 8, ERRBIT_ROWITEMS = 16 };
 
 __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
@@ -212,6 +215,7 @@ __device__ __forceinline__ void st_once(int *p, int v) {
 
 // first statement of a kernel that may be launched speculatively (grid-uniform: taken by every thread or by none)
 #define PRED_GATE(d) do { if ((d).pred && *(d).pred == 0) return; } while (0)
+#define DT_OVERRIDE(d, dt) do { if ((d).dtp) dt = *(d).dtp; } while (0)
 
 // does this context own row i?  Without a decomposition every row is owned (n_owned == nl, wave-uniform): no oid read.
 __device__ __forceinline__ bool owned(const Dev &d, int i) { return d.n_owned >= d.nl || d.oid[i] < d.n_owned; }

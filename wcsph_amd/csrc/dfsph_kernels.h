@@ -180,6 +180,8 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
 // the epilogue writes w only: no launch reads a word another thread of the same launch writes.
 template <int MODE, bool FUSEK = false>
 __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
+  PRED_GATE(d);
+  DT_OVERRIDE(d, dt);
   constexpr bool REC = FUSEK && MODE == DRHO_ITER;
   const int i = sorted_index(d);
   const bool live = i < d.nl;
@@ -239,6 +241,8 @@ __global__ void k_pack_k(Dev d, const float *kb) {
 // kap != nullptr (fused solver loops): kappa_i += k_i here instead of in k_make_k (dfsph.py:458 / 527)
 template <int COND>
 __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, float dt, float *kap = nullptr) {
+  PRED_GATE(d);
+  DT_OVERRIDE(d, dt);
   if (kap) acc_clear(ACC_SLOT(d, ACC_ERR));   // fused solver loops: the density-change pass launched next sums into it
   // The pass is HBM-bound on its own inputs: the particle's position comes with its (pos, k) record, and
   // pos[i] / oid[i] are read only where ownership is not trivial (slab decomposition) -- 40 B per particle less.
@@ -275,6 +279,8 @@ __global__ void k_warm_press_scale(Dev d, float dt) {
   d.kappa[i] = fmaxf(d.kappa[i] / dt / dt, -0.5f * d.rho_L0 * d.rho_L0);
 }
 __global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
+  PRED_GATE(d);
+  DT_OVERRIDE(d, dt);
   LOAD_I
   if (!own) return;
   if (!(d.adv_rho[i] > d.rho_L0)) return;
@@ -670,7 +676,22 @@ __global__ void __launch_bounds__(BLOCK) k_cfl(Dev d, float dt) {
   }
 }
 // one wave: max over the stripes -> flags[FLAG_VMAX] and slot 0 of the reference's vel_max field; stripes cleared
-__global__ void k_cfl_store(Dev d) {
+// the host rule of optimize_time_step (dfsph.py:113-129; wcsph_dfsph_optimize_time_step) for the device: the same IEEE
+// double expressions in the same order.  it = max(vs_iter, pr_iter) as the host knows it when it queues the launch.
+struct DtRule { float *out; float dt_old; int it; double eps, cfl_radius, user_max_t, user_min_t; };
+__device__ __forceinline__ float dt_rule(const DtRule &r, float vmax0) {
+  float dt = r.dt_old;
+  if ((double)vmax0 > r.eps) {
+    double time_step = 0.5 * 0.4 * r.cfl_radius * 2.0 / sqrt((double)vmax0);
+    if (time_step > r.user_max_t) time_step = r.user_max_t;
+    if (time_step < r.user_min_t) time_step = r.user_min_t;
+    if (r.it > 10) dt = (float)((double)dt * 0.9);
+    else if (r.it < 5) dt = (float)((double)dt * 1.1);
+    if ((double)dt > time_step) dt = (float)time_step;
+  }
+  return dt;
+}
+__global__ void k_cfl_store(Dev d, DtRule r) {
   PRED_GATE(d);
   int v = d.flags[4 + threadIdx.x];
   d.flags[4 + threadIdx.x] = 0;
@@ -679,6 +700,7 @@ __global__ void k_cfl_store(Dev d) {
   if (threadIdx.x == 0) {
     d.flags[FLAG_VMAX] = v;
     if (d.nl > 0 && d.n_owned > 0) d.vel_max[d.where[0]] = __int_as_float(v);
+    if (r.out) { const float dt = dt_rule(r, __int_as_float(v)); *r.out = dt; d.flags[FLAG_DT] = __float_as_int(dt); }
   }
 }
 
@@ -751,6 +773,8 @@ __global__ void k_end_div_begin_nonpressure(Dev d, float dt, int vort) {
 }
 // update_vel (dfsph.py:572-575) + the kappa rescale that opens warmstart_pressure (:490)
 __global__ void k_update_vel_warm_scale(Dev d, float dt) {
+  PRED_GATE(d);
+  DT_OVERRIDE(d, dt);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || !owned(d, i)) return;
   float4 v = ld_once(d.vel + i), a = ld_once(d.d_vel + i);
@@ -760,6 +784,7 @@ __global__ void k_update_vel_warm_scale(Dev d, float dt) {
 // end of solve_pressure (dfsph.py:549-552) + update_pos (:577-580)
 __global__ void k_end_press_update_pos(Dev d, float dt) {
   PRED_GATE(d);
+  DT_OVERRIDE(d, dt);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || !owned(d, i)) return;
   st_once(d.kappa + i, ld_once(d.kappa + i) * (dt * dt));

@@ -58,6 +58,11 @@ struct wcsph_ctx {
   bool speculate = WCSPH_SPECULATE != 0;   // -DWCSPH_SPECULATE=0: the rounds 1-3 control flow (one host wait per decision), for A/B builds
   unsigned long long spec_visc_seq = 0;   // != 0: solve_divergence queued the opening of compute_nonpressure_force behind its decision; its mail
   unsigned long long spec_cfl_seq = 0;    // != 0: ... and the end of it + the CFL reduction behind the viscosity decision; its mail
+  unsigned long long spec_press_seq = 0;  // != 0: ... and update_vel + the pressure solve up to its first decision; its mail
+  size_t spec_prof_mark = 0;      // prof_used before the speculative pressure iterations were queued
+  bool pr_resume = false;         // solve_pressure continues a solve whose first two iterations have run (speculatively)
+  bool spec_dt = false;           // the mail of the CFL reduction carries the deltaT the device formed (FLAG_DT)
+  float *dt_dev = nullptr;        // deltaT as k_cfl_store formed it, for the kernels queued behind it (Dev::dtp)
   McDev mc = {};                  // MarchingCubeGrid (lazily set up)
   int *mc_tables = nullptr;       // device: edge[256] + tri[256][MC_TRI_ROW]
   size_t mc_nodes = 0;
@@ -296,7 +301,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   DALLOC(ctx->pw, nmax); DALLOC(ctx->slot, nmax);
   size_t stage_n = (nl + d.ns) * 3 > nl * 9 ? (nl + d.ns) * 3 : nl * 9;
   DALLOC(ctx->stage, stage_n);
-  DALLOC(ctx->pred_dev, 4);
+  DALLOC(ctx->pred_dev, 4); DALLOC(ctx->dt_dev, 2);
   HIPCHK(hipMemsetAsync(ctx->pred_dev, 0, 4 * sizeof(int), ctx->stream));
   static_assert(MAIL_RING * sizeof(HostMail) <= 8 * ACC_STRIPES * sizeof(double), "mail ring fits the pinned buffer");
   HIPCHK(hipHostMalloc((void **)&ctx->h_acc_raw, 8 * ACC_STRIPES * sizeof(double)));
@@ -1016,11 +1021,12 @@ int wcsph_dfsph_cfl_reduce(wcsph_ctx *ctx) {
   if (ctx->spec_cfl_seq) {   // queued behind the viscosity decision by solve_divergence, and that decision was "stop": only the mail is left
     const unsigned long long seq = ctx->spec_cfl_seq;
     ctx->spec_cfl_seq = 0; ctx->cfl_done = false;
-    if ((rc = collect_mail(ctx, true, seq))) return rc;
+    if ((rc = collect_mail(ctx, true, seq))) { ctx->spec_press_seq = 0; return rc; }
+    ctx->spec_dt = true;
   } else {
     if (ctx->cfl_done) ctx->cfl_done = false;   // k_finish_nonpressure already took the per-particle maxima
     else ELEM(k_cfl, ctx->dt);
-    hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d);
+    hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d, DtRule{nullptr, 0.f, 0, 0.0, 0.0, 0.0, 0.0});
     LAUNCHCHK();
     if ((rc = pull_scalars(ctx))) return rc;
   }
@@ -1065,7 +1071,7 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
     // CFL reduction behind the viscosity decision (the common case: one PCG iteration)
     const unsigned long long seq = ctx->spec_visc_seq;
     ctx->spec_visc_seq = 0;
-    if ((rc = collect_mail(ctx, true, seq))) { ctx->spec_cfl_seq = 0; return rc; }
+    if ((rc = collect_mail(ctx, true, seq))) { ctx->spec_cfl_seq = ctx->spec_press_seq = 0; return rc; }
   } else {
     if (!begun && (rc = wcsph_dfsph_clear_nonpressure(ctx))) return rc;
     if ((rc = wcsph_dfsph_tension(ctx))) return rc;
@@ -1077,7 +1083,8 @@ int wcsph_dfsph_compute_nonpressure_force(wcsph_ctx *ctx) {  // ref: dfsph.py:84
     ctx->h_pred = 0;
   }
   const bool spec_finished = ctx->spec_cfl_seq != 0 && ctx->h_pred != 0;   // the device stopped the PCG and ran the gated end
-  if (!spec_finished) ctx->spec_cfl_seq = 0;                               // (otherwise: those launches did nothing)
+  if (!spec_finished && ctx->spec_press_seq) ctx->prof_used = ctx->spec_prof_mark;
+  if (!spec_finished) ctx->spec_cfl_seq = ctx->spec_press_seq = 0;         // (otherwise: those launches did nothing)
   ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
   ctx->cg_delta_old = ctx->cg_delta_zero;
   ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
@@ -1126,6 +1133,11 @@ int wcsph_dfsph_optimize_time_step(wcsph_ctx *ctx) {  // ref: dfsph.py:107-129
     if ((double)dt > time_step) dt = (float)time_step;
     ctx->dt = dt;
   }
+  if (ctx->spec_dt) {   // the kernels queued behind the CFL reduction ran with the device's deltaT: it has to be this one, bit for bit
+    ctx->spec_dt = false;
+    float ddt; memcpy(&ddt, &ctx->h_flags[FLAG_DT], 4);
+    if (memcmp(&ddt, &ctx->dt, 4) != 0) { ctx->spec_press_seq = 0; return ctx->fail(WCSPH_EHIP, "deltaT formed on the device differs from the host rule (dfsph.py:113-129)"); }
+  }
   return WCSPH_OK;
 }
 
@@ -1146,10 +1158,12 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
     if ((rc = divergence_iter_fused(ctx))) return rc;
     if (spec_ok(ctx) && ctx->dv_iter + 1 < 10) {
       // Speculation: the loop's next test is taken on the device (mail A) and the common-case continuation is queued behind
-      // it in three gated segments: [end of this solver + opening of compute_nonpressure_force up to its first mail B] gated
-      // by A; [end of compute_nonpressure_force + CFL reduction, mail C] gated by B's own decision (one PCG iteration
-      // suffices).  The GPU runs from here to the CFL mail without waiting for the host; a decision that falls the other
-      // way leaves the gated launches as no-ops and the host continues as before.
+      // it in gated segments: [end of this solver + opening of compute_nonpressure_force up to its first mail B] gated by
+      // A; once A has arrived with "stop": [end of compute_nonpressure_force + CFL reduction with deltaT formed on the
+      // device, mail C] and [update_vel + pressure solve up to its first decision, mail D] gated by B's own decision (one
+      // PCG iteration suffices), [end of the step] gated by D's.  The GPU runs from here to the end of the step without
+      // waiting for the host; a decision that falls the other way leaves the gated launches as no-ops and the host
+      // continues as before.
       int *pA = ctx->pred_dev + 1, *pB = ctx->pred_dev + 2;
       const double thr = 0.001 * (double)ctx->d.n_owned / (double)dt;
       if ((rc = publish_async(ctx, {PRED_DIV, thr, 1.0, pA, nullptr}))) return rc;
@@ -1160,18 +1174,41 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
       ctx->d.pred = nullptr;
       if ((rc = nonpressure_visc_open(ctx, pA, {PRED_VISC, (double)ctx->p.viscosity_err, (double)ctx->p.eps, pB, pA}))) return rc;
       const unsigned long long seqB = ctx->mail_seq;
-      ctx->d.pred = pB;
-      ELEM(k_finish_nonpressure, ctx->dt);
-      hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d);
-      ctx->d.pred = nullptr;
-      if ((rc = publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pB}))) return rc;
-      const unsigned long long seqC = ctx->mail_seq;
       if ((rc = collect_mail(ctx, true, seqA))) return rc;
       ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
       err = thr;
       ctx->dv_iter++;
       if (ctx->h_pred) {   // the device left the loop: the continuation is running
-        ctx->spec_visc_seq = seqB; ctx->spec_cfl_seq = seqC;
+        // The GPU is busy with the viscosity walks for the next ~0.2 ms: time to queue the rest of the step behind them.
+        // (Not before mail A: when the divergence solve goes on -- one step in four once the column collapses -- every
+        // gated launch costs 3-5 us as a no-op, and twenty of them cost more than the waits they hide.)
+        ctx->d.pred = pB;
+        ELEM(k_finish_nonpressure, ctx->dt);
+        // deltaT is formed on the device too: vs_iter = 1 on this branch (gated by "one PCG iteration sufficed"), pr_iter is last step's
+        const int it = ctx->pr_iter > 1 ? ctx->pr_iter : 1;
+        hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d,
+                           DtRule{ctx->dt_dev, ctx->dt, it, (double)ctx->p.eps, ctx->p.cfl_radius, ctx->p.user_max_t, ctx->p.user_min_t});
+        ctx->d.pred = nullptr;
+        if ((rc = publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pB}))) return rc;
+        const unsigned long long seqC = ctx->mail_seq;
+        // ... and the pressure solve up to its first decision (update_vel, warm start, begin, two iterations: dfsph.py:150-161
+        // forces two), still gated by B, taking deltaT from the device; its end gated by its own decision (mail D)
+        int *pD = ctx->pred_dev + 0;
+        ctx->spec_prof_mark = ctx->prof_used;   // in-situ timing: the event pairs of iterations that turn out gated off are dropped
+        ctx->d.pred = pB; ctx->d.dtp = ctx->dt_dev;
+        ELEM(k_update_vel_warm_scale, ctx->dt);
+        PASS(k_warm_press_vel, ctx->dt);
+        PASS((k_drho_press<DRHO_BEGIN, true>), ctx->dt);
+        rc = pressure_iter_fused(ctx);
+        if (!rc) rc = pressure_iter_fused(ctx);
+        ctx->d.pred = nullptr; ctx->d.dtp = nullptr;
+        if (rc) return rc;
+        if ((rc = publish_async(ctx, {PRED_PRESS, 0.001, (double)ctx->d.n_owned, pD, pB}))) return rc;
+        const unsigned long long seqD = ctx->mail_seq;
+        ctx->d.pred = pD; ctx->d.dtp = ctx->dt_dev;
+        ELEM(k_end_press_update_pos, ctx->dt);
+        ctx->d.pred = nullptr; ctx->d.dtp = nullptr;
+        ctx->spec_visc_seq = seqB; ctx->spec_cfl_seq = seqC; ctx->spec_press_seq = seqD;
         ctx->nonp_begun = true;
         return WCSPH_OK;
       }
@@ -1193,12 +1230,17 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
 int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
   NEED_GRID();
   int rc;
-  if ((rc = wcsph_dfsph_warmstart_pressure(ctx))) return rc;
-  ctx->pr_iter = 0;
   double err = 0.0;
   const bool fusek = ctx->d.n_owned == ctx->d.nl;
-  if (fusek) PASS((k_drho_press<DRHO_BEGIN, true>), ctx->dt);
-  else if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
+  if (ctx->pr_resume) {   // wcsph_dfsph_step: the first two iterations ran speculatively and the device's decision was "go on"
+    ctx->pr_resume = false;
+    err = (double)ctx->avg_density_err / (double)ctx->d.n_owned;
+  } else {
+    if ((rc = wcsph_dfsph_warmstart_pressure(ctx))) return rc;
+    ctx->pr_iter = 0;
+    if (fusek) PASS((k_drho_press<DRHO_BEGIN, true>), ctx->dt);
+    else if ((rc = wcsph_dfsph_begin_pressure(ctx))) return rc;
+  }
   while (ctx->fix_pr > 0 ? ctx->pr_iter < ctx->fix_pr : ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100)) {
     if ((rc = pressure_iter_fused(ctx))) return rc;
     ctx->pr_iter++;
@@ -1240,16 +1282,25 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   ctx->in_step_spec = fuse && ctx->speculate;
   rc = wcsph_dfsph_solve_divergence(ctx);
   ctx->fuse_elem = false; ctx->in_step_spec = false;
-  if (rc) { ctx->nonp_begun = false; ctx->vort_in_div = false; ctx->spec_visc_seq = ctx->spec_cfl_seq = 0; return rc; }
+  if (rc) { ctx->nonp_begun = false; ctx->vort_in_div = false; ctx->spec_visc_seq = ctx->spec_cfl_seq = ctx->spec_press_seq = 0; return rc; }
   ctx->in_step = true;
   rc = wcsph_dfsph_compute_nonpressure_force(ctx);
   ctx->in_step = false;
   ctx->nonp_begun = false; ctx->vort_in_div = false;
   if (rc) { ctx->cfl_done = false; return rc; }
   if ((rc = wcsph_dfsph_optimize_time_step(ctx))) return rc;
-  if (fuse) { ELEM(k_update_vel_warm_scale, ctx->dt); ctx->warm_scaled = true; }
-  else if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
   ctx->fuse_elem = fuse;
+  if (ctx->spec_press_seq) {
+    // update_vel and the pressure solve up to its first decision ran behind the CFL reduction (solve_divergence queued them)
+    const unsigned long long seq = ctx->spec_press_seq;
+    ctx->spec_press_seq = 0;
+    if ((rc = collect_mail(ctx, true, seq))) { ctx->fuse_elem = false; return rc; }
+    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+    ctx->pr_iter = 2;
+    if (ctx->h_pred) { ctx->fuse_elem = false; return WCSPH_OK; }   // two iterations sufficed and the step's last kernel has run
+    ctx->pr_resume = true;                                            // go on from iteration 3, one decision at a time
+  } else if (fuse) { ELEM(k_update_vel_warm_scale, ctx->dt); ctx->warm_scaled = true; }
+  else if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
   rc = wcsph_dfsph_solve_pressure(ctx);
   ctx->fuse_elem = false; ctx->warm_scaled = false;
   if (rc) return rc;
