@@ -463,8 +463,8 @@ __device__ __forceinline__ uint4 nb_stream(const uint4 *p) {
 }
 #define NB_LO(w) ((int)(short)((w) & 0xffffu))
 #define NB_HI(w) ((int)(w) >> 16)
-// NT = 2: the stream is loaded non-temporally (the density pass, the first walk after the list build: measured 7 us
-// faster that way); NT = 1: only in builds with -DWCSPH_STREAM_NT=1 (rounds 1-2 loaded the stream of every once-per-step
+// NT = 2: the stream is loaded non-temporally (nobody at present: dfsph_kernels.h WCSPH_DENS_NT); NT = 1: only in builds with
+// -DWCSPH_STREAM_NT=1 (rounds 1-2 loaded the stream of every once-per-step
 // pass non-temporally, to keep it from displacing the gather records; since round 3 the elementwise traffic is what
 // stays out of the Infinity Cache -- ld_once / st_once -- and every walk after the first finds the stream there).
 #ifndef WCSPH_TAIL4

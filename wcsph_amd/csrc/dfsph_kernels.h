@@ -5,6 +5,16 @@
 #include "device.h"
 
 #define WAVES6
+// Cache policy of the density pass, the first walk after the list build (profiles/r03_experiments.md (11), (15)): its stream
+// loads are plain -- they keep the stream the list build just wrote in the Infinity Cache for the walks that follow -- and its
+// (pos, rho) records, which nobody gathers before the last divergence iteration, are stored non-temporally so that they do
+// not displace it.  (2 / 0 = the first cut: non-temporal stream loads made this pass 8 us faster and the next one 17 slower.)
+#ifndef WCSPH_DENS_NT
+#define WCSPH_DENS_NT 0
+#endif
+#ifndef WCSPH_PR_NT
+#define WCSPH_PR_NT 1
+#endif
 #define LOAD_I                                        \
   const int i = sorted_index(d);                       \
   const bool live = i < d.nl;                         \
@@ -16,7 +26,7 @@ __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
   LOAD_I
   if (!own) return;
   float sl = 0.f, ss = 0.f;
-  walk<8, 2>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
+  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
           [&](int, float3, float r2) { ss += cubic_W(d, r2); });
   const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
   d.rho[i] = rho;
@@ -29,7 +39,7 @@ __global__ void __launch_bounds__(BLOCK) k_coff(Dev d) {
   if (!own) return;
   float3 sg = f3(0, 0, 0);
   float sq = 0.f;
-  walk<8, 2>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             float g = cubic_gradW_scale(d, r2) * d.VL0;
             sq += g * g * r2;
@@ -46,7 +56,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
   if (!own) return;
   float sl = 0.f, ss = 0.f, sq = 0.f;
   float3 sg = f3(0, 0, 0);
-  walk<8, 2>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             sl += cubic_W(d, r2);
             float g = cubic_gradW_scale(d, r2) * d.VL0;
@@ -73,7 +83,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
   float sl = 0.f, ss = 0.f, sq = 0.f, a = 0.f;
   float3 sg = f3(0, 0, 0);
   const float3 vi = xyz(d.vel[i]);
-  walk<8, 2>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
           [&](int, float3 r, float r2, float4 vj) {
             sl += cubic_W(d, r2);
             const float gw = cubic_gradW_scale(d, r2);
@@ -90,7 +100,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
           });
   const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
   st_once(d.rho + i, rho);
-  d.pr[i] = make_float4(pi.x, pi.y, pi.z, rho);
+  if (WCSPH_PR_NT) st_once(d.pr + i, make_float4(pi.x, pi.y, pi.z, rho)); else d.pr[i] = make_float4(pi.x, pi.y, pi.z, rho);
   sq += dot3(sg, sg);
   st_once(d.alpha + i, (sq > d.eps) ? -1.0f / sq : 0.0f);
   const float kv = 0.5f * fmaxf(ld_once(d.kappa_v + i) / dt, -0.5f * d.rho_L0 * d.rho_L0);
