@@ -12,6 +12,11 @@
 #ifndef WCSPH_DENS_NT
 #define WCSPH_DENS_NT 0
 #endif
+// ... and the (pos, k) record of the divergence iteration that also takes the vorticity sums: in three steps of four it is
+// the LAST iteration and nobody reads the record (ab_vpk: -0.6 % at rest, nothing in the developed flow)
+#ifndef WCSPH_VPK_NT
+#define WCSPH_VPK_NT 1
+#endif
 #ifndef WCSPH_PR_NT
 #define WCSPH_PR_NT 1
 #endif
@@ -174,7 +179,11 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
     a = fmaxf(a, 0.0f);
     if (nc < 20) a = 0.0f;  // raw list length, Q2
     st_once(d.adv_rho + i, a);
+#if WCSPH_VPK_NT
+    st_once(d.pk + i, make_float4(pi.x, pi.y, pi.z, a * ld_once(d.alpha + i)));
+#else
     d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * ld_once(d.alpha + i));
+#endif
     dom = dom + wi * (-2.0f * d.vort_init * d.vort_coff * (float)nc);
     st_once(d.d_omega + i, f4(dom, 0));
     st_once(d.cg_s + i, f4(dv, 0));
