@@ -231,12 +231,26 @@ def _pull_iters():
     vs_iter, dv_iter, pr_iter = a.value, b.value, c.value
 
 
+_step_out = None
+
+
 def step():
-    """One pass of the reference main-loop body (dfsph.py:606-617) with the host loops inside the library."""
-    global current_time
-    _call("wcsph_dfsph_step")
-    _pull_iters()
-    dt = float(deltaT.to_numpy()[0])
+    """One pass of the reference main-loop body (dfsph.py:606-617) with the host loops inside the library.
+    The GPU waits for nothing but this function between two steps (the library queues a whole step behind its own decisions):
+    what happens here after the library call is on the critical path, so it is three ctypes calls on preallocated
+    arguments and nothing else."""
+    global current_time, vs_iter, dv_iter, pr_iter, _step_out
+    import ctypes as C
+    if _step_out is None:
+        a, b, c, f = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
+        _step_out = (a, b, c, f, C.byref(a), C.byref(b), C.byref(c), C.byref(f), _lib.SCALAR_ID["deltaT"])
+    a, b, c, f, ra, rb, rc, rf, dt_id = _step_out
+    ctx, lib = particle_data._need_ctx(), _lib.load()
+    _lib.check(ctx, lib.wcsph_dfsph_step(ctx))
+    lib.wcsph_get_iters(ctx, ra, rb, rc)
+    vs_iter, dv_iter, pr_iter = a.value, b.value, c.value
+    _lib.check(ctx, lib.wcsph_get_scalar(ctx, dt_id, rf))
+    dt = float(f.value)
     current_time += dt
     return dt
 
