@@ -1174,14 +1174,10 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
       ctx->d.pred = nullptr;
       if ((rc = nonpressure_visc_open(ctx, pA, {PRED_VISC, (double)ctx->p.viscosity_err, (double)ctx->p.eps, pB, pA}))) return rc;
       const unsigned long long seqB = ctx->mail_seq;
-      if ((rc = collect_mail(ctx, true, seqA))) return rc;
-      ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
-      err = thr;
-      ctx->dv_iter++;
-      if (ctx->h_pred) {   // the device left the loop: the continuation is running
-        // The GPU is busy with the viscosity walks for the next ~0.2 ms: time to queue the rest of the step behind them.
-        // (Not before mail A: when the divergence solve goes on -- one step in four once the column collapses -- every
-        // gated launch costs 3-5 us as a no-op, and twenty of them cost more than the waits they hide.)
+      // the rest of the step behind B's decision (see below); seqC / seqD: its two mails
+      unsigned long long seqC = 0, seqD = 0;
+      auto queue_rest = [&]() -> int {
+        int rc = 0;
         ctx->d.pred = pB;
         ELEM(k_finish_nonpressure, ctx->dt);
         // deltaT is formed on the device too: vs_iter = 1 on this branch (gated by "one PCG iteration sufficed"), pr_iter is last step's
@@ -1190,7 +1186,7 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
                            DtRule{ctx->dt_dev, ctx->dt, it, (double)ctx->p.eps, ctx->p.cfl_radius, ctx->p.user_max_t, ctx->p.user_min_t});
         ctx->d.pred = nullptr;
         if ((rc = publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pB}))) return rc;
-        const unsigned long long seqC = ctx->mail_seq;
+        seqC = ctx->mail_seq;
         // ... and the pressure solve up to its first decision (update_vel, warm start, begin, two iterations: dfsph.py:150-161
         // forces two), still gated by B, taking deltaT from the device; its end gated by its own decision (mail D)
         int *pD = ctx->pred_dev + 0;
@@ -1204,14 +1200,30 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
         ctx->d.pred = nullptr; ctx->d.dtp = nullptr;
         if (rc) return rc;
         if ((rc = publish_async(ctx, {PRED_PRESS, 0.001, (double)ctx->d.n_owned, pD, pB}))) return rc;
-        const unsigned long long seqD = ctx->mail_seq;
+        seqD = ctx->mail_seq;
         ctx->d.pred = pD; ctx->d.dtp = ctx->dt_dev;
         ELEM(k_end_press_update_pos, ctx->dt);
         ctx->d.pred = nullptr; ctx->d.dtp = nullptr;
+        return 0;
+      };
+      // Small problems (config C2: a kernel takes 5-10 us) cannot wait for mail A before queueing the rest -- the GPU would
+      // run dry while the host issues twenty launches; large ones do: when the divergence solve goes on -- one step in four
+      // once the column collapses -- every gated launch costs 3-5 us as a no-op, and twenty of them cost more than the waits
+      // they hide, while the viscosity walks keep the GPU busy for 0.2 ms after mail A.
+      const bool up_front = ctx->d.nl < 400000;
+      ctx->spec_prof_mark = ctx->prof_used;
+      if (up_front && (rc = queue_rest())) return rc;
+      if ((rc = collect_mail(ctx, true, seqA))) return rc;
+      ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+      err = thr;
+      ctx->dv_iter++;
+      if (ctx->h_pred) {   // the device left the loop: the continuation is running
+        if (!up_front && (rc = queue_rest())) return rc;
         ctx->spec_visc_seq = seqB; ctx->spec_cfl_seq = seqC; ctx->spec_press_seq = seqD;
         ctx->nonp_begun = true;
         return WCSPH_OK;
       }
+      ctx->prof_used = ctx->spec_prof_mark;
       ctx->vort_in_div = vort;   // nothing of the continuation ran
       continue;
     }
