@@ -10,7 +10,7 @@
  * "ref: file:line" are into /root/reference) and is pinned by
  *   - the analytic known-answers in tests/test_oracle_known_answers.py (kernel normalisation, lattice density 799.978,
  *     alpha, gradW samples, int32-wrap hash values, default-scene blockSize);
- *   - round 3: golden vectors produced by the reference's UNMODIFIED text (dfsph.py, sesph.py imported from
+ *   - round 3: golden vectors produced by the reference's UNMODIFIED text (dfsph.py, sesph.py, iisph.py imported from
  *     /root/reference on a serial Taichi stand-in, tests/golden/make_reference_fixtures.py -> tests/golden/ref_*.npz;
  *     tests/test_reference_fixtures.py).  That pins formulas, constants, list order and host control flow; it does not
  *     pin Taichi's execution semantics, so the label above stays.
