@@ -1283,6 +1283,9 @@ int wcsph_dfsph_solve_pressure(wcsph_ctx *ctx) {  // ref: dfsph.py:150-164
 int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   NEED_SETUP();
   int rc;
+  // a step that failed half-way (launch error, reported device condition) must not leave its speculation state behind
+  ctx->d.pred = nullptr; ctx->d.dtp = nullptr;
+  ctx->spec_visc_seq = ctx->spec_cfl_seq = ctx->spec_press_seq = 0; ctx->spec_dt = false; ctx->pr_resume = false;
   if ((rc = wcsph_grid_update(ctx))) return rc;
   if (ctx->d.n_owned == ctx->d.nl) {
     PASS(k_density_coff_warm, ctx->dt);  // compute_density + compute_dfsph_coff + first warm-start pass in one walk
