@@ -315,3 +315,42 @@ def test_neighbor_count_of_scattered_clusters(mode):
         pos[:len(liquid)] += rng.normal(0, 0.02, (len(liquid), 3)).astype(np.float32)   # move every liquid particle a little
         set_state(g, o, pos=pos)
     g.close()
+
+
+@pytest.mark.parametrize("n,steps,squeeze", [(10, 4, 0.85), (75, 2, 0.93)])
+def test_speculative_step_falls_back_when_a_solver_goes_on(n, steps, squeeze):
+    """wcsph_dfsph_step queues its common-case continuation behind the solver decisions (taken on the device) -- one
+    divergence iteration, one PCG iteration, two pressure iterations.  Here every one of the three decisions falls the OTHER
+    way (a squeezed, jittered block with random velocities and a stiff, tightly converged viscosity solve): the gated
+    launches must turn out no-ops and the host loops go on exactly as the reference's (dfsph.py:84-103, 131-164).
+    n = 10: the whole continuation is queued before the first mail arrives (small problems); n = 75 (421 875 particles): the
+    part behind the viscosity decision is queued once the divergence decision is known."""
+    from wcsph_amd import dfsph, scene
+    from oracle import Oracle
+    liquid, solid = scene.dam_break_dfsph(n)
+    rng = np.random.default_rng(7)
+    c = liquid.mean(0)
+    liquid = c + squeeze * (liquid - c) + rng.uniform(-0.2, 0.2, liquid.shape) * scene.PARTICLE_RADIUS
+    vel0 = (rng.uniform(-1, 1, (len(liquid), 3)) * 2.0).astype(np.float32)
+    pd = dfsph.init_particle(particleDim=n, neighbor_mode="faithful", liquid=liquid, boundary=solid, viscosity=100.0, viscosity_err=1e-4)
+    o = Oracle(pd.pos.to_numpy(), pd.liquid_count, 0.025, mode="faithful")
+    dfsph.reset_param(); o.reset_param()
+    o.viscosity, o.viscosity_err = 100.0, 1e-4
+    pd.vel.from_numpy(vel0); o.vel[...] = vel0
+    seen = []
+    for s in range(steps):
+        dfsph.step()
+        o.dfsph_step()
+        seen.append((o.vs_iter, o.dv_iter, o.pr_iter))
+        assert (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter) == seen[-1], (s, seen)
+        # dt is CFL-limited here: it follows max |v|, which agrees to ~4e-6 in this violent scene (the per-kernel entry
+        # points, which do not speculate, show the same 1-2e-6 in dt)
+        assert abs(dfsph.deltaT[0] - o.deltaT) <= 2e-5 * o.deltaT
+        assert np.abs(pd.rho.to_numpy() - o.rho).max() / o.rho.max() < 1e-4
+        assert rel_err(pd.vel.to_numpy(), o.vel) < 1e-3
+        assert np.abs(pd.pos.to_numpy() - o.pos).max() < 1e-5
+        assert rel_err(dfsph.kappa.to_numpy(), o.kappa) < 1e-3
+        assert rel_err(pd.vel_guess.to_numpy(), o.vel_guess) < 1e-3
+    a = np.array(seen)
+    assert a[:, 0].max() >= 2 and a[:, 1].max() >= 2 and a[:, 2].max() >= 3, seen   # every fallback was taken
+    pd.close(); o.close()
