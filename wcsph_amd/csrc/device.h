@@ -162,10 +162,7 @@ __device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int
 // displacing what the neighbour passes come back to launch after launch: the 16-bit neighbour streams and the gather
 // records.  Arrays that a following pass GATHERS (pos, vel, pk, pr, vel_guess, cg_dir, omega) stay on plain accesses.
 #ifndef WCSPH_ONCE
-#define WCSPH_ONCE 1
-#endif
-#ifndef WCSPH_ONCE_ST
-#define WCSPH_ONCE_ST WCSPH_ONCE
+#define WCSPH_ONCE 1   /* -DWCSPH_ONCE=0: plain accesses everywhere (the A/B build of profiles/r03n_ab_once.md) */
 #endif
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_once(const float4 *p) {
@@ -191,7 +188,7 @@ __device__ __forceinline__ int ld_once(const int *p) {
 #endif
 }
 __device__ __forceinline__ void st_once(float4 *p, float4 v) {
-#if WCSPH_ONCE_ST
+#if WCSPH_ONCE
   v4f_nt w = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(w, reinterpret_cast<v4f_nt *>(p));
 #else
@@ -199,14 +196,14 @@ __device__ __forceinline__ void st_once(float4 *p, float4 v) {
 #endif
 }
 __device__ __forceinline__ void st_once(float *p, float v) {
-#if WCSPH_ONCE_ST
+#if WCSPH_ONCE
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;
 #endif
 }
 __device__ __forceinline__ void st_once(int *p, int v) {
-#if WCSPH_ONCE_ST
+#if WCSPH_ONCE
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;
@@ -450,27 +447,12 @@ template <class T>
 __device__ __forceinline__ T nb_ld(const T *base, int j) {
   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)j * (unsigned)sizeof(T));
 }
-// a stream block, optionally non-temporal (see walk<.., NT>)
-#ifndef WCSPH_STREAM_NT
-#define WCSPH_STREAM_NT 0   /* 1: the once-per-step passes load the stream non-temporally (rounds 1-2) */
-#endif
-template <int NT>
-__device__ __forceinline__ uint4 nb_stream(const uint4 *p) {
-  if (!(NT == 2 || (NT == 1 && WCSPH_STREAM_NT))) return *p;
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
 #define NB_LO(w) ((int)(short)((w) & 0xffffu))
 #define NB_HI(w) ((int)(w) >> 16)
-// NT = 2: the stream is loaded non-temporally (nobody at present: dfsph_kernels.h WCSPH_DENS_NT); NT = 1: only in builds with
-// -DWCSPH_STREAM_NT=1 (rounds 1-2 loaded the stream of every once-per-step
-// pass non-temporally, to keep it from displacing the gather records; since round 3 the elementwise traffic is what
-// stays out of the Infinity Cache -- ld_once / st_once -- and every walk after the first finds the stream there).
-#ifndef WCSPH_TAIL4
-#define WCSPH_TAIL4 1   /* 0: rounds 1-3 form (every trip eight slots); the same for the solid stream measured no gain */
-#endif
-template <int U, int NT = 0, class GL, class FL, class FS>
+// The stream is loaded plainly by every pass (rounds 1-2 loaded it non-temporally in the once-per-step passes, to keep it from
+// displacing the gather records; since round 3 the elementwise traffic is what stays out of the Infinity Cache -- ld_once /
+// st_once -- and every walk after the list build finds the stream there).
+template <int U, class GL, class FL, class FS>
 __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float4 *P, GL &&gl, FL &&fl, FS &&fs) {
   static_assert(U == 4 || U == 8, "U slots per trip");
   const float3 xi = xyz(pi);
@@ -484,9 +466,9 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
 #define WALK_OK(u, dd) const bool ok##u = (k + u < cl) & NB_IS_ENTRY(dd);   /* a lane mask in SGPRs: the deltas die here */
   // the stream block of the NEXT trip is requested before this trip's gathers go out: its (HBM) latency hides behind
   // the gathers and the arithmetic instead of heading the next trip's dependency chain
-  uint4 en = cl > 0 ? nb_stream<NT>(L) : make_uint4(0, 0, 0, 0);
+  uint4 en = cl > 0 ? *(L) : make_uint4(0, 0, 0, 0);
   for (int k = 0; k < cl; k += U) {
-    if (U == 8 && WCSPH_TAIL4 && __builtin_amdgcn_ballot_w64(k + 4 < cl) == 0) {
+    if (U == 8 && __builtin_amdgcn_ballot_w64(k + 4 < cl) == 0) {
       // last trip of the wave and no lane's list reaches the block's second half: four slots instead of eight (a gather
       // instruction costs its 16+ cycles whether or not a lane takes part, profiles/r03l_gather_rate.txt)
       const uint4 e = en;
@@ -500,7 +482,7 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
       WALK_ONE(0, ok0, j0, p0, b0) WALK_ONE(1, ok1, j1, p1, b1) WALK_ONE(2, ok2, j2, p2, b2) WALK_ONE(3, ok3, j3, p3, b3)
     } else if (U == 8) {
       const uint4 e = en;
-      if (k + 8 < cl) en = nb_stream<NT>(L + (size_t)((k >> 3) + 1) * st);
+      if (k + 8 < cl) en = *(L + (size_t)((k >> 3) + 1) * st);
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
       run = j7;
@@ -515,7 +497,7 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
       WALK_ONE(4, ok4, j4, p4, b4) WALK_ONE(5, ok5, j5, p5, b5) WALK_ONE(6, ok6, j6, p6, b6) WALK_ONE(7, ok7, j7, p7, b7)
     } else {
       const uint2 e = (k & 4) ? make_uint2(en.z, en.w) : make_uint2(en.x, en.y);   // k is wave-uniform
-      if ((k & 4) && k + 4 < cl) en = nb_stream<NT>(L + (size_t)((k >> 3) + 1) * st);
+      if ((k & 4) && k + 4 < cl) en = *(L + (size_t)((k >> 3) + 1) * st);
       const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y);
       const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3;
       run = j3;
@@ -534,7 +516,7 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   run = d.nsbase[i];
 #define WALK_SOL(u, dd, jj, pp) if (k + u < cs && NB_IS_ENTRY(dd)) { const float3 r = xi - xyz(pp); fs(jj, r, dot3(r, r)); }
   for (int k = 0; k < cs; k += 8) {
-    const uint4 e = nb_stream<NT>(S + (size_t)(k >> 3) * st);
+    const uint4 e = *(S + (size_t)(k >> 3) * st);
     const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
     const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
     run = j7;

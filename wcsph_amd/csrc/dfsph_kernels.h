@@ -8,18 +8,8 @@
 // Cache policy of the density pass, the first walk after the list build (profiles/r03_experiments.md (11), (15)): its stream
 // loads are plain -- they keep the stream the list build just wrote in the Infinity Cache for the walks that follow -- and its
 // (pos, rho) records, which nobody gathers before the last divergence iteration, are stored non-temporally so that they do
-// not displace it.  (2 / 0 = the first cut: non-temporal stream loads made this pass 8 us faster and the next one 17 slower.)
-#ifndef WCSPH_DENS_NT
-#define WCSPH_DENS_NT 0
-#endif
-// ... and the (pos, k) record of the divergence iteration that also takes the vorticity sums: in three steps of four it is
-// the LAST iteration and nobody reads the record (ab_vpk: -0.6 % at rest, nothing in the developed flow)
-#ifndef WCSPH_VPK_NT
-#define WCSPH_VPK_NT 1
-#endif
-#ifndef WCSPH_PR_NT
-#define WCSPH_PR_NT 1
-#endif
+// not displace it.  The (pos, k) record of the divergence iteration that also takes the vorticity sums likewise: in three
+// steps of four it is the LAST iteration and nobody reads the record.
 #define LOAD_I                                        \
   const int i = sorted_index(d);                       \
   const bool live = i < d.nl;                         \
@@ -40,7 +30,7 @@ __global__ void __launch_bounds__(BLOCK) k_density(Dev d) {
   LOAD_I
   if (!own) return;
   float sl = 0.f, ss = 0.f;
-  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
+  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); }, [&](int, float3, float r2, NoPayload) { sl += cubic_W(d, r2); },
           [&](int, float3, float r2) { ss += cubic_W(d, r2); });
   const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
   d.rho[i] = rho;
@@ -53,7 +43,7 @@ __global__ void __launch_bounds__(BLOCK) k_coff(Dev d) {
   if (!own) return;
   float3 sg = f3(0, 0, 0);
   float sq = 0.f;
-  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             float g = cubic_gradW_scale(d, r2) * d.VL0;
             sq += g * g * r2;
@@ -70,7 +60,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff(Dev d) {
   if (!own) return;
   float sl = 0.f, ss = 0.f, sq = 0.f;
   float3 sg = f3(0, 0, 0);
-  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
+  walk<8>(d, i, pi, d.pos, [](int, float4) { return NoPayload(); },
           [&](int, float3 r, float r2, NoPayload) {
             sl += cubic_W(d, r2);
             float g = cubic_gradW_scale(d, r2) * d.VL0;
@@ -97,7 +87,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
   float sl = 0.f, ss = 0.f, sq = 0.f, a = 0.f;
   float3 sg = f3(0, 0, 0);
   const float3 vi = xyz(d.vel[i]);
-  walk<8, WCSPH_DENS_NT>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
+  walk<8>(d, i, pi, d.pos, [&](int j, float4) { return nb_ld(d.vel, j); },
           [&](int, float3 r, float r2, float4 vj) {
             sl += cubic_W(d, r2);
             const float gw = cubic_gradW_scale(d, r2);
@@ -114,7 +104,7 @@ __global__ void __launch_bounds__(BLOCK) k_density_coff_warm(Dev d, float dt) {
           });
   const float rho = d.VL0 * d.rho_L0 * (d.mk_h3 + sl) + d.VS0 * d.rho_S0 * ss;
   st_once(d.rho + i, rho);
-  if (WCSPH_PR_NT) st_once(d.pr + i, make_float4(pi.x, pi.y, pi.z, rho)); else d.pr[i] = make_float4(pi.x, pi.y, pi.z, rho);
+  st_once(d.pr + i, make_float4(pi.x, pi.y, pi.z, rho));
   sq += dot3(sg, sg);
   st_once(d.alpha + i, (sq > d.eps) ? -1.0f / sq : 0.0f);
   const float kv = 0.5f * fmaxf(ld_once(d.kappa_v + i) / dt, -0.5f * d.rho_L0 * d.rho_L0);
@@ -188,11 +178,7 @@ __global__ void __launch_bounds__(BLOCK) k_drho_div_iter_vort(Dev d, float dt) {
     a = fmaxf(a, 0.0f);
     if (nc < 20) a = 0.0f;  // raw list length, Q2
     st_once(d.adv_rho + i, a);
-#if WCSPH_VPK_NT
     st_once(d.pk + i, make_float4(pi.x, pi.y, pi.z, a * ld_once(d.alpha + i)));
-#else
-    d.pk[i] = make_float4(pi.x, pi.y, pi.z, a * ld_once(d.alpha + i));
-#endif
     dom = dom + wi * (-2.0f * d.vort_init * d.vort_coff * (float)nc);
     st_once(d.d_omega + i, f4(dom, 0));
     st_once(d.cg_s + i, f4(dv, 0));
@@ -408,7 +394,7 @@ __device__ __forceinline__ float3 visc_Ax(const Dev &d, int i, float4 pi, const 
   float3 ret = f3(0, 0, 0);
   const float cl = d.dim_coff * d.visc * d.mass;
   const float cs = d.dim_coff * d.visc_b * d.rho_S0 / rhoi * d.VS0;
-  walk<8, 1>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(x, j); xj.w = p.w; return xj; },
+  walk<8>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(x, j); xj.w = p.w; return xj; },
           [&](int, float3 r, float r2, float4 xj) {
             float s = cl * dot3(xi - xyz(xj), r) * frcp(xj.w * (r2 + e));
             ret = ret + r * (s * cubic_gradW_scale(d, r2));
@@ -441,7 +427,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
     m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
     m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
   };
-  walk<8, 1>(d, i, pi, d.pr, [](int, float4 p) { return p.w; },
+  walk<8>(d, i, pi, d.pr, [](int, float4 p) { return p.w; },
           [&](int, float3 r, float r2, float rhoj) { accum(r, cl * frcp(rhoj * (r2 + e)) * cubic_gradW_scale(d, r2)); },
           [&](int, float3 r, float r2) { accum(r, cs * frcp(r2 + e) * cubic_gradW_scale(d, r2)); });
   const float f = dt / rhoi;
@@ -490,7 +476,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
       m00 += s * r.x * r.x; m01 += s * r.x * r.y; m02 += s * r.x * r.z;
       m11 += s * r.y * r.y; m12 += s * r.y * r.z; m22 += s * r.z * r.z;
     };
-    walk<8, 1>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(d.vel_guess, j); xj.w = p.w; return xj; },
+    walk<8>(d, i, pi, d.pr, [&](int j, float4 p) { float4 xj = nb_ld(d.vel_guess, j); xj.w = p.w; return xj; },
             [&](int, float3 r, float r2, float4 xj) {
               const float c = cl * cubic_gradW_scale(d, r2) * frcp(xj.w * (r2 + e));
               accum(r, c);
@@ -543,7 +529,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float 
     const float c2 = d.vort_coff / rhoi * d.mass;
     const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
     struct XVW { float4 x, v, w; };
-    walk<4, 1>(d, i, pi, d.pr, [&](int j, float4 p) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = p.w; q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
+    walk<4>(d, i, pi, d.pr, [&](int j, float4 p) { XVW q; q.x = nb_ld(d.vel_guess, j); q.x.w = p.w; q.v = nb_ld(d.vel, j); q.w = nb_ld(d.omega, j); return q; },
             [&](int, float3 r, float r2, XVW q) {
               const float g = cubic_gradW_scale(d, r2);
               const float irho = frcp(q.x.w);
@@ -650,7 +636,7 @@ __global__ void __launch_bounds__(BLOCK) k_vorticity(Dev d, float dt) {
   const float c2 = d.vort_coff / rhoi * d.mass;
   const float c3 = d.vort_coff / rhoi * d.vort_init * d.mass;
   struct WV { float4 w, v; };
-  walk<4, 1>(d, i, pi, d.pr, [&](int j, float4 q) { WV p; p.w = nb_ld(d.omega, j); p.w.w = q.w; p.v = nb_ld(d.vel, j); return p; },
+  walk<4>(d, i, pi, d.pr, [&](int j, float4 q) { WV p; p.w = nb_ld(d.omega, j); p.w.w = q.w; p.v = nb_ld(d.vel, j); return p; },
        [&](int, float3 r, float r2, WV pj) {
          float3 dw = wi - xyz(pj.w);
          float g = cubic_gradW_scale(d, r2);
