@@ -162,25 +162,30 @@ struct HostMail { double acc[8]; int flags[4]; unsigned long long seq; int pred;
 __global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned long long seq, PredSpec ps) {
   const int t = threadIdx.x;
   if (ps.gate && *ps.gate == 0) { if (t == 0 && ps.out) *ps.out = 0; return; }
-  if (t < 8) {
-    double v = 0.0;
-    for (int k = 0; k < ACC_STRIPES; k++) v += acc[t * ACC_STRIPES + k];
-    m->acc[t] = v;
-    if (t == ACC_ERR) {
-      int stop = 0;
-      const double e = (double)(float)v;                       // avg_density_err is a float32 field
-      if (ps.kind == PRED_PRESS) stop = !(e / ps.n > ps.thr);   // dfsph.py:160-161: while err > 0.001, err = avg_density_err / N
-      else if (ps.kind == PRED_DIV) stop = !(e > ps.thr);       // dfsph.py:141: while avg_density_err > err
-      else if (ps.kind == PRED_VISC) {                          // dfsph.py:96-97 after the first compute_viscosity_force
-        double dz = 0.0, dn = 0.0;
-        for (int k = 0; k < ACC_STRIPES; k++) { dz += acc[ACC_DZERO * ACC_STRIPES + k]; dn += acc[ACC_DNEW * ACC_STRIPES + k]; }
-        const double dzero = (double)(float)dz, delta = (double)(float)dn;   // cg_delta_zero, cg_delta: float32 fields
-        stop = (delta <= ps.thr * dzero) || (dzero < ps.n);
-      } else if (ps.kind == PRED_PASS) stop = 1;
-      m->pred = stop;
-      if (ps.out) *ps.out = stop;
-    }
-  } else if (t < 12) {
+  // one wave: lane t holds stripe t of every slot (eight independent loads in flight), the totals are formed by the same
+  // shuffle tree as acc_total() on the device -- host and device see the same bits -- and land in lane 0
+  static_assert(ACC_STRIPES == WAVE, "one stripe per lane");
+  double tot[8];
+#pragma unroll
+  for (int sl = 0; sl < 8; sl++) tot[sl] = acc[sl * ACC_STRIPES + t];
+#pragma unroll
+  for (int sl = 0; sl < 8; sl++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot[sl] += __shfl_down(tot[sl], o, WAVE);
+  if (t == 0) {
+#pragma unroll
+    for (int sl = 0; sl < 8; sl++) m->acc[sl] = tot[sl];
+    int stop = 0;
+    const double e = (double)(float)tot[ACC_ERR];              // avg_density_err is a float32 field
+    if (ps.kind == PRED_PRESS) stop = !(e / ps.n > ps.thr);   // dfsph.py:160-161: while err > 0.001, err = avg_density_err / N
+    else if (ps.kind == PRED_DIV) stop = !(e > ps.thr);       // dfsph.py:141: while avg_density_err > err
+    else if (ps.kind == PRED_VISC) {                          // dfsph.py:96-97 after the first compute_viscosity_force
+      const double dzero = (double)(float)tot[ACC_DZERO], delta = (double)(float)tot[ACC_DNEW];   // cg_delta_zero, cg_delta: float32 fields
+      stop = (delta <= ps.thr * dzero) || (dzero < ps.n);
+    } else if (ps.kind == PRED_PASS) stop = 1;
+    m->pred = stop;
+    if (ps.out) *ps.out = stop;
+  } else if (t >= 8 && t < 12) {
     m->flags[t - 8] = flags[t - 8];
     if (t - 8 == FLAG_ERR) flags[FLAG_ERR] = 0;   // handed over: reported exactly once
   }
