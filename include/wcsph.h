@@ -279,6 +279,14 @@ int wcsph_bucket_hist(wcsph_ctx *ctx, int which, void **d_ptr, int64_t *n);
  * halves independently; half the bytes of the plain histogram); _unpack() after the all-reduce, before _grid_update_end() */
 int wcsph_bucket_hist_pack(wcsph_ctx *ctx, void **d_ptr, int64_t *n_words);
 int wcsph_bucket_hist_unpack(wcsph_ctx *ctx);
+/* Once per step, before the rows change owner (no reference counterpart: the reference is single-device): classify the n
+ * state rows at d_rows (wcsph_load_state's row format, device memory) by their GLOBAL cell column c (HashGrid.py:68) against
+ * this slab's cuts [lo, hi): list 0 / 1 = lo <= c < lo + ghost / hi - ghost <= c < hi (ghosts of the left / right neighbour),
+ * list 2 / 3 = c < lo / c >= hi (change owner), count 4 = further than `ghost` columns beyond a cut (the caller's error).
+ * has_left / has_right: whether there is a neighbour on that side.  d_idx: device int64 [4][cap] row indices, d_counts:
+ * device int32 [5] (zeroed here); a count above cap means that list is truncated.  One launch on the context's stream. */
+int wcsph_slab_classify(wcsph_ctx *ctx, const void *d_rows, int64_t n, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right,
+                        int64_t *d_idx, int32_t cap, int32_t *d_counts);
 /* rows d_idx[0..n) (original indices, device array) of n_fields fields (enum wcsph_field, vec3 / scalar) side by side:
  * d_out / d_in is a device buffer [n][sum of widths] f32; one launch each */
 int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, void *d_out);

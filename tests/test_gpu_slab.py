@@ -181,3 +181,40 @@ def test_native_slab_step_equals_the_python_phase_driver(tmp_path, mode):
     np.testing.assert_allclose(logs[0][:, 3], logs[1][:, 3], rtol=1e-7)
     dpos, dvel, _ = slab_util.match_rows(rows[0], rows[1])
     assert dpos < 1e-6 and dvel < 1e-4
+
+
+def test_native_classifier_equals_the_torch_classification():
+    """wcsph_slab_classify (one launch) against the torch form of SlabSim.redistribute: the same four row sets and the same
+    five counts, cell columns formed as the grid update forms them (ref: HashGrid.py:68), including rows exactly on a cut"""
+    import slab_util
+    from wcsph_amd.slab import HipBackend, GHOST_CELLS, STATE_W
+    dev = torch.device("cuda", 0)
+    liquid, solid, bounds = slab_util.test_scene(8)
+    B = HipBackend(capacity=20000, solid_local=solid, bounds=bounds, window=(0, 17), particleR=0.025, device=dev)
+    minx, inv = np.float32(bounds[0][0]), np.float32(1.0 / (2 * 0.025))       # HashGrid.py:46: gridR = 2 R
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = 150001
+    rows = torch.rand((n, STATE_W), generator=g)
+    lo, hi = 7, 19
+    rows[:, 0] = float(minx) + rows[:, 0] * float(26.0 / inv)
+    rows[:64, 0] = float(minx) + torch.arange(64, dtype=torch.float32) * float(np.float32(0.5) / inv)     # cell edges
+    rows = rows.to(dev)
+    cx = torch.trunc((rows[:, 0] - float(minx)) * float(inv)).to(torch.int64)
+    torch.cuda.synchronize()
+    for has_l, has_r in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        with torch.cuda.stream(B.stream):       # as SlabSim.step does: the library's launches and torch's share one stream
+            got = B.classify_rows(rows, lo, hi, GHOST_CELLS, has_l, has_r)
+            torch.cuda.synchronize()
+        assert got is not None
+        cnt, lists = got
+        G = GHOST_CELLS
+        f = torch.zeros_like(cx, dtype=torch.bool)
+        go_l = (cx < lo) & (cx >= lo - G) if has_l else f
+        go_r = (cx >= hi) & (cx < hi + G) if has_r else f
+        lost = ((cx < lo - G) if has_l else f) | ((cx >= hi + G) if has_r else f)
+        near_l = (cx >= lo) & (cx < lo + G) & ~go_r & ~lost if has_l else f
+        near_r = (cx < hi) & (cx >= hi - G) & ~go_l & ~lost if has_r else f
+        for want, have in zip((near_l, near_r, go_l, go_r), lists):
+            assert torch.equal(torch.nonzero(want).flatten(), torch.sort(have)[0])
+        assert cnt == [int(near_l.sum()), int(near_r.sum()), int(go_l.sum()), int(go_r.sum()), int(lost.sum())]
+    B.close()

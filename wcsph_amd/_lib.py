@@ -74,7 +74,7 @@ OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_c
          "wcsph_surface_anisotropic_kernel", "wcsph_dfsph_step_fixed", "wcsph_sample_surface", "wcsph_mc_tables",
          "wcsph_mc_setup", "wcsph_mc_surface_value", "wcsph_mc_value_to_host", "wcsph_mc_marching_cube", "wcsph_canvas_draw",
          "wcsph_set_owned_columns", "wcsph_set_global_liquid", "wcsph_grid_update_begin", "wcsph_grid_update_end", "wcsph_bucket_hist", "wcsph_bucket_hist_pack", "wcsph_bucket_hist_unpack",
-         "wcsph_halo_pack", "wcsph_halo_unpack", "wcsph_slab_set_halo", "wcsph_slab_step", "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
+         "wcsph_slab_classify", "wcsph_halo_pack", "wcsph_halo_unpack", "wcsph_slab_set_halo", "wcsph_slab_step", "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
 ALL_SYMBOLS = CTX_ONLY + OTHER
 
 # include/wcsph.h: wcsph_slab_callbacks (the caller's communicator behind wcsph_slab_step)
@@ -162,6 +162,7 @@ def load():
     lib.wcsph_bucket_hist.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.wcsph_bucket_hist_pack.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.wcsph_bucket_hist_unpack.argtypes = [vp]
+    lib.wcsph_slab_classify.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp]
     lib.wcsph_halo_pack.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
     lib.wcsph_halo_unpack.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
     lib.wcsph_hashgrid_count_to_host.argtypes = [vp, vp, C.c_int64]

@@ -566,6 +566,46 @@ __global__ void k_permute1(float *f, const int *where, int n, const float *in) {
   if (o >= n) return;
   f[where[o]] = in[o];
 }
+// slab decomposition, once per step: which owned rows (state rows in the caller's order, x in column 0) sit within `ghost`
+// cell columns of a cut with a neighbour (class 0 / 1: left / right -- they are ghosts over there), which have crossed it
+// (2 / 3: they change owner), which are further than a ghost layer beyond it (4: CFL broken).  One pass; the row indices
+// of classes 0..3 are appended to four lists.  A workgroup takes CLS_ROWS rows per thread, counts its classes in LDS and
+// reserves its share of each list with ONE device atomic per class (one per wave was 125 k atomics on five addresses at
+// 2 M rows: 1 ms); order inside a list is arbitrary.  Cell column exactly as the grid update forms it (ref: HashGrid.py:68).
+constexpr int CLS_ROWS = 16;
+__global__ void __launch_bounds__(BLOCK) k_slab_classify(const float *rows, long long n, int W, float minx, float inv_grid, int lo, int hi, int ghost,
+                                                         int has_l, int has_r, long long *idx, int cap, int *counts) {
+  __shared__ int cnt[5], base[5];
+  if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const long long first = (long long)blockIdx.x * (BLOCK * CLS_ROWS) + threadIdx.x;
+  unsigned long long cls_of = 0;      // 4 bits per row: class + 1, 0 = interior
+  int at[CLS_ROWS];
+#pragma unroll
+  for (int r = 0; r < CLS_ROWS; r++) {
+    const long long i = first + (long long)r * BLOCK;
+    int cls = -1;
+    if (i < n) {
+      const int cx = (int)__fmul_rn(__fsub_rn(rows[i * W], minx), inv_grid);
+      if (has_l) { if (cx < lo + ghost) cls = 0; if (cx < lo) cls = 2; if (cx < lo - ghost) cls = 4; }
+      if (has_r) { if (cx >= hi - ghost) cls = 1; if (cx >= hi) cls = 3; if (cx >= hi + ghost) cls = 4; }
+    }
+    at[r] = cls >= 0 ? atomicAdd(&cnt[cls], 1) : 0;
+    cls_of |= (unsigned long long)(cls + 1) << (4 * r);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < CLS_ROWS; r++) {
+    const int cls = (int)((cls_of >> (4 * r)) & 15) - 1;
+    if (cls >= 0 && cls < 4) {
+      const int o = base[cls] + at[r];
+      if (o < cap) idx[(size_t)cls * cap + o] = first + (long long)r * BLOCK;
+    }
+  }
+}
+
 // halo pack / unpack of SEVERAL fields in one launch: out[k][W] = the listed fields of original row idx[k], side by side
 struct HaloFields { int n; const float *ptr[8]; int width[8], stride[8]; int W; };
 __global__ void k_halo_pack(HaloFields h, const int *where, const int *idx, int n, float *out) {

@@ -1815,6 +1815,18 @@ static int halo_fields(wcsph_ctx *ctx, int nf, const int32_t *fields, HaloFields
   }
   return 0;
 }
+int wcsph_slab_classify(wcsph_ctx *ctx, const void *d_rows, int64_t n, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right,
+                        int64_t *d_idx, int32_t cap, int32_t *d_counts) {
+  NEED_SETUP();
+  if (n < 0 || cap < 0 || (n > 0 && !d_rows) || !d_idx || !d_counts) return WCSPH_EARG;
+  HIPCHK(hipMemsetAsync(d_counts, 0, 5 * sizeof(int32_t), ctx->stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)d_rows, (long long)n, STATE_W,
+                       ctx->d.minx, ctx->d.inv_grid, lo, hi, ghost, has_left, has_right, (long long *)d_idx, cap, d_counts);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+
 int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, void *d_out) {
   NEED_SETUP();
   HaloFields h;

@@ -105,10 +105,28 @@ class HipBackend:
         self._chk(self.lib.wcsph_load_state(self.ctx, int(n_owned), int(rows.shape[0]), C.c_void_p(rows.data_ptr())))
         self._keep = rows  # keep alive until the stream has consumed it
 
+    def classify_rows(self, rows, lo, hi, ghost, has_l, has_r):
+        """wcsph_slab_classify: ((near_l, near_r, go_l, go_r, lost) counts, four int64 index lists) in one launch and one
+        host wait; None when a list did not fit its buffer (the caller falls back to the torch form)"""
+        n = int(rows.shape[0])
+        cap = max(65536, n // 8)
+        if getattr(self, "_cls_idx", None) is None or self._cls_idx.shape[1] < cap:
+            self._cls_idx = torch.empty((4, cap), dtype=torch.int64, device=self.device)
+            self._cls_cnt = torch.empty(5, dtype=torch.int32, device=self.device)
+        rows = rows.contiguous()
+        self._chk(self.lib.wcsph_slab_classify(self.ctx, C.c_void_p(rows.data_ptr()), n, int(lo), int(hi), int(ghost), int(has_l), int(has_r),
+                                               C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.c_void_p(self._cls_cnt.data_ptr())))
+        c = self._cls_cnt.tolist()
+        if max(c[:4]) > self._cls_idx.shape[1]:
+            return None
+        return c, [self._cls_idx[k, :c[k]] for k in range(4)]
+
     def store_state(self):
-        out = torch.empty((self.n_owned, STATE_W), dtype=torch.float32, device=self.device)
-        self._chk(self.lib.wcsph_store_state(self.ctx, C.c_void_p(out.data_ptr())))
-        return out
+        # a view of a slightly larger buffer: rows that arrive next step are appended in place (SlabSim._swap_rows)
+        slack = max(4096, self.n_owned // 64)
+        base = torch.empty((self.n_owned + slack, STATE_W), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.wcsph_store_state(self.ctx, C.c_void_p(base.data_ptr())))
+        return base[:self.n_owned]
 
     def grid_update(self):
         self._chk(self.lib.wcsph_grid_update(self.ctx))
@@ -574,47 +592,107 @@ class SlabSim:
             self.B.load_state(self.n_owned, rows)
             return
         G = GHOST_CELLS
-        cx = self._cellx(rows)
+        n = rows.shape[0]
         has_l, has_r = self.rank > 0, self.rank < self.world - 1
-        false = torch.zeros_like(cx, dtype=torch.bool)
-        go_l = (cx < self.lo) if has_l else false
-        go_r = (cx >= self.hi) if has_r else false
-        stay = ~(go_l | go_r)
-        near_l = (stay & (cx < self.lo + G)) if has_l else false
-        near_r = (stay & (cx >= self.hi - G)) if has_r else false
-        lost = ((cx < self.lo - G) & has_l) | ((cx >= self.hi + G) & has_r)     # more than a ghost layer per step: CFL broken
-        n_ml, n_mr, n_lost = self._host(torch.stack([go_l.sum(), go_r.sum(), lost.sum()]))
+        # classification of every owned row by its cell column: 1 / 2 = stays within G columns of the left / right cut (a
+        # ghost over there), 3 / 4 = crossed the left / right cut (changes owner), 5 = more than a ghost layer beyond a cut
+        # in one step (CFL broken).  ONE pass over the rows, ONE compaction of the ~6 % that are not interior, ONE host wait.
+        native = self.B.classify_rows(rows, self.lo, self.hi, G, has_l, has_r) if (rows.is_cuda and hasattr(self.B, "classify_rows")) else None
+        if native is not None:       # one launch of the library + one host wait (the lists come in arbitrary order)
+            (n_nl, n_nr, n_ml, n_mr, n_lost), (idx_nl, idx_nr, idx_gl, idx_gr) = native
+            self.n_host_waits += 1
+        else:
+            cx = self._cellx(rows)
+            code = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            if has_l:
+                code = torch.where(cx < self.lo + G, 1, code)
+                code = torch.where(cx < self.lo, 3, code)
+                code = torch.where(cx < self.lo - G, 5, code)
+            if has_r:
+                code = torch.where(cx >= self.hi - G, 2, code)
+                code = torch.where(cx >= self.hi, 4, code)
+                code = torch.where(cx >= self.hi + G, 5, code)
+            idx = torch.nonzero(code).flatten()
+            sub = code[idx].to(torch.int64)
+            c = self._host(torch.bincount(sub, minlength=6))
+            n_nl, n_nr, n_ml, n_mr, n_lost = int(c[1]), int(c[2]), int(c[3]), int(c[4]), int(c[5])
+            idx = idx[torch.argsort(sub, stable=True)]           # by class, ascending row index inside a class
+            idx_nl, idx_nr = idx[:n_nl], idx[n_nl:n_nl + n_nr]
+            idx_gl, idx_gr = idx[n_nl + n_nr:n_nl + n_nr + n_ml], idx[n_nl + n_nr + n_ml:n_nl + n_nr + n_ml + n_mr]
         if n_lost:
             raise RuntimeError("rank %d: %d particles moved more than %d cell columns past a cut in one step (CFL violated); "
                                "they would land outside the neighbour's cell window" % (self.rank, n_lost, G))
-        new_index = torch.cumsum(stay.to(torch.int64), 0) - 1                    # row index after the leavers are removed
-        idx_nl, idx_nr = torch.nonzero(near_l).flatten(), torch.nonzero(near_r).flatten()
-        mig_l = rows.index_select(0, torch.nonzero(go_l).flatten()) if n_ml else rows[:0]
-        mig_r = rows.index_select(0, torch.nonzero(go_r).flatten()) if n_mr else rows[:0]
+        mig_l, mig_r = rows.index_select(0, idx_gl), rows.index_select(0, idx_gr)
         to_l = torch.cat([mig_l, rows.index_select(0, idx_nl)], 0)
         to_r = torch.cat([mig_r, rows.index_select(0, idx_nr)], 0)
         in_l, in_r, hl, hr = self._exchange_var(to_l, to_r, (n_ml,), (n_mr,))
         a_l, a_r = int(hl[0]), int(hr[0])                                        # rows that became mine
-        owned = rows if not (n_ml or n_mr) else rows[stay]
-        n_stay = owned.shape[0]
-        if a_l or a_r:
-            owned = torch.cat([owned, in_l[:a_l], in_r[:a_r]], 0)
-        n = owned.shape[0]
-        ar = lambda a, b: torch.arange(a, b, dtype=torch.int64, device=self.device)   # noqa: E731
-        self.send_l = torch.cat([new_index[idx_nl], ar(n_stay, n_stay + a_l)]).to(i32)
-        self.send_r = torch.cat([new_index[idx_nr], ar(n_stay + a_l, n)]).to(i32)
+        # ownership changes IN PLACE: the rows that arrived fill the slots of the rows that left; what is left over is
+        # appended, or the tail is folded into the remaining holes -- O(rows that moved), never a copy of the whole slab
+        arrivals = torch.cat([in_l[:a_l], in_r[:a_r]], 0) if (a_l or a_r) else rows[:0]
+        rows, pos_arr, idx_nl, idx_nr = self._swap_rows(rows, torch.cat([idx_gl, idx_gr]), arrivals, idx_nl, idx_nr)
+        n = rows.shape[0]
+        i32 = torch.int32
+        self.send_l = torch.cat([idx_nl, pos_arr[:a_l]]).to(i32)
+        self.send_r = torch.cat([idx_nr, pos_arr[a_l:]]).to(i32)
         gl = torch.cat([in_l[a_l:], mig_l], 0)
         gr = torch.cat([in_r[a_r:], mig_r], 0)
         self.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=self.device)
         self.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=self.device)
         self.send_all = torch.cat([self.send_l, self.send_r])
         self.ghost_all = torch.cat([self.ghost_l, self.ghost_r])
-        self.rows = owned
+        self.rows = rows
         self.n_owned = n
         if hasattr(self.B, "load_state_split"):
-            self.B.load_state_split(owned, (gl, gr))
+            self.B.load_state_split(rows, (gl, gr))
         else:
-            self.B.load_state(n, torch.cat([owned, gl, gr], 0))
+            self.B.load_state(n, torch.cat([rows, gl, gr], 0))
+
+    def _swap_rows(self, rows, holes, arrivals, *index_lists):
+        """rows (n, W) loses the rows `holes` (k indices) and gains `arrivals` (a rows), in place where it can.
+        Returns (rows', positions of the arrivals in rows', the index lists translated to rows').  a >= k: the first k
+        arrivals take the holes, the rest is appended (into the slack behind a store_state() view, else one concatenation).
+        a < k: the arrivals take the first a holes; the table shrinks by L = k - a, and the rows of its last L slots that
+        stay are folded into the remaining holes below the new end.  No host wait: every size is known on the host."""
+        n, k, a = rows.shape[0], int(holes.shape[0]), int(arrivals.shape[0])
+        dev = rows.device
+        if k == 0 and a == 0:
+            return (rows, holes[:0]) + index_lists
+        if a >= k:
+            if k:
+                rows.index_copy_(0, holes, arrivals[:k])
+            extra = a - k
+            if extra:
+                base = rows._base
+                if (base is not None and base.dim() == 2 and base.shape[1] == rows.shape[1] and base.is_contiguous() and rows.is_contiguous()
+                        and base.data_ptr() == rows.data_ptr() and base.shape[0] >= n + extra):
+                    rows = base[:n + extra]
+                    rows[n:] = arrivals[k:]
+                else:
+                    rows = torch.cat([rows, arrivals[k:]], 0)
+            pos = torch.cat([holes, torch.arange(n, n + extra, dtype=torch.int64, device=dev)])
+            return (rows, pos) + index_lists
+        if a:
+            rows.index_copy_(0, holes[:a], arrivals)
+        rest, L = holes[a:], k - a                  # L holes stay open: the table shrinks to n - L rows
+        n_new = n - L
+        in_tail = rest >= n_new
+        # tail slot j (row n_new + j) stays unless it is a hole itself
+        hole_tail = torch.zeros(L + 1, dtype=torch.bool, device=dev)
+        hole_tail[torch.where(in_tail, rest - n_new, L)] = True          # slot L: dummy for the holes below the new end
+        keep = ~hole_tail[:L]
+        # the r-th staying tail row goes to the r-th hole below the new end (there are equally many of both)
+        below = ~in_tail
+        target = torch.full((L + 1,), n, dtype=torch.int64, device=dev)   # n: a row index nobody reads afterwards
+        target[torch.where(below, torch.cumsum(below, 0) - 1, L)] = rest
+        dest = torch.where(keep, target[:L][(torch.cumsum(keep, 0) - 1).clamp_(min=0)], n_new + torch.arange(L, device=dev))
+        # (a tail row that is a hole "moves" onto itself: beyond the new end, dropped with it)
+        rows.index_copy_(0, dest, rows[n_new:].clone())
+        out = []
+        for lst in (holes[:a],) + index_lists:       # an arrival that took a hole in the tail was folded like any other row
+            moved = lst >= n_new
+            out.append(torch.where(moved, dest[(lst - n_new).clamp_(min=0)], lst))
+        return (rows[:n_new],) + tuple(out)
 
     def rebalance(self, force=False):
         """between steps only (never from inside _step: the backend, and everything queued on it, is replaced)"""
