@@ -361,3 +361,23 @@ def test_speculative_step_falls_back_when_a_solver_goes_on(n, steps, squeeze):
     a = np.array(seen)
     assert a[:, 0].max() >= 2 and a[:, 1].max() >= 2 and a[:, 2].max() >= 3, seen   # every fallback was taken
     pd.close(); o.close()
+
+
+def test_neighbor_count_follows_moving_particles_update_after_update():
+    """Faithful mode, one context: the bucket histogram / neighborCount kernels of a grid update run on a side stream beside
+    the sort and the list build and are joined at its end (wcsph_grid_update).  Twelve updates in a row on moving
+    particles, each read back at once: neighborCount and gridCount equal the oracle's every time (a missing join, or a
+    histogram / region flag left over from the previous update, shows up here)."""
+    g, o = make_pair(8, "faithful", jitter=0.4)
+    rng = np.random.default_rng(11)
+    pos = g.pd.pos.to_numpy().copy()
+    nl = g.pd.liquid_count
+    for k in range(12):
+        pos[:nl] += (rng.standard_normal((nl, 3)) * 0.012).astype(np.float32)
+        set_state(g, o, pos=pos)
+        g.pd.hash_grid.update_grid()
+        o.update_grid()
+        np.testing.assert_array_equal(g.pd.hash_grid.neighborCount.to_numpy(), o.neighborCount, err_msg="update %d" % k)
+        if k % 4 == 3:
+            np.testing.assert_array_equal(g.pd.hash_grid.gridCount, o.gridCount)
+    g.close()

@@ -85,6 +85,16 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
     bbox[6 * blockIdx.x + 3 + a] = h;
   }
 }
+// the reference bucket histogram on its own (wcsph_grid_update of one faithful context: beside the sort, on the side stream):
+// rows [0, n) = the owned liquid rows, cells from k_cell_assign's packed words, the same ownership rule
+__global__ void __launch_bounds__(BLOCK) k_bucket_hist(Dev d, const int *pw, int n, int *bcount) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int w = pw[i];
+  if (w < 0) return;
+  const int gx = (w & 1023) + d.x0;
+  if (gx >= d.own_lo && gx < d.own_hi) atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+}
 // one block: reduce the per-block boxes of k_cell_assign into out[6] = {xmin,ymin,zmin,xmax,ymax,zmax} (max < 0: empty)
 __global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};

@@ -29,6 +29,10 @@ struct wcsph_ctx {
   wcsph_params p;
   Dev d;          // DFSPH view (CubicKernel with h = HashGrid.searchR)
   hipStream_t stream = nullptr, own_stream = nullptr;
+  // faithful mode, one context: the reference bucket histogram and neighborCount (k_bucket_hist .. k_ncount_box) run on a
+  // side stream beside the counting sort and the list build, which need neither (wcsph_grid_update)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_assign = nullptr, ev_scan = nullptr, ev_side = nullptr;
   std::string err;
   bool is_setup = false, grid_valid = false;
   // double buffers of the persistent fields (the *_b set is the scatter target)
@@ -254,6 +258,10 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
     return ctx->fail(WCSPH_EARG, "tension_fixed=0 (the literal loop of dfsph.py:264-305) runs over the reference's raw bucket lists: faithful neighbour mode only");
   HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
+  HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_assign, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_scan, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
   Dev &d = ctx->d;
   memset(&d, 0, sizeof d);
   d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
@@ -319,11 +327,14 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
 int wcsph_destroy(wcsph_ctx *ctx) {
   if (!ctx) return WCSPH_EARG;
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
+  if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+  for (hipEvent_t e : {ctx->ev_assign, ctx->ev_scan, ctx->ev_side}) if (e) hipEventDestroy(e);
   delete ctx;
   return WCSPH_OK;
 }
@@ -457,7 +468,16 @@ int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]) {
 
 // ---- HashGrid.update_grid -------------------------------------------------------------------
 // first half: cells, counting sort, this context's share of the reference bucket histogram (owned liquid particles)
-static int grid_begin(wcsph_ctx *ctx) {
+// fork (wcsph_grid_update of ONE faithful context): the bucket histogram is not taken inside k_cell_assign -- its 2 M random
+// device-scope atomics are 71 of that kernel's 88 us at C3 -- but by k_bucket_hist on the side stream, followed there by the
+// bucket sums, gridCount[hash(cell)] and (once the scan is done) the neighborCount box sums, while this stream scans,
+// sorts and builds the lists: none of those reads the histogram or neighborCount.  grid_end() joins.  What this buys is
+// the holes of the one-block kernels (k_bbox_final, k_scan_bsums: ~21 us of an otherwise idle GPU per step), 1-1.5 % of the
+// step at C3 -- full-chip kernels of two streams time-slice, they do not add up (forking behind the sort, beside the list
+// build, gains nothing: profiles/r03_experiments.md (21)).  On a slab decomposition the histogram is all-reduced between
+// the two halves and stays where it was.
+static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box);
+static int grid_begin(wcsph_ctx *ctx, bool fork = false) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
@@ -473,11 +493,26 @@ static int grid_begin(wcsph_ctx *ctx) {
   ctx->hist_dirty = true;
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
-                       d.faithful ? ctx->bcount_l : (int *)nullptr, ctx->bbox_part, d.n_owned,
+                       d.faithful && !fork ? ctx->bcount_l : (int *)nullptr, ctx->bbox_part, d.n_owned,
                        d.faithful ? ctx->region_occ : (int *)nullptr);
+  if (fork) {
+    hipStream_t s2 = ctx->side_stream;
+    HIPCHK(hipEventRecord(ctx->ev_assign, s));
+    HIPCHK(hipStreamWaitEvent(s2, ctx->ev_assign, 0));
+    const int nh = d.nl < d.n_owned ? d.nl : d.n_owned;
+    if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
+    neighbor_count_launches(ctx, s2, false);
+  }
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
+  if (fork) {   // the box sums read the cell table and the occupied box
+    HIPCHK(hipEventRecord(ctx->ev_scan, s));
+    HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_scan, 0));
+    neighbor_count_launches(ctx, ctx->side_stream, true);
+    HIPCHK(hipEventRecord(ctx->ev_side, ctx->side_stream));
+  }
+
   if (d.nl > 0) {
     SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.pressure, d.oid,
                      ctx->pos_b, ctx->vel_b, ctx->vel_guess_b, ctx->omega_b, ctx->kappa_b, ctx->kappa_v_b, ctx->pressure_b, ctx->oid_b, d.where};
@@ -491,24 +526,33 @@ static int grid_begin(wcsph_ctx *ctx) {
   return 0;
 }
 // second half: raw neighbour-list length (HashGrid.neighborCount) from the GLOBAL bucket occupancy, compact lists
-static int grid_end(wcsph_ctx *ctx) {
+// faithful mode: box = false: bucket sums and gridCount[hash(cell)] of the occupied regions; box = true: neighborCount, the
+// 5x5x5 box sum of gridCount[hash(cell)] around every occupied cell, one LDS-tiled launch (grid.h)
+static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box) {
   Dev &d = ctx->d;
-  hipStream_t s = ctx->stream;
-  if (d.faithful) {
+  const int nb = ctx->n_regions;
+  if (!box) {
     hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
-    // neighborCount: 5x5x5 box sum of gridCount[hash(cell)] around every occupied cell, one LDS-tiled launch (grid.h)
     if (d.nl > 0) {
-      const int nb = ctx->n_regions;
       if (d.max_in_grid <= 255)
         hipLaunchKernelGGL(k_cellval_occ<unsigned char>, dim3(nb), dim3(BLOCK), 0, s, d, (const unsigned char *)ctx->bcount8, (const int *)ctx->region_occ, ctx->cellval);
       else
         hipLaunchKernelGGL(k_cellval_occ<int>, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount, (const int *)ctx->region_occ, ctx->cellval);
-      hipLaunchKernelGGL(k_ncount_box, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
     }
+  } else if (d.nl > 0) {
+    hipLaunchKernelGGL(k_ncount_box, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
+  }
+}
+static int grid_end(wcsph_ctx *ctx, bool fork = false) {
+  Dev &d = ctx->d;
+  hipStream_t s = ctx->stream;
+  if (d.faithful) {
+    if (!fork) { neighbor_count_launches(ctx, s, false); neighbor_count_launches(ctx, s, true); }
   } else if (d.nl > 0) {
     hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
   }
   if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
+  if (fork) HIPCHK(hipStreamWaitEvent(s, ctx->ev_side, 0));   // join: whatever follows may read neighborCount and the flags
   ctx->d.rev ^= 1;
   LAUNCHCHK();
   ctx->hist_dirty = false;   // k_bucket_sum / k_ncount_box have left the histogram and the region flags zeroed
@@ -518,9 +562,13 @@ static int grid_end(wcsph_ctx *ctx) {
 }
 int wcsph_grid_update(wcsph_ctx *ctx) {
   NEED_SETUP();
-  int rc = grid_begin(ctx);
+#ifndef WCSPH_GRID_FORK
+#define WCSPH_GRID_FORK 1   /* -DWCSPH_GRID_FORK=0: everything on the context's stream (the A/B build) */
+#endif
+  const bool fork = WCSPH_GRID_FORK && ctx->d.faithful && ctx->d.nl > 0;
+  int rc = grid_begin(ctx, fork);
   if (rc) return rc;
-  return grid_end(ctx);
+  return grid_end(ctx, fork);
 }
 // slab decomposition, faithful neighbour mode: the drivers all-reduce the liquid bucket histogram between the halves
 int wcsph_grid_update_begin(wcsph_ctx *ctx) { NEED_SETUP(); ctx->grid_valid = false; return grid_begin(ctx); }
