@@ -366,6 +366,10 @@ int wcsph_set_part(wcsph_ctx *ctx, int32_t mode, int32_t x_lo, int32_t x_hi);
  *                        wcsph_set_acc_buffer() (kernels launched next read the global total)
  *   allreduce_max(user, &v): MAX over ranks of a host double (the CFL velocity maximum, dfsph.py:113-114)
  *   allreduce_words(user, d_words, n): SUM over ranks of n int32 words on the device (the packed bucket histogram)
+ *   allreduce_max_bits(user, d_word): MAX over ranks of ONE int32 word on the device, in place -- the bit pattern of the
+ *                        non-negative f32 CFL velocity maximum (bit patterns of non-negative floats order like the floats), so
+ *                        the global maximum costs no host round trip of its own: the host reads it with the wait it needs
+ *                        anyway.  May be NULL: the library then reads the local maximum and calls allreduce_max on the host
  * world <= 1 or cb == NULL: no callback is made (one slab = the whole domain). */
 typedef struct wcsph_slab_callbacks {
   void *user;
@@ -376,6 +380,7 @@ typedef struct wcsph_slab_callbacks {
   int (*allreduce_acc)(void *user, int32_t slot);
   int (*allreduce_max)(void *user, double *v);
   int (*allreduce_words)(void *user, void *d_words, int64_t n);
+  int (*allreduce_max_bits)(void *user, void *d_word);
 } wcsph_slab_callbacks;
 /* the rows this rank sends (original indices of OWNED rows, left neighbour's first) and the ghost rows it receives into,
  * both device int32 arrays that stay valid until the next call; after every wcsph_load_state*() */

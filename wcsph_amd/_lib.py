@@ -84,11 +84,13 @@ CB_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p)
 CB_ACC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)
 CB_MAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
 CB_WORDS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+CB_MAXBITS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
 class SlabCallbacks(C.Structure):
     _fields_ = [("user", C.c_void_p), ("world", C.c_int32), ("halo_buffers", CB_BUFFERS), ("halo_post", CB_POST),
-                ("halo_wait", CB_WAIT), ("allreduce_acc", CB_ACC), ("allreduce_max", CB_MAX), ("allreduce_words", CB_WORDS)]
+                ("halo_wait", CB_WAIT), ("allreduce_acc", CB_ACC), ("allreduce_max", CB_MAX), ("allreduce_words", CB_WORDS),
+                ("allreduce_max_bits", CB_MAXBITS)]
 
 
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",

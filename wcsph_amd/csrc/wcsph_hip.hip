@@ -2168,10 +2168,30 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   if (cfl_here) { ELEM(k_finish_nonpressure, dt); ctx->cfl_done = true; }
   else { ELEM(k_visc_end, dt); ELEM(k_vorticity_integrate, dt); }
   // ---- optimize_time_step() (dfsph.py:107-129) on the GLOBAL velocity maximum
-  SRC(wcsph_dfsph_cfl_reduce(ctx));
-  R.n_wait++;
-  double vmax = (double)ctx->vel_max0;
-  if (R.multi && (rc = cb->allreduce_max(cb->user, &vmax))) return ctx->fail(rc, "slab callback allreduce_max failed");
+  double vmax;
+  if (R.multi && cb->allreduce_max_bits) {
+    // the maximum over the ranks is formed on the device (a MAX all-reduce of the bit pattern, queued behind k_cfl_store) and
+    // read with the one wait this decision needs anyway.  Every rank makes the call, also one whose reference launches nothing
+    // (dfsph.py:108-111 with a single liquid particle: vel_max[0] keeps its 0)
+    if (d.faithful && d.nl <= 1) HIPCHK(hipMemsetAsync(d.flags + FLAG_VMAX, 0, sizeof(int), ctx->stream));
+    else {
+      if (ctx->cfl_done) ctx->cfl_done = false;   // k_finish_nonpressure already took the per-particle maxima
+      else ELEM(k_cfl, ctx->dt);
+      hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d, DtRule{nullptr, 0.f, 0, 0.0, 0.0, 0.0, 0.0});
+      LAUNCHCHK();
+    }
+    if ((rc = cb->allreduce_max_bits(cb->user, d.flags + FLAG_VMAX))) return ctx->fail(rc, "slab callback allreduce_max_bits failed");
+    SRC(pull_scalars(ctx));
+    const int bits = ctx->h_flags[FLAG_VMAX];
+    memcpy(&ctx->vel_max0, &bits, 4);
+    R.n_wait++;
+    vmax = (double)ctx->vel_max0;
+  } else {
+    SRC(wcsph_dfsph_cfl_reduce(ctx));
+    R.n_wait++;
+    vmax = (double)ctx->vel_max0;
+    if (R.multi && (rc = cb->allreduce_max(cb->user, &vmax))) return ctx->fail(rc, "slab callback allreduce_max failed");
+  }
   if ((double)(float)vmax > (double)ctx->p.eps) {
     double time_step = 0.5 * 0.4 * ctx->p.cfl_radius * 2.0 / sqrt((double)(float)vmax);
     if (time_step > ctx->p.user_max_t) time_step = ctx->p.user_max_t;

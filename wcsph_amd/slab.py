@@ -563,11 +563,15 @@ class SlabSim:
         def words(_u, ptr, n):
             self._allreduce_tensor(torch.as_tensor(_DevArray(ptr, n), device=self.device))
 
+        def maxbits(_u, ptr):     # the CFL maximum as an int32 bit pattern on the device: no host value, no extra wait
+            self._allreduce_tensor(torch.as_tensor(_DevArray(ptr, 1), device=self.device), dist.ReduceOp.MAX)
+
         cb = _lib.SlabCallbacks()
         cb.user, cb.world = None, int(self.world)
         self._cb_keep = [_lib.CB_BUFFERS(guard(buffers)), _lib.CB_POST(guard(post)), _lib.CB_WAIT(guard(wait)),
-                         _lib.CB_ACC(guard(acc)), _lib.CB_MAX(guard(vmax)), _lib.CB_WORDS(guard(words))]
-        cb.halo_buffers, cb.halo_post, cb.halo_wait, cb.allreduce_acc, cb.allreduce_max, cb.allreduce_words = self._cb_keep
+                         _lib.CB_ACC(guard(acc)), _lib.CB_MAX(guard(vmax)), _lib.CB_WORDS(guard(words)), _lib.CB_MAXBITS(guard(maxbits))]
+        (cb.halo_buffers, cb.halo_post, cb.halo_wait, cb.allreduce_acc, cb.allreduce_max, cb.allreduce_words,
+         cb.allreduce_max_bits) = self._cb_keep
         return cb
 
     def allsum(self, v): return self._allreduce(v, dist.ReduceOp.SUM)   # noqa: E704
