@@ -24,7 +24,11 @@ import subprocess
 import sys
 import time
 
-import numpy as np
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL and device-tensor sharing fail with hipIpcGetMemHandle: invalid
+# argument otherwise); the driver's environment exports it already -- keep it for every other launcher, before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

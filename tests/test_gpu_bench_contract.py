@@ -54,3 +54,22 @@ def test_two_rank_bench_line_over_gloo():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0     # measured once, on rank 0's host
     # 4 decision points inside the step (divergence, viscosity, CFL, pressure) + 2 in the migration / ghost rebuild (counts)
     assert d["config"]["host_waits_per_step"] <= 6.5 and d["config"]["step_driver"].startswith("wcsph_slab_step")
+
+
+def test_two_rank_bench_survives_an_rccl_that_refuses():
+    """The default launch (RCCL data plane) with both ranks on the ONE GPU of the test box: RCCL refuses that at group creation
+    ("Duplicate GPU detected") on every rank -- a real RCCL failure, not a simulated one.  The ranks agree over the gloo
+    control plane, the same HIP computation runs with the halos staged through the host, and rank 0 still prints ONE JSON
+    line that says which transport carried the halos."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", WCSPH_BENCH_LOCAL_GPU="0")
+    env.pop("WCSPH_BENCH_COMM", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "24",
+                        "--cpu-n", "8"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and sum(d["config"]["owned_per_rank"]) == d["config"]["n_liquid"]
+    assert d["config"]["comm"].startswith("gloo fallback") and "RCCL probe failed" in r.stderr

@@ -19,6 +19,7 @@ checker backend; the product backend is HipBackend (libwcsph_hip.so through the 
 import ctypes as C
 import math
 import os
+import sys
 import time
 
 import numpy as np
@@ -884,6 +885,29 @@ def dam_break_slab(n, rank, world, particleRadius=scene.PARTICLE_RADIUS, cuts=No
     return liquid, solid, (minb, maxb), cuts, n ** 3, gid
 
 
+def _rccl_probe(rank, world, dev, group):
+    """the kinds of calls a slab step makes over RCCL, once, small: raises what RCCL / torch raise"""
+    t = torch.full((64,), float(rank + 1), dtype=torch.float64, device=dev)
+    dist.all_reduce(t, group=group)
+    w = torch.tensor([rank], dtype=torch.int32, device=dev)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
+    ops, keep = [], []
+    for peer in (rank - 1, rank + 1):
+        if 0 <= peer < world:
+            a = torch.full((128, STATE_W), float(rank), dtype=torch.float32, device=dev)
+            b = torch.empty((128, STATE_W), dtype=torch.float32, device=dev)
+            keep.append((peer, a, b))
+            ops += [dist.P2POp(dist.isend, a, peer, group=group), dist.P2POp(dist.irecv, b, peer, group=group)]
+    for req in (dist.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+    torch.cuda.synchronize(dev)
+    if float(t[0].item()) != world * (world + 1) / 2.0 or int(w.item()) != world - 1:
+        raise RuntimeError("all_reduce returned %r / %r" % (float(t[0].item()), int(w.item())))
+    for peer, _a, b in keep:
+        if float(b[0, 0].item()) != float(peer) or float(b[-1, -1].item()) != float(peer):
+            raise RuntimeError("send/recv with rank %d returned wrong data" % peer)
+
+
 def bench_main(args):
     """bench.py --gpus N (N > 1): weak scaling, ~2 M liquid particles per GPU (config C4 at N = 8).  Rank 0 returns the
     JSON object (bench.py adds the cpu_baseline leg, measured once on rank 0's host after the ranks have left)."""
@@ -897,12 +921,39 @@ def bench_main(args):
     comm = os.environ.get("WCSPH_BENCH_COMM", "nccl")
     if comm == "gloo":
         local = 0
+    local = int(os.environ.get("WCSPH_BENCH_LOCAL_GPU", local))     # tests: every rank on the one GPU of the box
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if comm == "gloo":
-        dist.init_process_group("gloo")
-    else:
-        dist.init_process_group("nccl", device_id=dev)
+    # Control plane: a gloo group over the same ranks, always there -- barriers, the timing maximum and the agreement below
+    # travel over it as host tensors; it is never on the data path of an RCCL run.
+    dist.init_process_group("gloo")
+    grp = None
+    one_gpu = comm == "gloo"
+    if not one_gpu:
+        # Data plane: RCCL (backend "nccl"), one GPU per rank.  RCCL has never run with more than one rank on the development
+        # pool (single-GPU boxes; two ranks on one GPU are refused: tools/rccl_probe.py): before the run every rank creates
+        # the group and tries the kinds of calls a step makes -- all_reduce (f64 SUM, i32 MAX), a grouped isend / irecv with
+        # its slab neighbours -- and the ranks agree over gloo whether all of them came through.  If not, the SAME HIP
+        # computation runs with the halo buffers staged through the host over gloo (slower, still one GPU per rank, and
+        # the JSON line says so) instead of the job dying without a number.  A rank that HANGS inside RCCL is not
+        # recoverable here: the watchdog above ends the job.
+        ok, why, ng = 1, "", None
+        try:
+            if os.environ.get("WCSPH_BENCH_FAIL_RCCL_PROBE"):          # test hook: the fall-back path on a healthy box
+                raise RuntimeError("WCSPH_BENCH_FAIL_RCCL_PROBE is set")
+            ng = dist.new_group(backend="nccl", device_id=dev)
+            _rccl_probe(rank, world, dev, ng)
+        except Exception as e:      # noqa: BLE001 -- whatever RCCL / torch raise here, the decision must be collective
+            ok, why = 0, "%s: %s" % (type(e).__name__, str(e).strip().splitlines()[0][:200] if str(e).strip() else "")
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            grp = ng
+        else:
+            if why:
+                print("[bench rank %d] RCCL probe failed (%s): halos staged through the host over gloo" % (rank, why), file=sys.stderr, flush=True)
+            comm = "gloo fallback (the RCCL probe failed on at least one rank): one GPU per rank, halo buffers staged through the host"
+    staged = comm != "nccl"
     import __graft_entry__ as g
     if rank == 0:
         g.build()
@@ -912,9 +963,8 @@ def bench_main(args):
     n = int(round(n_base * world ** (1.0 / 3.0)))
     liquid, solid, bounds, cuts, n_global, gid = dam_break_slab(n, rank, world)
     sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, cuts, n_global, rank, world, device=dev,
-                  comm_device=torch.device("cpu") if comm == "gloo" else dev, neighbor_mode=args.mode, gid_local=gid,
+                  comm_device=torch.device("cpu") if staged else dev, neighbor_mode=args.mode, gid_local=gid, group=grp,
                   rebalance_every=int(os.environ.get("WCSPH_REBALANCE_EVERY", "200")))
-    cdev = sim.comm_device
     iters = []
     for _ in range(args.warmup):
         sim.step()
@@ -929,7 +979,7 @@ def bench_main(args):
         sim.step()
         iters.append((sim.vs_iter, sim.dv_iter, sim.pr_iter))
     dist.barrier(); torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)       # control plane: host tensors over gloo
     insitu_ms, insitu_n = None, 0
     if prof:
         ms_, n_ = C.c_float(), C.c_int32()
@@ -937,7 +987,7 @@ def bench_main(args):
             _lib.check(sim.B.ctx, sim.B.lib.wcsph_profile_end(sim.B.ctx, C.byref(ms_), C.byref(n_)))
         insitu_ms, insitu_n = ms_.value, n_.value
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    cnt = torch.tensor([sim.n_owned], dtype=torch.int64, device=cdev)
+    cnt = torch.tensor([sim.n_owned], dtype=torch.int64)
     allc = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(allc, cnt)
     result = None
@@ -959,7 +1009,7 @@ def bench_main(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DFSPH 3D dam-break %d^3 = %d liquid particles over %d x-slabs (C3 load per GPU; C4 at 8 "
-                                   "GPUs), ghost halos over RCCL send/recv, viscosity PCG + vorticity on" % (n, n_global, world),
+                                   "GPUs), ghost halos over %s, viscosity PCG + vorticity on" % (n, n_global, world, "RCCL send/recv" if not staged else "gloo (host-staged)"),
                        "neighbor_mode": args.mode, "n_liquid": n_global, "cuts": sim.cuts, "comm": comm,
                        "step_driver": "wcsph_slab_step (library, communicator behind callbacks)" if sim.native else "python phase driver",
                        "host_waits_per_step": round(sim.n_host_waits / float(args.steps + args.warmup), 1),
