@@ -91,3 +91,15 @@ def test_pci_coff_is_the_reference_lattice_sum():
     ax = np.array([-0.1, -0.05, 0.0, 0.05, 0.1])
     g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
     assert int((np.sqrt((g * g).sum(1)) < 0.1 - 1e-12).sum()) == 27
+
+
+def test_max_of_bit_patterns_is_the_max_of_non_negative_floats():
+    """wcsph_slab_callbacks.allreduce_max_bits all-reduces the CFL velocity maximum as an int32 bit pattern (MAX): for
+    non-negative IEEE-754 floats, including 0, denormals and +inf, the integer order of the bit patterns is the float order"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    v = np.concatenate([rng.uniform(0, 1e-3, 50), rng.uniform(0, 1e4, 50), [0.0, 0.1, 1e-45, 3.4e38, np.inf]]).astype(np.float32)
+    for _ in range(200):
+        pick = rng.choice(v, size=8)
+        bits = pick.view(np.int32)
+        assert np.array([bits.max()], np.int32).view(np.float32)[0] == pick.max()
