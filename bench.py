@@ -137,6 +137,10 @@ def _cpu_child(n, steps, sweep, single):
 
 def _run_cpu_child(n, steps, sweep, single, timeout):
     env = dict(os.environ, WCSPH_ORACLE_BASELINE="1")
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers when the caller set none: the baseline child runs after
+    # the ranks have left, alone on the host, and sweeps the thread counts itself
+    if "TORCHELASTIC_RUN_ID" in env or int(env.get("WORLD_SIZE", "1")) > 1:
+        env.pop("OMP_NUM_THREADS", None)
     code = "import bench; bench._cpu_child(%d, %d, %r, %r)" % (n, steps, list(sweep), bool(single))
     try:
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)

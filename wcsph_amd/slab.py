@@ -225,7 +225,7 @@ class HipBackend:
         if sim._cb_exc is not None:
             raise sim._cb_exc
         self._chk(rc)
-        sim.n_exchanges += stats[0]; sim.n_host_waits += stats[1]
+        sim.n_host_waits += stats[1]       # (the exchanges of the step are counted where they are posted: SlabSim._post)
         dt, err = C.c_float(), C.c_float()
         vs, dv, pr = C.c_int32(), C.c_int32(), C.c_int32()
         self._chk(lib.wcsph_get_scalar(ctx, _lib.SCALAR_ID["deltaT"], C.byref(dt)))
