@@ -95,6 +95,72 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist(Dev d, const int *pw, int
   const int gx = (w & 1023) + d.x0;
   if (gx >= d.own_lo && gx < d.own_hi) atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
 }
+// ---- the same histogram without one memory-side atomic per particle (profiles/r03w_pmc_bucket_hist.txt: every one of the
+// 2 M atomics of k_bucket_hist misses the XCD's L2; 79 us at C3) ------------------------------------------------------------
+// k_hash_bin: a workgroup takes HB_ROWS rows per thread, forms their bucket ids, counts them per RANGE of 2^HB_SHIFT buckets in
+// LDS, reserves its share of every range's list with ONE device atomic per range and writes the bucket ids there.
+// k_bin_hist: one workgroup per range counts its list in an LDS table of 2^HB_SHIFT ints and writes this step's liquid
+// histogram of the range, zeros included, coalesced.  A list that does not fit its buffer raises bins[HB_FLAG]: k_bin_hist
+// then writes nothing and the gated k_bucket_hist takes the histogram with atomics (the flag is cleared before every k_hash_bin).
+#define HB_SHIFT 15
+#define HB_MAXBINS 256
+#define HB_FLAG HB_MAXBINS
+#define HB_ROWS 16
+__global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n, int nbins, int cap, int *bins, int *binbuf) {
+  __shared__ int cnt[HB_MAXBINS], base[HB_MAXBINS];
+  for (int b = threadIdx.x; b < nbins; b += BLOCK) cnt[b] = 0;
+  __syncthreads();
+  const int first = blockIdx.x * (BLOCK * HB_ROWS) + threadIdx.x;
+  int h[HB_ROWS], at[HB_ROWS];
+#pragma unroll
+  for (int r = 0; r < HB_ROWS; r++) {
+    const int i = first + r * BLOCK;
+    h[r] = -1; at[r] = 0;
+    if (i < n) {
+      const int w = pw[i];
+      if (w >= 0) {
+        const int gx = (w & 1023) + d.x0;
+        if (gx >= d.own_lo && gx < d.own_hi) h[r] = ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size);
+      }
+    }
+    if (h[r] >= 0) at[r] = atomicAdd(&cnt[h[r] >> HB_SHIFT], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins; b += BLOCK) base[b] = cnt[b] ? atomicAdd(&bins[b], cnt[b]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < HB_ROWS; r++) {
+    if (h[r] < 0) continue;
+    const int b = h[r] >> HB_SHIFT, o = base[b] + at[r];
+    if (o < cap) binbuf[(size_t)b * cap + o] = h[r];
+    else bins[HB_FLAG] = 1;
+  }
+}
+__global__ void __launch_bounds__(1024) k_bin_hist(Dev d, int cap, int *bins, const int *binbuf, int *bl) {
+  __shared__ int tab[1 << HB_SHIFT];
+  if (bins[HB_FLAG]) return;                       // grid-uniform: an overflowing list -> the atomics path
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < (1 << HB_SHIFT); k += 1024) tab[k] = 0;
+  __syncthreads();
+  const int n = bins[b];
+  const int *src = binbuf + (size_t)b * cap;
+  for (int k = threadIdx.x; k < n; k += 1024) atomicAdd(&tab[src[k] & ((1 << HB_SHIFT) - 1)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) bins[b] = 0;               // consumed: the next update starts from empty lists
+  const int b0 = b << HB_SHIFT;
+  for (int k = threadIdx.x; k < (1 << HB_SHIFT) && b0 + k < d.table_size; k += 1024) bl[b0 + k] = tab[k];
+}
+// the atomics path, only when a range list overflowed (also leaves the lists empty for the next update)
+__global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *pw, int n, int *bcount, int nbins, int *bins) {
+  if (!bins[HB_FLAG]) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nbins) bins[i] = 0;
+  if (i >= n) return;
+  const int w = pw[i];
+  if (w < 0) return;
+  const int gx = (w & 1023) + d.x0;
+  if (gx >= d.own_lo && gx < d.own_hi) atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+}
 // one block: reduce the per-block boxes of k_cell_assign into out[6] = {xmin,ymin,zmin,xmax,ymax,zmax} (max < 0: empty)
 __global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};

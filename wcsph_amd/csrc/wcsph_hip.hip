@@ -41,6 +41,7 @@ struct wcsph_ctx {
   int *oid_b = nullptr;
   // grid scratch
   int *cnt = nullptr, *pw = nullptr, *slot = nullptr, *bsum = nullptr;
+  int *hb_bins = nullptr, *hb_buf = nullptr; int hb_nbins = 0, hb_cap = 0;   // binned histogram (grid.h k_hash_bin): range counters [+ flag], range lists
   int *bcount = nullptr, *bcount_s = nullptr, *bcount_l = nullptr, *cellval = nullptr;   // gridCount = _s (static solids) + _l (liquid, per step)
   int *bbox_part = nullptr;
   int n_alias = 0, scan_blocks = 0, n_regions = 0;
@@ -394,7 +395,13 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   DALLOC(d.cell_info, d.ncell_p);
   DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1));
   if (d.faithful) {
-    DALLOC(ctx->bcount, d.table_size + 1); DALLOC(ctx->bcount_s, d.table_size + 1); DALLOC(ctx->bcount_l, d.table_size + 1);   // [T] stays 0: the scan's end sentinel
+    DALLOC(ctx->bcount, d.table_size + 1); DALLOC(ctx->bcount_s, d.table_size + 1); DALLOC(ctx->bcount_l, d.table_size + 1);
+    ctx->hb_nbins = (d.table_size + (1 << HB_SHIFT) - 1) >> HB_SHIFT;
+    if (ctx->hb_nbins <= HB_MAXBINS) {   // (larger tables keep the atomics)
+      // a range holds table_size / nbins buckets of a pseudo-random hash: twice its share of the rows + a margin
+      ctx->hb_cap = (int)(2 * ((size_t)ctx->capacity / ctx->hb_nbins + 1) + 8192);
+      DALLOC(ctx->hb_bins, HB_MAXBINS + 1); DALLOC(ctx->hb_buf, (size_t)ctx->hb_nbins * ctx->hb_cap);
+    }   // [T] stays 0: the scan's end sentinel
     DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->bcount8, d.table_size + 1);
     {
       const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
@@ -489,6 +496,7 @@ static int grid_begin(wcsph_ctx *ctx, bool fork = false) {
   if (d.faithful && ctx->hist_dirty) {
     HIPCHK(hipMemsetAsync(ctx->bcount_l, 0, (size_t)d.table_size * sizeof(int), s));
     HIPCHK(hipMemsetAsync(ctx->region_occ, 0, (size_t)ctx->n_regions * sizeof(int), s));
+    if (ctx->hb_bins) HIPCHK(hipMemsetAsync(ctx->hb_bins, 0, (HB_MAXBINS + 1) * sizeof(int), s));
   }
   ctx->hist_dirty = true;
   if (d.nl > 0)
@@ -500,7 +508,16 @@ static int grid_begin(wcsph_ctx *ctx, bool fork = false) {
     HIPCHK(hipEventRecord(ctx->ev_assign, s));
     HIPCHK(hipStreamWaitEvent(s2, ctx->ev_assign, 0));
     const int nh = d.nl < d.n_owned ? d.nl : d.n_owned;
-    if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
+#ifndef WCSPH_BINNED_HIST
+#define WCSPH_BINNED_HIST 1   /* -DWCSPH_BINNED_HIST=0: one device atomic per particle (the A/B build) */
+#endif
+    if (nh > 0 && WCSPH_BINNED_HIST && ctx->hb_bins) {
+      HIPCHK(hipMemsetAsync(ctx->hb_bins + HB_FLAG, 0, sizeof(int), s2));
+      hipLaunchKernelGGL(k_hash_bin, dim3((nh + BLOCK * HB_ROWS - 1) / (BLOCK * HB_ROWS)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh,
+                         ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf);
+      hipLaunchKernelGGL(k_bin_hist, dim3(ctx->hb_nbins), dim3(1024), 0, s2, d, ctx->hb_cap, ctx->hb_bins, (const int *)ctx->hb_buf, ctx->bcount_l);
+      hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins);
+    } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
     neighbor_count_launches(ctx, s2, false);
   }
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
