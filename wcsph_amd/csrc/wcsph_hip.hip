@@ -400,6 +400,9 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
     if (ctx->hb_nbins <= HB_MAXBINS) {   // (larger tables keep the atomics)
       // a range holds table_size / nbins buckets of a pseudo-random hash: twice its share of the rows + a margin
       ctx->hb_cap = (int)(2 * ((size_t)ctx->capacity / ctx->hb_nbins + 1) + 8192);
+#ifdef HB_TEST_CAP   /* test build: lists that overflow at once, i.e. the atomics fall-back on every update */
+      ctx->hb_cap = HB_TEST_CAP;
+#endif
       DALLOC(ctx->hb_bins, HB_MAXBINS + 1); DALLOC(ctx->hb_buf, (size_t)ctx->hb_nbins * ctx->hb_cap);
     }   // [T] stays 0: the scan's end sentinel
     DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->bcount8, d.table_size + 1);
