@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist(Dev d, const int *pw, int
 // histogram of the range, zeros included, coalesced.  A list that does not fit its buffer raises bins[HB_FLAG]: k_bin_hist
 // then writes nothing and the gated k_bucket_hist takes the histogram with atomics (the flag is cleared before every k_hash_bin).
 #define HB_SHIFT 15
-#define HB_MAXBINS 256
+#define HB_MAXBINS 1024   /* tables up to 33.5 M buckets (a 16 M + 4 M particle decomposition has 20 M) */
 #define HB_FLAG HB_MAXBINS
 #define HB_ROWS 16
 __global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n, int nbins, int cap, int *bins, int *binbuf) {

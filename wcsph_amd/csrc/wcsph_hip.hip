@@ -478,6 +478,23 @@ int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]) {
 
 // ---- HashGrid.update_grid -------------------------------------------------------------------
 // first half: cells, counting sort, this context's share of the reference bucket histogram (owned liquid particles)
+// this step's liquid bucket histogram of the owned rows (ref: HashGrid.py:67-76), from the packed cells k_cell_assign left:
+// binned per workgroup and counted in LDS (grid.h k_hash_bin / k_bin_hist), atomics when the table is too large for that
+#ifndef WCSPH_BINNED_HIST
+#define WCSPH_BINNED_HIST 1   /* -DWCSPH_BINNED_HIST=0: one device atomic per particle (the A/B build) */
+#endif
+static int bucket_hist_launches(wcsph_ctx *ctx, hipStream_t s2) {
+  Dev &d = ctx->d;
+  const int nh = d.nl < d.n_owned ? d.nl : d.n_owned;
+  if (nh > 0 && WCSPH_BINNED_HIST && ctx->hb_bins) {
+    HIPCHK(hipMemsetAsync(ctx->hb_bins + HB_FLAG, 0, sizeof(int), s2));
+    hipLaunchKernelGGL(k_hash_bin, dim3((nh + BLOCK * HB_ROWS - 1) / (BLOCK * HB_ROWS)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh,
+                       ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf);
+    hipLaunchKernelGGL(k_bin_hist, dim3(ctx->hb_nbins), dim3(1024), 0, s2, d, ctx->hb_cap, ctx->hb_bins, (const int *)ctx->hb_buf, ctx->bcount_l);
+    hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins);
+  } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
+  return 0;
+}
 // fork (wcsph_grid_update of ONE faithful context): the bucket histogram is not taken inside k_cell_assign -- its 2 M random
 // device-scope atomics are 71 of that kernel's 88 us at C3 -- but by k_bucket_hist on the side stream, followed there by the
 // bucket sums, gridCount[hash(cell)] and (once the scan is done) the neighborCount box sums, while this stream scans,
@@ -504,23 +521,14 @@ static int grid_begin(wcsph_ctx *ctx, bool fork = false) {
   ctx->hist_dirty = true;
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
-                       d.faithful && !fork ? ctx->bcount_l : (int *)nullptr, ctx->bbox_part, d.n_owned,
+                       (int *)nullptr, ctx->bbox_part, d.n_owned,
                        d.faithful ? ctx->region_occ : (int *)nullptr);
+  if (d.faithful && !fork) { int rc_ = bucket_hist_launches(ctx, s); if (rc_) return rc_; }   // slab halves: on this stream, before the all-reduce
   if (fork) {
     hipStream_t s2 = ctx->side_stream;
     HIPCHK(hipEventRecord(ctx->ev_assign, s));
     HIPCHK(hipStreamWaitEvent(s2, ctx->ev_assign, 0));
-    const int nh = d.nl < d.n_owned ? d.nl : d.n_owned;
-#ifndef WCSPH_BINNED_HIST
-#define WCSPH_BINNED_HIST 1   /* -DWCSPH_BINNED_HIST=0: one device atomic per particle (the A/B build) */
-#endif
-    if (nh > 0 && WCSPH_BINNED_HIST && ctx->hb_bins) {
-      HIPCHK(hipMemsetAsync(ctx->hb_bins + HB_FLAG, 0, sizeof(int), s2));
-      hipLaunchKernelGGL(k_hash_bin, dim3((nh + BLOCK * HB_ROWS - 1) / (BLOCK * HB_ROWS)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh,
-                         ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf);
-      hipLaunchKernelGGL(k_bin_hist, dim3(ctx->hb_nbins), dim3(1024), 0, s2, d, ctx->hb_cap, ctx->hb_bins, (const int *)ctx->hb_buf, ctx->bcount_l);
-      hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins);
-    } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
+    { int rc_ = bucket_hist_launches(ctx, s2); if (rc_) return rc_; }
     neighbor_count_launches(ctx, s2, false);
   }
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
