@@ -1,0 +1,415 @@
+// api_slab.h -- slab decomposition: windows, halo pack / unpack, whole-state load / store, and the DFSPH step of one slab in one call (no reference counterpart).
+#pragma once
+extern "C" {
+
+// ---- slab decomposition -----------------------------------------------------------------------------
+int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1) {
+  if (!ctx || x1 <= x0) return WCSPH_EARG;
+  if (ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_set_cell_window() must precede wcsph_setup()");
+  ctx->win_x0 = x0; ctx->win_x1 = x1;
+  return WCSPH_OK;
+}
+int wcsph_set_owned_columns(wcsph_ctx *ctx, int32_t lo, int32_t hi) {
+  if (!ctx || hi <= lo) return WCSPH_EARG;
+  if (ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_set_owned_columns() must precede wcsph_setup()");
+  ctx->d.own_lo = lo; ctx->d.own_hi = hi;
+  return WCSPH_OK;
+}
+int wcsph_set_global_liquid(wcsph_ctx *ctx, int64_t n_liquid_global) {   // Q5: the CFL prefix is defined on GLOBAL particle ids
+  if (!ctx || n_liquid_global < 0) return WCSPH_EARG;
+  ctx->d.cfl_prefix = 0x7fffffff;
+  if (ctx->d.faithful && n_liquid_global > 1) { long s = 1; while (s * 2 < n_liquid_global) s *= 2; ctx->d.cfl_prefix = (int)(s > 0x7fffffffL ? 0x7fffffffL : s); }
+  return WCSPH_OK;
+}
+// halo pack / unpack: several fields of the rows idx[0..n) side by side in one buffer, one launch each way
+static int halo_fields(wcsph_ctx *ctx, int nf, const int32_t *fields, HaloFields *h) {
+  if (nf < 1 || nf > 8 || !fields) return ctx->fail(WCSPH_EARG, "halo: 1..8 fields");
+  h->n = nf; h->W = 0;
+  for (int k = 0; k < nf; k++) {
+    FieldDesc fd = field_desc(ctx, fields[k]);
+    if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "halo: vec3 / scalar fields only");
+    h->ptr[k] = (const float *)fd.ptr; h->width[k] = fd.kind == 3 ? 3 : 1; h->stride[k] = fd.kind == 3 ? 4 : 1;
+    h->W += h->width[k];
+  }
+  return 0;
+}
+int wcsph_slab_classify(wcsph_ctx *ctx, const void *d_rows, int64_t n, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right,
+                        int64_t *d_idx, int32_t cap, int32_t *d_counts) {
+  NEED_SETUP();
+  if (n < 0 || cap < 0 || (n > 0 && !d_rows) || !d_idx || !d_counts) return WCSPH_EARG;
+  HIPCHK(hipMemsetAsync(d_counts, 0, 5 * sizeof(int32_t), ctx->stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)d_rows, (long long)n, STATE_W,
+                       ctx->d.minx, ctx->d.inv_grid, lo, hi, ghost, has_left, has_right, (long long *)d_idx, cap, d_counts);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+
+int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, void *d_out) {
+  NEED_SETUP();
+  HaloFields h;
+  int rc = halo_fields(ctx, n_fields, fields, &h);
+  if (rc) return rc;
+  if (n <= 0) return WCSPH_OK;
+  hipLaunchKernelGGL(k_halo_pack, dim3(nblk(n * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, d_idx, n, (float *)d_out);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_halo_unpack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, const void *d_in) {
+  NEED_SETUP();
+  HaloFields h;
+  int rc = halo_fields(ctx, n_fields, fields, &h);
+  if (rc) return rc;
+  if (n <= 0) return WCSPH_OK;
+  hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(n * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, d_idx, n, (const float *)d_in);
+  LAUNCHCHK();
+  for (int k = 0; k < n_fields; k++) if (fields[k] == WCSPH_F_POS) ctx->grid_valid = false;
+  ctx->pr_valid = false;
+  return WCSPH_OK;
+}
+int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows) {
+  NEED_SETUP();
+  if (n_owned < 0 || n_total < n_owned || n_total > ctx->capacity) return ctx->fail(WCSPH_EARG, "load_state: counts exceed the context capacity");
+  ctx->d.nl = n_total; ctx->d.n_owned = n_owned;
+  if (n_total > 0) {
+    if (!d_rows) return WCSPH_EARG;
+    hipLaunchKernelGGL(k_load_state, dim3(nblk(n_total)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows, n_total, 0);
+    LAUNCHCHK();
+  }
+  ctx->grid_valid = false;
+  return WCSPH_OK;
+}
+int wcsph_load_state_split(wcsph_ctx *ctx, int32_t n_owned, const float *d_owned_rows, int32_t n_ghost, const float *d_ghost_rows) {
+  NEED_SETUP();
+  if (n_owned < 0 || n_ghost < 0 || (long)n_owned + n_ghost > ctx->capacity) return ctx->fail(WCSPH_EARG, "load_state: counts exceed the context capacity");
+  if ((n_owned > 0 && !d_owned_rows) || (n_ghost > 0 && !d_ghost_rows)) return WCSPH_EARG;
+  ctx->d.nl = n_owned + n_ghost; ctx->d.n_owned = n_owned;
+  if (n_owned > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_owned)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_owned_rows, n_owned, 0);
+  if (n_ghost > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_ghost)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_ghost_rows, n_ghost, n_owned);
+  LAUNCHCHK();
+  ctx->grid_valid = false;
+  return WCSPH_OK;
+}
+int wcsph_store_state(wcsph_ctx *ctx, float *d_rows) {
+  NEED_SETUP();
+  if (ctx->d.nl > 0) {
+    if (!d_rows) return WCSPH_EARG;
+    if (ctx->d.n_owned > 0) hipLaunchKernelGGL(k_store_state, dim3(nblk(ctx->d.n_owned)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows);
+    LAUNCHCHK();
+  }
+  return WCSPH_OK;
+}
+int wcsph_get_acc(wcsph_ctx *ctx, int slot, double *v) {
+  if (!ctx || slot < 0 || slot >= 8 || !v) return WCSPH_EARG;
+  int rc = pull_scalars(ctx);
+  if (rc) return rc;
+  *v = ctx->h_acc[slot];
+  return WCSPH_OK;
+}
+int wcsph_set_acc(wcsph_ctx *ctx, int slot, double v) {
+  if (!ctx || slot < 0 || slot >= 8) return WCSPH_EARG;
+  double row[ACC_STRIPES] = {0};
+  row[0] = v;
+  HIPCHK(hipMemcpyAsync(ctx->d.acc + slot * ACC_STRIPES, row, sizeof row, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // row lives on this stack
+  return WCSPH_OK;
+}
+int wcsph_set_acc_buffer(wcsph_ctx *ctx, void *device_doubles) {
+  NEED_SETUP();
+  if (!device_doubles) return WCSPH_EARG;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->d.acc = (double *)device_doubles;   // the context's own buffer stays in ctx->allocs and is freed with it
+  HIPCHK(hipMemsetAsync(ctx->d.acc, 0, 8 * ACC_STRIPES * sizeof(double), ctx->stream));
+  return WCSPH_OK;
+}
+int wcsph_set_part(wcsph_ctx *ctx, int32_t mode, int32_t x_lo, int32_t x_hi) {
+  if (!ctx || mode < 0 || mode > 2) return WCSPH_EARG;
+  ctx->d.part_mode = mode; ctx->d.part_x0 = x_lo; ctx->d.part_x1 = x_hi > x_lo ? x_hi : x_lo;
+  return WCSPH_OK;
+}
+int wcsph_phase(wcsph_ctx *ctx, int ph) {
+  NEED_GRID();
+  int rc = 0;
+  const float dt = ctx->dt;
+  switch (ph) {
+    case WCSPH_PH_DENSITY_COFF: PASS(k_density_coff); ctx->pr_valid = false; break;   // ghost rows: rho arrives by halo exchange
+    case WCSPH_PH_DENSITY_COFF_WARM: PASS(k_density_coff_warm, dt); ctx->pr_valid = false; break;
+    case WCSPH_PH_VISC_MINV_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; RPASS(k_visc_minv_residual, dt); break;
+    case WCSPH_PH_VISC_MINV_RESIDUAL_VORT: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; RPASS(k_visc_minv_residual_vort, dt); break;
+    case WCSPH_PH_DRHO_DIV_WARM: HOT_DRHO_DIV(DRHO_WARM, dt); break;
+    case WCSPH_PH_VEL_WARM: HOT_VEL(1, ctx->d.kappa_v, dt, 1); break;
+    case WCSPH_PH_DRHO_DIV_BEGIN: HOT_DRHO_DIV(DRHO_BEGIN, dt); break;
+    case WCSPH_PH_MAKE_K_DIV: ELEM(k_make_k, ctx->d.kappa_v, 0.0f); break;
+    case WCSPH_PH_VEL_ITER: HOT_VEL(0, ctx->d.kbuf, dt, ctx->d.n_owned < ctx->d.nl); break;
+    case WCSPH_PH_DRHO_DIV_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_DIV(DRHO_ITER, dt); break;
+    case WCSPH_PH_END_DIV: ELEM(k_end_div, dt); break;
+    case WCSPH_PH_WARM_PRESS_SCALE: ELEM(k_warm_press_scale, dt); break;
+    case WCSPH_PH_WARM_PRESS_VEL: PASS(k_warm_press_vel, dt); break;
+    case WCSPH_PH_DRHO_PRESS_BEGIN: HOT_DRHO_PRESS(DRHO_BEGIN, dt); break;
+    case WCSPH_PH_MAKE_K_PRESS: ELEM(k_make_k, ctx->d.kappa, 1.0f); break;
+    case WCSPH_PH_DRHO_PRESS_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_PRESS(DRHO_ITER, dt); break;
+    case WCSPH_PH_END_PRESS: ELEM(k_end_press, dt); break;
+    case WCSPH_PH_CLEAR: ELEM(k_clear_nonpressure); break;
+    // tension_fixed = 0: the reference loop literally, over its raw bucket rows (bucket.h).  On a slab window the table
+    // spans all ranks (far aliased entries name particles of other slabs): bucket_build refuses with a message.
+    case WCSPH_PH_TENSION_NORMAL:
+      if (ctx->p.tension_fixed == 0) {
+        if (ctx->d.n_owned < ctx->d.nl) return ctx->fail(WCSPH_EARG, "the literal compute_tension (tension_fixed = 0) needs a context that owns every row");
+        if ((rc = bucket_build_rows(ctx))) return rc;
+        PASS(k_tension_normal_literal, ctx->bk);
+      }
+      else RPASS(k_tension_normal);
+      break;
+    case WCSPH_PH_TENSION_ACCEL:
+      if (ctx->p.tension_fixed == 0) {
+        if (ctx->d.n_owned < ctx->d.nl) return ctx->fail(WCSPH_EARG, "the literal compute_tension (tension_fixed = 0) needs a context that owns every row");
+        if ((rc = bucket_build_rows(ctx))) return rc;
+        ELEM(k_tension_accel_literal, ctx->bk);
+      }
+      else PASS(k_tension_accel);
+      break;
+    case WCSPH_PH_VISC_GUESS: ELEM(k_visc_guess); break;
+    case WCSPH_PH_VISC_MINV: RPASS(k_visc_minv, dt); break;
+    case WCSPH_PH_VISC_RESIDUAL: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DZERO))) return rc; RPASS(k_visc_residual, dt); break;
+    case WCSPH_PH_VISC_AD: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_DAD))) return rc; RPASS(k_visc_Ad, dt); break;
+    case WCSPH_PH_VISC_UPDATE: if ((rc = zero_acc(ctx, ACC_DNEW))) return rc; ELEM(k_visc_update, ctx->cg_delta); break;
+    case WCSPH_PH_VISC_DIR: ELEM(k_visc_dir, ctx->cg_delta); break;
+    case WCSPH_PH_VISC_END: ELEM(k_visc_end, dt); break;
+    case WCSPH_PH_VORTICITY: RPASS(k_vorticity, dt); break;
+    case WCSPH_PH_VORTICITY_INT: ELEM(k_vorticity_integrate, dt); break;
+    case WCSPH_PH_UPDATE_VEL: ELEM(k_update_vel, dt); break;
+    case WCSPH_PH_UPDATE_POS: ELEM(k_update_pos, dt); break;
+    case WCSPH_PH_END_DIV_BEGIN_NONPRESSURE: ELEM(k_end_div_begin_nonpressure, dt, 0); break;
+    case WCSPH_PH_UPDATE_VEL_WARM_SCALE: ELEM(k_update_vel_warm_scale, dt); break;
+    case WCSPH_PH_END_PRESS_UPDATE_POS: ELEM(k_end_press_update_pos, dt); break;
+    default: return ctx->fail(WCSPH_EARG, "unknown phase id");
+  }
+  return WCSPH_OK;
+}
+
+// ---- the slab step in one call (include/wcsph.h "the whole DFSPH step of one slab") ----------------------------------
+int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_send, const int32_t *d_ghost_idx, int32_t n_ghost) {
+  NEED_SETUP();
+  if (n_send < 0 || n_ghost < 0 || (n_send > 0 && !d_send_idx) || (n_ghost > 0 && !d_ghost_idx)) return WCSPH_EARG;
+  ctx->halo_send = d_send_idx; ctx->n_halo_send = n_send; ctx->halo_ghost = d_ghost_idx; ctx->n_halo_ghost = n_ghost;
+  return WCSPH_OK;
+}
+}  // extern "C" (templates below)
+// ghost rows' gather records: (pos, 0) -- their payload (.w) arrives with the halo refreshes, their positions do not
+// change during the step
+__global__ void k_ghost_records(Dev d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nl || d.oid[i] < d.n_owned) return;
+  const float4 p = d.pos[i];
+  d.pk[i] = make_float4(p.x, p.y, p.z, 0.f);
+  d.pr[i] = make_float4(p.x, p.y, p.z, 0.f);
+}
+namespace {
+struct SlabRun {
+  wcsph_ctx *ctx;
+  const wcsph_slab_callbacks *cb;
+  bool multi, overlap;
+  int ilo, ihi, n_xchg = 0, n_wait = 0;
+  HaloFields h;
+  void hf_begin() { h.n = 0; h.W = 0; }
+  void hf_add(const void *ptr, int width, int stride) { h.ptr[h.n] = (const float *)ptr; h.width[h.n] = width; h.stride[h.n] = stride; h.W += width; h.n++; }
+  // refresh the ghost rows of the fields collected in `h`, then run `launch()`, a neighbour pass that reads them from
+  // neighbours j -- overlapped: the pass runs on the slab interior while the exchange is in flight, on the rest once it
+  // has landed.  launch == nullptr-like (no_pass): exchange only.
+  // also: a second set of destinations for the same received columns (rho lands in the field AND in the (pos, rho) records)
+  template <class F>
+  int xp(bool has_pass, F &&launch, const HaloFields *also = nullptr) {
+    int rc;
+    if (!multi) return has_pass ? launch() : 0;
+    void *snd = nullptr, *rcv = nullptr;
+    if ((rc = cb->halo_buffers(cb->user, h.W, &snd, &rcv))) return ctx->fail(rc, "slab callback halo_buffers failed");
+    if (ctx->n_halo_send > 0) {
+      hipLaunchKernelGGL(k_halo_pack, dim3(nblk(ctx->n_halo_send * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_send, ctx->n_halo_send, (float *)snd);
+      LAUNCHCHK();
+    }
+    if ((rc = cb->halo_post(cb->user, h.W))) return ctx->fail(rc, "slab callback halo_post failed");
+    n_xchg++;
+    const bool split = overlap && has_pass;
+    if (split) { ctx->d.part_mode = 1; ctx->d.part_x0 = ilo; ctx->d.part_x1 = ihi > ilo ? ihi : ilo; if ((rc = launch())) return rc; }
+    if ((rc = cb->halo_wait(cb->user))) return ctx->fail(rc, "slab callback halo_wait failed");
+    if (ctx->n_halo_ghost > 0) {
+      hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
+      if (also) hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, *also, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
+      LAUNCHCHK();
+    }
+    if (!has_pass) return 0;
+    if (split) ctx->d.part_mode = 2;
+    rc = launch();
+    ctx->d.part_mode = 0;
+    return rc;
+  }
+  int allreduce(int slot) {   // the stripes of a reduction slot summed over the ranks, in place on the device
+    int rc;
+    if (multi && (rc = cb->allreduce_acc(cb->user, slot))) return ctx->fail(rc, "slab callback allreduce_acc failed");
+    return 0;
+  }
+  int fetch() { n_wait++; return pull_scalars(ctx); }   // one host wait: every slot total + the error flags
+};
+}  // namespace
+extern "C" {
+#define SRC(x) do { if ((rc = (x))) { ctx->d.part_mode = 0; return rc; } } while (0)
+#define SPASS_(kern, ...) [&]() -> int { PASS(kern, ##__VA_ARGS__); return 0; }
+int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
+                    int32_t flags, int32_t stats[2]) {
+  NEED_SETUP();
+  if (n_global < 1) return WCSPH_EARG;
+  SlabRun R{ctx, cb, cb && cb->world > 1, (flags & 1) != 0 && cb && cb->world > 1, interior_lo, interior_hi};
+  if (R.multi && (!cb->halo_buffers || !cb->halo_post || !cb->halo_wait || !cb->allreduce_acc || !cb->allreduce_max || !cb->allreduce_words)) return WCSPH_EARG;
+  Dev &d = ctx->d;
+  int rc;
+  const double N = (double)n_global;
+  const bool tension = (flags & 2) && !(d.tension == 0.0f && d.tension_b == 0.0f);
+  if (tension && ctx->p.tension_fixed == 0 && R.multi) return ctx->fail(WCSPH_EARG, "the literal compute_tension reads the reference's raw bucket rows, which span all slabs: tension_fixed = 1 on a decomposition");
+  auto no_pass = []() -> int { return 0; };
+  // ---- particle_data.hash_grid.update_grid(): with the reference's GLOBAL bucket table in faithful mode (HashGrid.py:108-114)
+  if (d.faithful && R.multi) {
+    void *words = nullptr; int64_t nw = 0;
+    SRC(wcsph_grid_update_begin(ctx));
+    SRC(wcsph_bucket_hist_pack(ctx, &words, &nw));
+    if ((rc = cb->allreduce_words(cb->user, words, nw))) return ctx->fail(rc, "slab callback allreduce_words failed");
+    SRC(wcsph_bucket_hist_unpack(ctx));
+    SRC(wcsph_grid_update_end(ctx));
+  } else SRC(wcsph_grid_update(ctx));
+  if (d.nl == 0) { if (stats) stats[0] = stats[1] = 0; return WCSPH_OK; }
+  if (d.n_owned < d.nl) ELEM(k_ghost_records);
+  // ---- compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146): they read
+  // pos_j / vel_j only, which the ghost rows brought with them
+  PASS(k_density_coff_warm, ctx->dt);
+  ctx->dv_iter = 0;
+  // rho_j (field and gather record) and the rescaled kappa_v_j (the payload of the warm-start velocity pass) in ONE message
+  R.hf_begin(); R.hf_add(d.rho, 1, 1); R.hf_add((const float *)d.pk + 3, 1, 4);
+  {
+    HaloFields also = R.h;                    // column 0 once more: -> pr.w
+    also.ptr[0] = (const float *)d.pr + 3; also.stride[0] = 4;
+    SRC(R.xp(false, no_pass, &also));
+  }
+  ctx->pr_valid = true;                       // (pos, rho) records of every row: own rows by the density pass, ghosts just now
+  SRC(SPASS_(k_vel_from_k<1>, (const float4 *)d.pk, ctx->dt)());      // warm-start velocities (dfsph.py:420-439); ghosts' kappa_v arrived above
+  double err = -0.1;
+  const float dt = ctx->dt;
+  R.hf_begin(); R.hf_add(d.vel, 3, 4);
+  SRC(R.xp(true, SPASS_((k_drho_div<DRHO_BEGIN, true>), dt)));
+  const bool vort_div = d.n_owned >= 0;       // the vorticity sums ride on the last divergence iteration (k_drho_div_iter_vort)
+  while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
+    R.hf_begin(); R.hf_add((const float *)d.pk + 3, 1, 4);           // k_j = b_j alpha_j, written by the density-change pass
+    SRC(R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dt, d.kappa_v)));
+    R.hf_begin(); R.hf_add(d.vel, 3, 4);
+    if (vort_div) SRC(R.xp(true, SPASS_(k_drho_div_iter_vort, dt)));
+    else SRC(R.xp(true, SPASS_((k_drho_div<DRHO_ITER, true>), dt)));
+    SRC(R.allreduce(ACC_ERR));
+    SRC(R.fetch());
+    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+    err = 0.001 * N / (double)dt;
+    ctx->dv_iter++;
+  }
+  // ---- compute_nonpressure_force() (dfsph.py:84-103)
+  ELEM(k_end_div_begin_nonpressure, dt, vort_div ? 1 : 0);
+  if (tension) {
+    RPASS(k_tension_normal);
+    R.hf_begin(); R.hf_add(d.normal, 3, 4);
+    SRC(R.xp(true, SPASS_(k_tension_accel)));
+  }
+  R.hf_begin(); R.hf_add(d.vel_guess, 3, 4);
+  if (vort_div) SRC(R.xp(true, SPASS_(k_visc_minv_residual, dt)));
+  else SRC(R.xp(true, SPASS_(k_visc_minv_residual_vort, dt)));
+  SRC(R.allreduce(ACC_DZERO));                  // the first k_visc_update takes delta_zero from the device
+  R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
+  SRC(R.xp(true, SPASS_(k_visc_Ad, dt)));
+  SRC(R.allreduce(ACC_DAD));
+  ELEM(k_visc_update, 0.0f, 1);
+  SRC(R.allreduce(ACC_DNEW));
+  SRC(R.fetch());
+  ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
+  ctx->cg_delta_old = ctx->cg_delta_zero;
+  ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+  ctx->vs_iter = 1;
+  while (ctx->vs_iter < 100) {
+    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero || (double)ctx->cg_delta_zero < (double)ctx->p.eps) break;
+    ELEM(k_visc_dir, ctx->cg_delta_old);        // beta = delta' (global, on the device) / delta the last iteration started with
+    R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
+    SRC(R.xp(true, SPASS_(k_visc_Ad, dt)));
+    SRC(R.allreduce(ACC_DAD));
+    ELEM(k_visc_update, ctx->cg_delta);
+    SRC(R.allreduce(ACC_DNEW));
+    SRC(R.fetch());
+    ctx->cg_delta_old = ctx->cg_delta;
+    ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+    ctx->vs_iter++;
+  }
+  // end_viscosity + the integration loop of compute_vorticity + the per-particle part of the CFL reduction
+  const bool cfl_here = !(d.faithful && d.nl <= 1);
+  if (cfl_here) { ELEM(k_finish_nonpressure, dt); ctx->cfl_done = true; }
+  else { ELEM(k_visc_end, dt); ELEM(k_vorticity_integrate, dt); }
+  // ---- optimize_time_step() (dfsph.py:107-129) on the GLOBAL velocity maximum
+  double vmax;
+  if (R.multi && cb->allreduce_max_bits) {
+    // the maximum over the ranks is formed on the device (a MAX all-reduce of the bit pattern, queued behind k_cfl_store) and
+    // read with the one wait this decision needs anyway.  Every rank makes the call, also one whose reference launches nothing
+    // (dfsph.py:108-111 with a single liquid particle: vel_max[0] keeps its 0)
+    if (d.faithful && d.nl <= 1) HIPCHK(hipMemsetAsync(d.flags + FLAG_VMAX, 0, sizeof(int), ctx->stream));
+    else {
+      if (ctx->cfl_done) ctx->cfl_done = false;   // k_finish_nonpressure already took the per-particle maxima
+      else ELEM(k_cfl, ctx->dt);
+      hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d, DtRule{nullptr, 0.f, 0, 0.0, 0.0, 0.0, 0.0});
+      LAUNCHCHK();
+    }
+    if ((rc = cb->allreduce_max_bits(cb->user, d.flags + FLAG_VMAX))) return ctx->fail(rc, "slab callback allreduce_max_bits failed");
+    SRC(pull_scalars(ctx));
+    const int bits = ctx->h_flags[FLAG_VMAX];
+    memcpy(&ctx->vel_max0, &bits, 4);
+    R.n_wait++;
+    vmax = (double)ctx->vel_max0;
+  } else {
+    SRC(wcsph_dfsph_cfl_reduce(ctx));
+    R.n_wait++;
+    vmax = (double)ctx->vel_max0;
+    if (R.multi && (rc = cb->allreduce_max(cb->user, &vmax))) return ctx->fail(rc, "slab callback allreduce_max failed");
+  }
+  if ((double)(float)vmax > (double)ctx->p.eps) {
+    double time_step = 0.5 * 0.4 * ctx->p.cfl_radius * 2.0 / sqrt((double)(float)vmax);
+    if (time_step > ctx->p.user_max_t) time_step = ctx->p.user_max_t;
+    if (time_step < ctx->p.user_min_t) time_step = ctx->p.user_min_t;
+    const int it = ctx->vs_iter > ctx->pr_iter ? ctx->vs_iter : ctx->pr_iter;  // max(vs, max(pr, vs)), Q6
+    float d2 = ctx->dt;
+    if (it > 10) d2 = (float)((double)d2 * 0.9);
+    else if (it < 5) d2 = (float)((double)d2 * 1.1);
+    if ((double)d2 > time_step) d2 = (float)time_step;
+    ctx->dt = d2;
+  }
+  const float dtn = ctx->dt;
+  // ---- update_vel(); solve_pressure() (dfsph.py:150-164; the warm start changes no velocity in the reference, Q7)
+  ELEM(k_update_vel_warm_scale, dtn);
+  PASS(k_warm_press_vel, dtn);
+  ctx->pr_iter = 0;
+  err = 0.0;
+  R.hf_begin(); R.hf_add(d.vel, 3, 4);
+  SRC(R.xp(true, SPASS_((k_drho_press<DRHO_BEGIN, true>), dtn)));
+  while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
+    const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
+    if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
+    R.hf_begin(); R.hf_add((const float *)d.pk + 3, 1, 4);
+    SRC(R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dtn, d.kappa)));
+    R.hf_begin(); R.hf_add(d.vel, 3, 4);
+    SRC(R.xp(true, SPASS_((k_drho_press<DRHO_ITER, true>), dtn)));
+    if (prof) { HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream)); ctx->prof_used += 2; }
+    ctx->pr_iter++;
+    if (ctx->pr_iter < 2) { err = 1.0; continue; }   // `pr_iter < 2` forces the second iteration whatever the first reports
+    SRC(R.allreduce(ACC_ERR));
+    SRC(R.fetch());
+    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+    err = (double)ctx->avg_density_err / N;
+  }
+  ELEM(k_end_press_update_pos, dtn);
+  if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; }
+  return WCSPH_OK;
+}
+#undef SPASS_
+#undef SRC
+
+
+}  // extern "C"

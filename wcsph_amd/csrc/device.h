@@ -125,11 +125,9 @@ __device__ __forceinline__ float cubic_gradW_scale(const Dev &d, float r2) {
 }
 
 // ---- tile-ordered cell index ----------------------------------------------------------------------------
-#ifndef T0B      /* -DT0B=0 -DT1B=0 -DT2B=3 gives the plain z-fastest order (tools/state_bench.py compares shapes) */
 #define T0B 1   /* outer axis: 2 cells per tile  */
 #define T1B 2   /* middle axis: 4 cells per tile */
 #define T2B 4   /* z: 16 cells per tile (row_pieces relies on >= 5 cells: a walked row touches at most two tiles) */
-#endif
 #define TILE_SHIFT (T0B + T1B + T2B)
 // index of the first cell (z = 0 of z-tile 0) of the z-row through (cx, cy): cell (cx, cy, cz) = row + ((cz >> T2B) << TILE_SHIFT) + (cz & (2^T2B - 1))
 __device__ __forceinline__ int cell_row(const Dev &d, int cx, int cy) {
@@ -161,53 +159,26 @@ __device__ __forceinline__ RowPieces row_pieces(const Dev &d, const int *CS, int
 // elementwise traffic of a step -- scratch vectors of the PCG, per-particle scalars, the sort's copies -- is kept from
 // displacing what the neighbour passes come back to launch after launch: the 16-bit neighbour streams and the gather
 // records.  Arrays that a following pass GATHERS (pos, vel, pk, pr, vel_guess, cg_dir, omega) stay on plain accesses.
-#ifndef WCSPH_ONCE
-#define WCSPH_ONCE 1   /* -DWCSPH_ONCE=0: plain accesses everywhere (the A/B build of profiles/r03n_ab_once.md) */
-#endif
 typedef float v4f_nt __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_once(const float4 *p) {
-#if WCSPH_ONCE
   const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt *>(p));
   return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return *p;
-#endif
 }
 __device__ __forceinline__ float ld_once(const float *p) {
-#if WCSPH_ONCE
   return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
 }
 __device__ __forceinline__ int ld_once(const int *p) {
-#if WCSPH_ONCE
   return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
 }
 __device__ __forceinline__ void st_once(float4 *p, float4 v) {
-#if WCSPH_ONCE
   v4f_nt w = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(w, reinterpret_cast<v4f_nt *>(p));
-#else
-  *p = v;
-#endif
 }
 __device__ __forceinline__ void st_once(float *p, float v) {
-#if WCSPH_ONCE
   __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
 }
 __device__ __forceinline__ void st_once(int *p, int v) {
-#if WCSPH_ONCE
   __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
 }
 
 // first statement of a kernel that may be launched speculatively (grid-uniform: taken by every thread or by none)
@@ -233,9 +204,7 @@ __device__ __forceinline__ bool part_ok(const Dev &d, float4 pi) {
 __device__ __forceinline__ int sorted_index(const Dev &d) {
   const int per = gridDim.x >> 3;
   int q = blockIdx.x >> 3;
-#ifndef WCSPH_NO_ALT
   if (d.rev) q = per - 1 - q;   // every XCD walks its eighth backwards
-#endif
   const int blk = (blockIdx.x & 7) * per + q;
   return blk * BLOCK + threadIdx.x;
 }
