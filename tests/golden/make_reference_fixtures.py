@@ -5,6 +5,8 @@
     python tests/golden/make_reference_fixtures.py dfsph_perturbed  ->  tests/golden/ref_dfsph_perturbed_default_scene.npz
     python tests/golden/make_reference_fixtures.py sesph            ->  tests/golden/ref_sesph_default_scene.npz
     python tests/golden/make_reference_fixtures.py iisph            ->  tests/golden/ref_iisph_default_scene.npz    (expanded + jittered state, see run_iisph)
+    python tests/golden/make_reference_fixtures.py dfsph_squeezed   ->  tests/golden/ref_dfsph_squeezed_default_scene.npz   (round 4: 3 steps, Q5 / Q6 observable)
+    python tests/golden/make_reference_fixtures.py dfsph_adhesion   ->  tests/golden/ref_dfsph_adhesion_default_scene.npz   (round 4: the solid branch of compute_tension)
 
 `dfsph` starts from the script's own rest state, where most neighbour sums are identically zero for the first steps
 (v = 0, omega = 0).  `dfsph_perturbed` is the same imported script with a non-trivial STATE written into its fields
@@ -59,7 +61,63 @@ def perturb(ref, pd, out):
     out["tension_coff"], out["tension_coff_b"] = np.float32(0.05), np.float32(0.05)
 
 
-def run_dfsph(steps, perturbed=False):
+
+def row_hashes(rows, counts):
+    """all rows of HashGrid.neighbor as three numbers per row: sum, xor and an ORDER-SENSITIVE polynomial hash of the
+    entries 0 .. count-1 (uint64 wrap-around: h = h * 1000003 + (j + 1)); a fixture of 8000 x 3 words instead of 8000 x 2048"""
+    n = rows.shape[0]
+    s = np.zeros(n, np.int64); x = np.zeros(n, np.int64); h = np.zeros(n, np.uint64)
+    kmax = int(counts.max()) if n else 0
+    with np.errstate(over="ignore"):
+        for k in range(kmax):
+            live = counts > k
+            j = rows[:, k].astype(np.int64)
+            s += np.where(live, j, 0)
+            x ^= np.where(live, j, 0)
+            h = np.where(live, h * np.uint64(1000003) + (j + 1).astype(np.uint64), h)
+    return s, x, h
+
+
+SQUEEZE_FIRST, SQUEEZE_FACTOR = 4400, 0.9
+
+
+def squeeze_half(ref, pd, out):
+    """perturb(), then the liquid particles with original index >= 4400 (x-planes 11..19 of the 20^3 block) compressed to 0.9
+    of their spacing about their centroid.  Chosen with the oracle so that the reference's own quirks become OBSERVABLE in
+    deltaT: the compressed half makes solve_pressure() iterate (pr_iter = 5 at step 0) while the particles the CFL tree
+    actually covers -- original indices [0, 4096), Q5 -- stay calm, so the time-step cap does not bite and the dt rule
+    shows which iteration count it read: step 1 keeps dt (it = max(vs_iter, pr_iter OF STEP 0) = 5, Q6), step 2 grows it
+    by 1.1 (pr_iter of step 1 = 2).  A true velocity maximum would cap dt at ~0.0004 from step 1 on."""
+    perturb(ref, pd, out)
+    nl = pd.liquid_count
+    pos = pd.pos.to_numpy()
+    sel = np.arange(nl) >= SQUEEZE_FIRST
+    c = pos[:nl][sel].mean(0, dtype=np.float64)
+    pos[:nl][sel] = (c + SQUEEZE_FACTOR * (pos[:nl][sel].astype(np.float64) - c)).astype(np.float32)
+    pd.pos.from_numpy(pos)
+    out["squeeze_first"], out["squeeze_factor"] = np.int32(SQUEEZE_FIRST), np.float64(SQUEEZE_FACTOR)
+
+
+ADH_N, ADH_R = 600, 0.2
+
+
+def adhesion_ball(ref, pd, out):
+    """perturb(), then the first 600 solid rows of the imported script moved onto a sphere of radius 0.2 around (0, 0.5, 0)
+    -- inside the 0.26 gate of dfsph.py:300-302 and inside the liquid block, so that liquid particles sit at h/2 < r <= h
+    from them and the adhesion term (kernels/AdhesionKernel.py:20-29) is non-zero.  No solid of model/box_boundry.obj lies
+    inside that gate, which is why no other fixture exercises the branch."""
+    perturb(ref, pd, out)
+    nl = pd.liquid_count
+    pos = pd.pos.to_numpy()
+    k = np.arange(ADH_N) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / ADH_N); th = np.pi * (1.0 + 5.0 ** 0.5) * k        # Fibonacci sphere
+    ball = np.stack([ADH_R * np.cos(th) * np.sin(phi), 0.5 + ADH_R * np.cos(phi), ADH_R * np.sin(th) * np.sin(phi)], 1)
+    pos[nl:nl + ADH_N] = ball.astype(np.float32)
+    pd.pos.from_numpy(pos)
+    out["adh_n"], out["adh_r"] = np.int32(ADH_N), np.float64(ADH_R)
+
+
+def run_dfsph(steps, perturbed=False, state=None):
     os.chdir(REF)                       # the script opens model/box_boundry.obj and MCData.txt by relative path
     import taichi as ti
     t0 = time.time()
@@ -67,7 +125,9 @@ def run_dfsph(steps, perturbed=False):
     pd = ref.particle_data
     _name_fields(ti, ref, pd, pd.hash_grid)
     out = {}
-    if perturbed:
+    if state is not None:
+        state(ref, pd, out)
+    elif perturbed:
         perturb(ref, pd, out)
     out.update({"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
            "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()})
@@ -83,7 +143,10 @@ def run_dfsph(steps, perturbed=False):
         pd.hash_grid.update_grid()
         snap("grid", neighborCount=pd.hash_grid.neighborCount, gridCount=pd.hash_grid.gridCount)
         if step == 0:
-            out["neighbor_rows_0_64"] = pd.hash_grid.neighbor.to_numpy()[:64]
+            rows0 = pd.hash_grid.neighbor.to_numpy()
+            out["neighbor_rows_0_64"] = rows0[:64]
+            if state is not None:        # round 4: every row of step 0, as three hashes per row
+                out["rows_sum"], out["rows_xor"], out["rows_poly"] = row_hashes(rows0, pd.hash_grid.neighborCount.to_numpy())
         ref.compute_density()
         snap("density", rho=pd.rho)
         ref.compute_dfsph_coff()
@@ -104,6 +167,39 @@ def run_dfsph(steps, perturbed=False):
     out["steps"] = np.int32(steps)
     out["oob_reads"] = np.array(["%s=%d" % kv for kv in sorted(ti.oob_reads.items())] or ["none"])
     print("out-of-bounds reads served as 0:", dict(ti.oob_reads), flush=True)
+    return out
+
+
+def run_adhesion():
+    """grid, density, then clear_nonpressure + compute_tension through the script's own kernels (dfsph.py:264-305, 333-336):
+    `normal` and `d_vel` with a live solid branch"""
+    os.chdir(REF)
+    import taichi as ti
+    t0 = time.time()
+    import dfsph as ref
+    pd = ref.particle_data
+    _name_fields(ti, ref, pd, pd.hash_grid)
+    out = {}
+    adhesion_ball(ref, pd, out)
+    out.update({"pos0": pd.pos.to_numpy(), "n_liquid": np.int32(pd.liquid_count), "n_solid": np.int32(pd.solid_count),
+                "blockSize": pd.hash_grid.blockSize.to_numpy()[0], "maxb": pd.maxboundarynp.copy(), "minb": pd.minboundarynp.copy()})
+    pd.hash_grid.update_grid()
+    out["neighborCount"], out["gridCount"] = pd.hash_grid.neighborCount.to_numpy(), pd.hash_grid.gridCount.to_numpy()
+    out["rows_sum"], out["rows_xor"], out["rows_poly"] = row_hashes(pd.hash_grid.neighbor.to_numpy(), out["neighborCount"])
+    print("  grid %.0f s" % (time.time() - t0), flush=True)
+    ref.compute_density()
+    out["rho"] = pd.rho.to_numpy()
+    print("  density %.0f s" % (time.time() - t0), flush=True)
+    ref.clear_nonpressure()
+    ref.compute_tension()
+    out["normal"], out["d_vel"] = pd.normal.to_numpy(), pd.d_vel.to_numpy()
+    # the same two loops with the liquid coefficient off: what is left of d_vel - g is the solid branch alone
+    pd.tension_coff = 0.0
+    ref.clear_nonpressure()
+    ref.compute_tension()
+    out["d_vel_solid_only"] = pd.d_vel.to_numpy()
+    print("  tension %.0f s" % (time.time() - t0), flush=True)
+    out["oob_reads"] = np.array(["%s=%d" % kv for kv in sorted(ti.oob_reads.items())] or ["none"])
     return out
 
 
@@ -204,8 +300,12 @@ def run_iisph(steps):
 
 if __name__ == "__main__":
     which = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else (2 if which.startswith("dfsph") else 1)
-    if which.startswith("dfsph"):
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else (3 if which == "dfsph_squeezed" else 2 if which.startswith("dfsph") else 1)
+    if which == "dfsph_adhesion":
+        res = run_adhesion()
+    elif which == "dfsph_squeezed":
+        res = run_dfsph(steps, state=squeeze_half)
+    elif which.startswith("dfsph"):
         res = run_dfsph(steps, which == "dfsph_perturbed")
     elif which == "iisph":
         res = run_iisph(steps)

@@ -37,6 +37,28 @@ def _close(name, a, b, tol=RTOL, floor=1e-30):
     assert err < tol, "%s: rel err %.3e (tol %.1e)" % (name, err, tol)
 
 
+def _row_hashes(rows, counts):
+    """as tests/golden/make_reference_fixtures.py row_hashes: per row the sum, the xor and an ORDER-SENSITIVE polynomial hash
+    (uint64 wrap-around: h = h * 1000003 + (j + 1)) of the entries 0 .. count-1"""
+    rows, counts = np.asarray(rows), np.asarray(counts)
+    n = rows.shape[0]
+    s = np.zeros(n, np.int64); x = np.zeros(n, np.int64); h = np.zeros(n, np.uint64)
+    with np.errstate(over="ignore"):
+        for k in range(int(counts.max()) if n else 0):
+            live = counts > k
+            j = rows[:, k].astype(np.int64)
+            s += np.where(live, j, 0)
+            x ^= np.where(live, j, 0)
+            h = np.where(live, h * np.uint64(1000003) + (j + 1).astype(np.uint64), h)
+    return s, x, h
+
+
+def _check_all_rows(f, rows, counts):
+    """EVERY row of HashGrid.neighbor of step 0 against the reference text's own, entry for entry and in order (three hashes per row)"""
+    s, x, h = _row_hashes(rows, counts)
+    np.testing.assert_array_equal(s, f["rows_sum"]); np.testing.assert_array_equal(x, f["rows_xor"]); np.testing.assert_array_equal(h, f["rows_poly"])
+
+
 # ---- the oracle (CPU) -------------------------------------------------------------------------------------------------
 def _oracle_dfsph(f):
     from oracle import Oracle
@@ -63,6 +85,8 @@ def test_oracle_reproduces_the_reference_text_dfsph(fixture):
         np.testing.assert_array_equal(o.neighborCount, g("grid_neighborCount"))
         if s == 0:
             np.testing.assert_array_equal(o.neighbor[:64], f["neighbor_rows_0_64"])     # rows entry for entry (ascending-id bucket order)
+            if "rows_poly" in f.files:
+                _check_all_rows(f, o.neighbor, o.neighborCount)
         o.compute_density(); _close("rho", o.rho, g("density_rho"))
         o.compute_dfsph_coff(); _close("alpha", o.alpha_coff, g("coff_alpha"))
         o.solve_vel_divergence()
@@ -127,6 +151,9 @@ def test_hip_reproduces_the_reference_text_dfsph(fixture):
         np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), g("grid_neighborCount"))
         if s == 0:
             np.testing.assert_array_equal(pd.hash_grid.neighbor.rows(0, 64)[1], f["neighbor_rows_0_64"])
+            if "rows_poly" in f.files:
+                cnt, rows = pd.hash_grid.neighbor.rows(0, nl)
+                _check_all_rows(f, rows, cnt)
         dfsph.compute_density(); _close("rho", pd.rho.to_numpy(), g("density_rho"), 1e-5)
         dfsph.compute_dfsph_coff(); _close("alpha", dfsph.alpha_coff.to_numpy(), g("coff_alpha"), 1e-5)
         dfsph.solve_vel_divergence()
@@ -183,6 +210,60 @@ def test_hip_reproduces_the_reference_text_sesph():
     sesph.update_pressure(); _close("rho", sesph.rho.to_numpy(), f["s0_rho"], 1e-5); _close("pressure", sesph.pressure.to_numpy(), f["s0_pressure"], 5e-4, floor=1.0)
     sesph.compute_force(); _close("d_vel", sesph.d_vel.to_numpy(), f["s0_d_vel"], 5e-4)
     sesph.integrator_sesph(); _close("vel", sesph.vel.to_numpy(), f["s0_vel"], 5e-4); _close("pos", pd.pos.to_numpy()[:nl], f["s0_pos"][:nl], 1e-6)
+    pd.close()
+
+
+
+# ---- the solid branch of compute_tension (dfsph.py:297-304, kernels/AdhesionKernel.py:20-29) -------------------------------------
+# make_reference_fixtures.py `dfsph_adhesion`: the imported script, perturbed state, tension_coff = tension_coff_b = 0.05, and 600 of
+# its solid rows moved onto a sphere of radius 0.2 around (0, 0.5, 0) -- inside the 0.26 gate and inside the liquid -- then grid,
+# density, clear_nonpressure + compute_tension through the script's own kernels.  859 particles carry a non-zero adhesion term.
+G = np.array([0.0, -9.81, 0.0], np.float32)
+
+
+def test_oracle_reproduces_the_reference_text_adhesion():
+    from oracle import Oracle
+    f = _load("ref_dfsph_adhesion_default_scene.npz")
+    nl = int(f["n_liquid"])
+    solid = f["d_vel_solid_only"] - G
+    assert int((np.abs(solid).max(1) > 0).sum()) > 500 and float(np.abs(solid).max()) > 0.1     # the branch is live in the fixture
+    o = Oracle(f["pos0"], nl, 0.025, mode="faithful", bounds=(f["maxb"], f["minb"]))
+    o.tension_fixed = 0
+    o.reset_param()
+    o.tension_coff, o.tension_coff_b = float(f["tension_coff"]), float(f["tension_coff_b"])
+    o.update_grid()
+    np.testing.assert_array_equal(o.gridCount, f["gridCount"]); np.testing.assert_array_equal(o.neighborCount, f["neighborCount"])
+    _check_all_rows(f, o.neighbor, o.neighborCount)
+    o.compute_density(); _close("rho", o.rho, f["rho"])
+    o.clear_nonpressure(); o.compute_tension()
+    _close("normal", o.normal, f["normal"]); _close("d_vel", o.d_vel, f["d_vel"])
+    o.tension_coff = 0.0
+    o.clear_nonpressure(); o.compute_tension()
+    _close("adhesion alone", o.d_vel - G, solid, 2e-5)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_reference_text_adhesion():
+    from wcsph_amd import dfsph
+    f = _load("ref_dfsph_adhesion_default_scene.npz")
+    nl = int(f["n_liquid"])
+    pd = dfsph.init_particle(particleDim=20, neighbor_mode="faithful", liquid=f["pos0"][:nl].astype(np.float64), boundary=f["pos0"][nl:].astype(np.float64),
+                             tension_coff=float(f["tension_coff"]), tension_coff_b=float(f["tension_coff_b"]))
+    np.testing.assert_array_equal(pd.pos.to_numpy(), f["pos0"])
+    dfsph.reset_param()
+    pd.hash_grid.update_grid()
+    np.testing.assert_array_equal(pd.hash_grid.gridCount, f["gridCount"])
+    np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), f["neighborCount"])
+    cnt, rows = pd.hash_grid.neighbor.rows(0, nl)
+    _check_all_rows(f, rows, cnt)
+    dfsph.compute_density(); _close("rho", pd.rho.to_numpy(), f["rho"], 1e-5)
+    dfsph.clear_nonpressure(); dfsph.compute_tension()
+    _close("normal", pd.normal.to_numpy(), f["normal"], 5e-5); _close("d_vel", pd.d_vel.to_numpy(), f["d_vel"], 5e-5)
+    from wcsph_amd import _lib                                # the liquid coefficient off: what is left of d_vel - g is the solid branch
+    _lib.check(pd._need_ctx(), _lib.load().wcsph_set_scalar(pd._need_ctx(), _lib.SCALAR_ID["tension_coff"], 0.0))
+    dfsph.clear_nonpressure(); dfsph.compute_tension()
+    _close("adhesion alone", pd.d_vel.to_numpy() - G, f["d_vel_solid_only"] - G, 5e-5)
     pd.close()
 
 
