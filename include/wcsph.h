@@ -146,7 +146,8 @@ int wcsph_compact_lists_to_host(wcsph_ctx *ctx, int32_t i0, int32_t n, int32_t c
 /* diagnostics: how evenly the compact lists load the 64-lane waves that walk them (a wave runs as many trips as its
  * longest list).  Histograms over 8-slot stream blocks, 0..63 (64 bins each):
  * hist[0] particles by liquid blocks, hist[1] by solid blocks, hist[2] / hist[3] waves (64 consecutive cell-sorted
- * particles) by their LONGEST liquid / solid list, hist[4] waves by the block count 3/4 of their lanes reach (liquid) */
+ * particles) by their LONGEST liquid / solid list, hist[4] waves by their largest liquid + solid block count (the trips a
+ * neighbour pass makes for the wave: one trip sequence serves both streams) */
 int wcsph_list_stats(wcsph_ctx *ctx, int64_t hist[5][64]);
 
 /* ---- dfsph.py kernels (one entry per @ti.kernel) ------------------------------------- */
@@ -271,10 +272,13 @@ int wcsph_set_cell_window(wcsph_ctx *ctx, int32_t x0, int32_t x1);
  *  - wcsph_set_owned_columns(): the global cell columns whose boundary particles THIS rank counts (each exactly once),
  *  - wcsph_bucket_hist(which = 1): static boundary histogram, summed over ranks ONCE after wcsph_setup();
  *    (which = 0): liquid histogram of the step, int32[n] on the device, summed over ranks between
- *    wcsph_grid_update_begin() and wcsph_grid_update_end() (wcsph_grid_update() = both, for a single context). */
+ *    wcsph_grid_update_begin() [cells, this rank's histogram], wcsph_grid_update_mid() [scan, sort, list build: reads nothing of
+ *    the histogram, so the all-reduce can be in flight behind it; optional -- _end() runs whatever has not run] and
+ *    wcsph_grid_update_end() [neighborCount] (wcsph_grid_update() = all of it, for a single context). */
 int wcsph_set_owned_columns(wcsph_ctx *ctx, int32_t lo, int32_t hi);
 int wcsph_set_global_liquid(wcsph_ctx *ctx, int64_t n_liquid_global);
 int wcsph_grid_update_begin(wcsph_ctx *ctx);
+int wcsph_grid_update_mid(wcsph_ctx *ctx);
 int wcsph_grid_update_end(wcsph_ctx *ctx);
 int wcsph_bucket_hist(wcsph_ctx *ctx, int which, void **d_ptr, int64_t *n);
 /* the per-step liquid histogram packed for the wire: two 16-bit counts per int32 word (an int32 SUM all-reduce adds the
@@ -383,14 +387,24 @@ typedef struct wcsph_slab_callbacks {
   int (*allreduce_max)(void *user, double *v);
   int (*allreduce_words)(void *user, void *d_words, int64_t n);
   int (*allreduce_max_bits)(void *user, void *d_word);
+  /* the packed bucket histogram's all-reduce in two halves, so that it is in flight while the library scans, sorts and builds
+   * the lists (which read none of it): _post starts it (ordered behind the work already on the context's stream), _wait makes
+   * the context's stream wait for it.  Both NULL: allreduce_words (blocking, on the critical path) is used instead */
+  int (*allreduce_words_post)(void *user, void *d_words, int64_t n);
+  int (*allreduce_words_wait)(void *user);
 } wcsph_slab_callbacks;
 /* the rows this rank sends (original indices of OWNED rows, left neighbour's first) and the ghost rows it receives into,
  * both device int32 arrays that stay valid until the next call; after every wcsph_load_state*() */
 int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_send, const int32_t *d_ghost_idx, int32_t n_ghost);
 /* n_global: liquid particles of ALL slabs (error thresholds are per global particle, dfsph.py:143, 162);
  * interior [x_lo, x_hi): global cell columns whose particles have no ghost within reach (wcsph_set_part);
- * flags: bit 0 = overlap halo refreshes with the interior, bit 1 = surface tension passes on.
- * Afterwards: wcsph_get_scalar(DELTA_T), wcsph_get_iters(), stats[0] = halo exchanges, stats[1] = host waits of this step. */
+ * flags: bit 0 = overlap halo refreshes with the interior, bit 1 = surface tension passes on, bit 2 = no speculation (one host
+ * wait per solver decision, the control flow of rounds 1-3).
+ * Speculation (default; needs allreduce_max_bits): every solver decision is taken on the device from the all-reduced -- hence
+ * rank-identical -- error sum and the common-case continuation is queued behind it in gated segments, halo exchanges included
+ * (a gated-off exchange moves a stale buffer that nobody unpacks): the GPU runs the step without waiting for the host.
+ * Afterwards: wcsph_get_scalar(DELTA_T), wcsph_get_iters(), stats[0] = halo exchanges, stats[1] = host waits of this step
+ * with the GPU idle behind them (1 in the common case: the step's last mail). */
 int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
                     int32_t flags, int32_t stats[2]);
 

@@ -40,6 +40,7 @@ def _hip_run(rank, world, port, outdir, n):
     torch.cuda.synchronize()
     np.save(os.path.join(outdir, "hrows_w%d_r%d.npy" % (world, rank)), sim.rows.cpu().numpy())
     np.save(os.path.join(outdir, "hlog_w%d_r%d.npy" % (world, rank)), np.array(log))
+    np.save(os.path.join(outdir, "hwaits_w%d_r%d.npy" % (world, rank)), np.array([sim.n_host_waits, sim.n_exchanges, STEPS]))
     sim.B.close()
     if world > 1:
         dist.barrier()
@@ -181,6 +182,41 @@ def test_native_slab_step_equals_the_python_phase_driver(tmp_path, mode):
     np.testing.assert_allclose(logs[0][:, 3], logs[1][:, 3], rtol=1e-7)
     dpos, dvel, _ = slab_util.match_rows(rows[0], rows[1])
     assert dpos < 1e-6 and dvel < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["clean", "faithful"])
+def test_speculative_slab_step_changes_nothing_and_hides_the_decisions(tmp_path, mode):
+    """wcsph_slab_step queues the common-case continuation behind every solver decision (the decisions are taken on the device
+    from the all-reduced, rank-identical sums; gated launches, unconditional exchanges): against WCSPH_SLAB_SPECULATE=0 -- one
+    host wait per decision, the control flow of rounds 1-3 -- the same iteration counts, dt history and rows; and the host
+    waits with an idle GPU behind them drop from >= 4 per step to the step's last mail (+ 1 for the row classification)
+    wherever the common case holds."""
+    import slab_util
+    from test_slab_gloo import _free_port
+    n, outs = 12, []
+    os.environ["SLAB_TEST_MODE"] = mode
+    try:
+        for spec in ("1", "0"):
+            out = os.path.join(str(tmp_path), "spec" + spec)
+            os.makedirs(out)
+            os.environ["WCSPH_SLAB_SPECULATE"] = spec
+            mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+            outs.append(out)
+    finally:
+        os.environ.pop("WCSPH_SLAB_SPECULATE", None); os.environ.pop("SLAB_TEST_MODE", None)
+    rows = [np.concatenate([np.load(os.path.join(o, "hrows_w2_r%d.npy" % r)) for r in range(2)]) for o in outs]
+    logs = [np.load(os.path.join(o, "hlog_w2_r0.npy")) for o in outs]
+    np.testing.assert_array_equal(logs[0][:, :3], logs[1][:, :3])
+    np.testing.assert_allclose(logs[0][:, 3], logs[1][:, 3], rtol=1e-7)
+    dpos, dvel, _ = slab_util.match_rows(rows[0], rows[1])
+    assert dpos < 1e-6 and dvel < 1e-4
+    w_spec, w_plain = (np.load(os.path.join(o, "hwaits_w2_r0.npy")) for o in outs)
+    steps = float(w_spec[2])
+    # plain: divergence, viscosity, CFL, pressure (>= 4) + the classification; speculative: the last mail + the classification,
+    # plus one per decision that fell the other way (the drifting block of this scene needs extra iterations in some steps)
+    assert w_plain[0] / steps >= 5.0
+    assert w_spec[0] / steps <= w_plain[0] / steps - 2.0
+    print("host waits per step: speculative %.2f, plain %.2f; exchanges per step %.1f / %.1f" % (w_spec[0] / steps, w_plain[0] / steps, w_spec[1] / steps, w_plain[1] / steps))
 
 
 def test_native_classifier_equals_the_torch_classification():

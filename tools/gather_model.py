@@ -87,9 +87,12 @@ def model(shape=(1, 2, 4), list_order="walk", align=None, seed=1, subcell=None):
             groups = []
             for l, x in enumerate(lists):
                 i = idx[l]
-                g = (co[x] - co[i] + 2) * (5 if align == "row" else 1) + ((cm[x] - cm[i] + 2) if align == "row" else 0)
+                if isinstance(align, tuple):     # a partition of the five outer planes: align[d + 2] = group of plane offset d
+                    g = np.array(align)[co[x] - co[i] + 2]
+                else:
+                    g = (co[x] - co[i] + 2) * (5 if align == "row" else 1) + ((cm[x] - cm[i] + 2) if align == "row" else 0)
                 groups.append(g)
-            ng = 25 if align == "row" else 5
+            ng = (max(align) + 1) if isinstance(align, tuple) else (25 if align == "row" else 5)
             cols = []
             for gid in range(ng):
                 cnt = [int((g == gid).sum()) for g in groups]
@@ -119,7 +122,12 @@ def model(shape=(1, 2, 4), list_order="walk", align=None, seed=1, subcell=None):
 if __name__ == "__main__":
     import json
     base = None
-    runs = [dict(), dict(list_order="index"), dict(list_order="mid_first"), dict(list_order="zrel"), dict(align="plane"), dict(align="row"),
+    if len(sys.argv) > 3 and sys.argv[3] == "rest":
+        runs = [dict(), dict(align="plane"), dict(shape=(0, 3, 3)), dict(shape=(1, 2, 3)), dict(shape=(2, 2, 2)), dict(shape=(1, 3, 2))]
+    elif len(sys.argv) > 3 and sys.argv[3] == "groups":
+        runs = [dict(), dict(align=(0, 0, 1, 2, 2)), dict(align=(0, 0, 0, 1, 1)), dict(align=(0, 0, 1, 1, 1)), dict(shape=(1, 3, 2)), dict(shape=(1, 2, 3), align="plane")]
+    else:
+      runs = [dict(), dict(list_order="index"), dict(list_order="mid_first"), dict(list_order="zrel"), dict(align="plane"), dict(align="row"),
             dict(subcell="morton"), dict(shape=(0, 1, 5)), dict(shape=(0, 0, 6)), dict(shape=(1, 1, 5)), dict(shape=(0, 2, 4)), dict(shape=(0, 3, 3)), dict(shape=(1, 2, 3)), dict(shape=(2, 2, 2))]
     for kw in runs:
         r = model(**kw)

@@ -23,14 +23,14 @@ for tgt in (10, late):
     npart, nwave = h[0].sum(), h[2].sum()
     useful_l, useful_s = (h[0] * b).sum(), (h[1] * b).sum()
     lanes_l, lanes_s = 64 * (h[2] * b).sum(), 64 * (h[3] * b).sum()
-    common = 64 * (h[4] * b).sum()
+    lanes_m = 64 * (h[4] * b).sum()
     print("step %d: %d particles, %d waves" % (tgt, npart, nwave))
     print("  liquid blocks/particle mean %.2f; hist %s" % (useful_l / npart, {int(k): int(v) for k, v in zip(b, h[0]) if v}))
     print("  solid  blocks/particle mean %.2f; hist %s" % (useful_s / npart, {int(k): int(v) for k, v in zip(b, h[1]) if v}))
     print("  wave max liquid hist %s" % {int(k): int(v) for k, v in zip(b, h[2]) if v})
     print("  wave max solid  hist %s" % {int(k): int(v) for k, v in zip(b, h[3]) if v})
-    print("  wave T(3/4) liquid hist %s" % {int(k): int(v) for k, v in zip(b, h[4]) if v})
+    print("  wave max (liquid + solid) hist %s" % {int(k): int(v) for k, v in zip(b, h[4]) if v})
     print("  lane-trips (lane = particle): liquid %.3g solid %.3g total %.3g; useful %.3g  -> efficiency %.2f" % (
         lanes_l, lanes_s, lanes_l + lanes_s, useful_l + useful_s, (useful_l + useful_s) / (lanes_l + lanes_s)))
-    print("  liquid: common part (T per wave) %.3g lane-trips + tail %.3g items" % (common, useful_l - np.minimum(0, 0) - 0), flush=True)
+    print("  one trip sequence for both streams (device.h walk()): %.3g lane-trips -> efficiency %.2f" % (lanes_m, (useful_l + useful_s) / lanes_m), flush=True)
 pd.close()

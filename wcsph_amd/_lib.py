@@ -73,7 +73,7 @@ OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_c
          "wcsph_load_state", "wcsph_load_state_split", "wcsph_store_state", "wcsph_get_acc", "wcsph_set_acc", "wcsph_phase", "wcsph_set_part", "wcsph_set_acc_buffer",
          "wcsph_surface_anisotropic_kernel", "wcsph_dfsph_step_fixed", "wcsph_sample_surface", "wcsph_mc_tables",
          "wcsph_mc_setup", "wcsph_mc_surface_value", "wcsph_mc_value_to_host", "wcsph_mc_marching_cube", "wcsph_canvas_draw",
-         "wcsph_set_owned_columns", "wcsph_set_global_liquid", "wcsph_grid_update_begin", "wcsph_grid_update_end", "wcsph_bucket_hist", "wcsph_bucket_hist_pack", "wcsph_bucket_hist_unpack",
+         "wcsph_set_owned_columns", "wcsph_set_global_liquid", "wcsph_grid_update_begin", "wcsph_grid_update_mid", "wcsph_grid_update_end", "wcsph_bucket_hist", "wcsph_bucket_hist_pack", "wcsph_bucket_hist_unpack",
          "wcsph_slab_classify", "wcsph_halo_pack", "wcsph_halo_unpack", "wcsph_slab_set_halo", "wcsph_slab_step", "wcsph_hashgrid_count_to_host", "wcsph_hashgrid_rows_to_host", "wcsph_field_rows_to_host", "wcsph_field_rows_from_host"]
 ALL_SYMBOLS = CTX_ONLY + OTHER
 
@@ -90,7 +90,7 @@ CB_MAXBITS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 class SlabCallbacks(C.Structure):
     _fields_ = [("user", C.c_void_p), ("world", C.c_int32), ("halo_buffers", CB_BUFFERS), ("halo_post", CB_POST),
                 ("halo_wait", CB_WAIT), ("allreduce_acc", CB_ACC), ("allreduce_max", CB_MAX), ("allreduce_words", CB_WORDS),
-                ("allreduce_max_bits", CB_MAXBITS)]
+                ("allreduce_max_bits", CB_MAXBITS), ("allreduce_words_post", CB_WORDS), ("allreduce_words_wait", CB_WAIT)]
 
 
 PHASES = ["DENSITY_COFF", "DRHO_DIV_WARM", "VEL_WARM", "DRHO_DIV_BEGIN", "MAKE_K_DIV", "VEL_ITER", "DRHO_DIV_ITER", "END_DIV",
@@ -160,6 +160,7 @@ def load():
     lib.wcsph_set_owned_columns.argtypes = [vp, C.c_int32, C.c_int32]
     lib.wcsph_set_global_liquid.argtypes = [vp, C.c_int64]
     lib.wcsph_grid_update_begin.argtypes = [vp]
+    lib.wcsph_grid_update_mid.argtypes = [vp]
     lib.wcsph_grid_update_end.argtypes = [vp]
     lib.wcsph_bucket_hist.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.wcsph_bucket_hist_pack.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]

@@ -22,14 +22,16 @@ static int bucket_hist_launches(wcsph_ctx *ctx, hipStream_t s2) {
 // device-scope atomics are 71 of that kernel's 88 us at C3 -- but by k_bucket_hist on the side stream, followed there by the
 // bucket sums, gridCount[hash(cell)] and (once the scan is done) the neighborCount box sums, while this stream scans,
 // sorts and builds the lists: none of those reads the histogram or neighborCount.  grid_end() joins.  What this buys is
-// the holes of the one-block kernels (k_bbox_final, k_scan_bsums: ~21 us of an otherwise idle GPU per step), 1-1.5 % of the
+// the holes of the one-block kernels (k_bbox_final and, until round 4, k_scan_bsums: ~21 us of an otherwise idle GPU per step), 1-1.5 % of the
 // step at C3 -- full-chip kernels of two streams time-slice, they do not add up (forking behind the sort, beside the list
 // build, gains nothing: profiles/r03_experiments.md (21)).  On a slab decomposition the histogram is all-reduced between
 // the two halves and stays where it was.
 static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box);
-static int grid_begin(wcsph_ctx *ctx, bool fork = false) {
+// The update in four parts.  ONE context: assign (fork) -> sort (fork) -> lists -> join.  A slab of a decomposition in faithful
+// mode: assign [+ this rank's share of the bucket histogram] -> the histogram's all-reduce is POSTED -> sort + lists run while it
+// is in flight (they read neither the histogram nor neighborCount) -> the all-reduce is awaited -> counts (wcsph_slab_step).
+static int grid_assign(wcsph_ctx *ctx, bool fork = false) {
   Dev &d = ctx->d;
-  const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
   // ctx->cnt is all zero here: k_scan_final clears the counters it consumes.  The error flags are NOT cleared here: a
   // condition stays on the device until k_publish has handed it to the host once (see pull_scalars)
@@ -54,6 +56,15 @@ static int grid_begin(wcsph_ctx *ctx, bool fork = false) {
     { int rc_ = bucket_hist_launches(ctx, s2); if (rc_) return rc_; }
     neighbor_count_launches(ctx, s2, false);
   }
+  LAUNCHCHK();
+  ctx->grid_stage = 1;
+  return 0;
+}
+// the counting sort: occupied box, exclusive scan of the cell counters, every persistent field to its cell-sorted place
+static int grid_sort(wcsph_ctx *ctx, bool fork = false) {
+  Dev &d = ctx->d;
+  const int nscan = d.ncell_p + 2;
+  hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
@@ -74,6 +85,7 @@ static int grid_begin(wcsph_ctx *ctx, bool fork = false) {
     std::swap(d.oid, ctx->oid_b); std::swap(d.pressure, ctx->pressure_b);
   }
   LAUNCHCHK();
+  ctx->grid_stage = 2;
   return 0;
 }
 // second half: raw neighbour-list length (HashGrid.neighborCount) from the GLOBAL bucket occupancy, compact lists
@@ -94,36 +106,63 @@ static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box) {
     hipLaunchKernelGGL(k_ncount_box, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
   }
 }
-static int grid_end(wcsph_ctx *ctx, bool fork = false) {
+// raw neighbour-list length (HashGrid.neighborCount) on the context's stream (a forked update has them on the side stream)
+static int grid_counts(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
-  hipStream_t s = ctx->stream;
-  if (d.faithful) {
-    if (!fork) { neighbor_count_launches(ctx, s, false); neighbor_count_launches(ctx, s, true); }
-  } else if (d.nl > 0) {
-    hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d);
-  }
-  if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, s, d, 1);
-  if (fork) HIPCHK(hipStreamWaitEvent(s, ctx->ev_side, 0));   // join: whatever follows may read neighborCount and the flags
-  ctx->d.rev ^= 1;
+  if (d.faithful) { neighbor_count_launches(ctx, ctx->stream, false); neighbor_count_launches(ctx, ctx->stream, true); }
+  else if (d.nl > 0) hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, ctx->stream, d);
   LAUNCHCHK();
+  return 0;
+}
+// the compact per-step lists (they read the sorted positions and the cell table, nothing of the bucket histogram)
+static int grid_lists(wcsph_ctx *ctx) {
+  Dev &d = ctx->d;
+  if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, ctx->stream, d, 1);
+  LAUNCHCHK();
+  ctx->grid_stage = 3;
+  return 0;
+}
+static int grid_finish(wcsph_ctx *ctx, bool fork) {
+  if (fork) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));   // join: whatever follows may read neighborCount and the flags
+  ctx->d.rev ^= 1;
   ctx->hist_dirty = false;   // k_bucket_sum / k_ncount_box have left the histogram and the region flags zeroed
   ctx->grid_valid = true;
   ctx->bk_valid = false;
+  ctx->grid_stage = 0;
   return WCSPH_OK;
 }
 int wcsph_grid_update(wcsph_ctx *ctx) {
   NEED_SETUP();
   const bool fork = ctx->d.faithful && ctx->d.nl > 0;
-  int rc = grid_begin(ctx, fork);
-  if (!rc) rc = grid_end(ctx, fork);
+  int rc = grid_assign(ctx, fork);
+  if (!rc) rc = grid_sort(ctx, fork);
+  if (!rc && !fork) rc = grid_counts(ctx);
+  if (!rc) rc = grid_lists(ctx);
+  if (!rc) rc = grid_finish(ctx, fork);
   // an error return after the fork: nothing may stay queued on the side stream that the next update's memsets
   // and launches on the context's stream would race with
   if (rc && fork) (void)hipStreamSynchronize(ctx->side_stream);
   return rc;
 }
 // slab decomposition, faithful neighbour mode: the drivers all-reduce the liquid bucket histogram between the halves
-int wcsph_grid_update_begin(wcsph_ctx *ctx) { NEED_SETUP(); ctx->grid_valid = false; return grid_begin(ctx); }
-int wcsph_grid_update_end(wcsph_ctx *ctx) { NEED_SETUP(); return grid_end(ctx); }
+// begin: cells + this rank's histogram; mid: sort + lists (to be queued while the all-reduce is in flight; optional -- end runs
+// whatever has not run yet); end: neighborCount from the global histogram
+int wcsph_grid_update_begin(wcsph_ctx *ctx) { NEED_SETUP(); ctx->grid_valid = false; return grid_assign(ctx); }
+int wcsph_grid_update_mid(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  if (ctx->grid_stage != 1) return ctx->fail(WCSPH_EARG, "wcsph_grid_update_mid() follows wcsph_grid_update_begin()");
+  int rc = grid_sort(ctx);
+  return rc ? rc : grid_lists(ctx);
+}
+int wcsph_grid_update_end(wcsph_ctx *ctx) {
+  NEED_SETUP();
+  int rc = 0;
+  if (ctx->grid_stage == 0) return ctx->fail(WCSPH_EARG, "wcsph_grid_update_end() without wcsph_grid_update_begin()");
+  if (ctx->grid_stage == 1 && (rc = grid_sort(ctx))) return rc;
+  if ((rc = grid_counts(ctx))) return rc;
+  if (ctx->grid_stage == 2 && (rc = grid_lists(ctx))) return rc;
+  return grid_finish(ctx, false);
+}
 int wcsph_bucket_hist_pack(wcsph_ctx *ctx, void **d_ptr, int64_t *n_words) {   // liquid histogram, two 16-bit counts per word
   NEED_SETUP();
   if (!d_ptr || !n_words) return WCSPH_EARG;
@@ -132,7 +171,7 @@ int wcsph_bucket_hist_pack(wcsph_ctx *ctx, void **d_ptr, int64_t *n_words) {   /
   // per-rank clamp max_in_grid + 1: enough to trip the cap after the sum, and world * (max_in_grid + 1) stays below 2^16
   // for every sane cap (a carry into the neighbouring bucket's half needs max_in_grid > 8190 at 8 ranks)
   const int clamp = ctx->d.max_in_grid + 1 < 0xffff ? ctx->d.max_in_grid + 1 : 0xffff;
-  hipLaunchKernelGGL(k_hist_pack16, dim3(nblk(W)), dim3(BLOCK), 0, ctx->stream, (const int *)ctx->bcount_l, T, ctx->bcount, clamp);   // bcount is rebuilt by grid_end
+  hipLaunchKernelGGL(k_hist_pack16, dim3(nblk(W)), dim3(BLOCK), 0, ctx->stream, (const int *)ctx->bcount_l, T, ctx->bcount, clamp);   // bcount is rebuilt by k_bucket_sum
   LAUNCHCHK();
   *d_ptr = ctx->bcount; *n_words = W;
   return WCSPH_OK;

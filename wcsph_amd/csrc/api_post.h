@@ -250,9 +250,10 @@ __global__ void __launch_bounds__(BLOCK) k_list_stats(Dev d, unsigned long long 
   int ml = nbl, ms = nbs;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { ml = max(ml, __shfl_xor(ml, o, WAVE)); ms = max(ms, __shfl_xor(ms, o, WAVE)); }
-  int T = 0;   // the block count at least 3/4 of the wave's lanes reach
-  for (int t = 1; t <= 63; t++) { if (__popcll(__ballot(nbl >= t)) < (WAVE * 3) / 4) break; T = t; }
-  if ((threadIdx.x & (WAVE - 1)) == 0 && __ballot(own)) { atomicAdd(&hist[128 + ml], 1ull); atomicAdd(&hist[192 + ms], 1ull); atomicAdd(&hist[256 + min(T, 63)], 1ull); }
+  int mt = min(nbl + nbs, 63);   // the trips of the merged walk (device.h walk()): the wave's maximum of liquid + solid blocks
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mt = max(mt, __shfl_xor(mt, o, WAVE));
+  if ((threadIdx.x & (WAVE - 1)) == 0 && __ballot(own)) { atomicAdd(&hist[128 + ml], 1ull); atomicAdd(&hist[192 + ms], 1ull); atomicAdd(&hist[256 + mt], 1ull); }
 }
 int wcsph_list_stats(wcsph_ctx *ctx, int64_t hist[5][64]) {
   NEED_GRID();

@@ -24,7 +24,7 @@ int wcsph_set_global_liquid(wcsph_ctx *ctx, int64_t n_liquid_global) {   // Q5: 
 // halo pack / unpack: several fields of the rows idx[0..n) side by side in one buffer, one launch each way
 static int halo_fields(wcsph_ctx *ctx, int nf, const int32_t *fields, HaloFields *h) {
   if (nf < 1 || nf > 8 || !fields) return ctx->fail(WCSPH_EARG, "halo: 1..8 fields");
-  h->n = nf; h->W = 0;
+  h->n = nf; h->W = 0; h->pred = nullptr;
   for (int k = 0; k < nf; k++) {
     FieldDesc fd = field_desc(ctx, fields[k]);
     if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "halo: vec3 / scalar fields only");
@@ -211,7 +211,7 @@ struct SlabRun {
   bool multi, overlap;
   int ilo, ihi, n_xchg = 0, n_wait = 0;
   HaloFields h;
-  void hf_begin() { h.n = 0; h.W = 0; }
+  void hf_begin() { h.n = 0; h.W = 0; h.pred = nullptr; }
   void hf_add(const void *ptr, int width, int stride) { h.ptr[h.n] = (const float *)ptr; h.width[h.n] = width; h.stride[h.n] = stride; h.W += width; h.n++; }
   // refresh the ghost rows of the fields collected in `h`, then run `launch()`, a neighbour pass that reads them from
   // neighbours j -- overlapped: the pass runs on the slab interior while the exchange is in flight, on the rest once it
@@ -223,6 +223,7 @@ struct SlabRun {
     if (!multi) return has_pass ? launch() : 0;
     void *snd = nullptr, *rcv = nullptr;
     if ((rc = cb->halo_buffers(cb->user, h.W, &snd, &rcv))) return ctx->fail(rc, "slab callback halo_buffers failed");
+    h.pred = ctx->d.pred;   // a speculatively queued refresh packs / unpacks nothing when its predicate is 0 (the exchange itself is unconditional)
     if (ctx->n_halo_send > 0) {
       hipLaunchKernelGGL(k_halo_pack, dim3(nblk(ctx->n_halo_send * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_send, ctx->n_halo_send, (float *)snd);
       LAUNCHCHK();
@@ -234,7 +235,10 @@ struct SlabRun {
     if ((rc = cb->halo_wait(cb->user))) return ctx->fail(rc, "slab callback halo_wait failed");
     if (ctx->n_halo_ghost > 0) {
       hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
-      if (also) hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, *also, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
+      if (also) {
+        HaloFields a2 = *also; a2.pred = ctx->d.pred;
+        hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, a2, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
+      }
       LAUNCHCHK();
     }
     if (!has_pass) return 0;
@@ -252,8 +256,15 @@ struct SlabRun {
 };
 }  // namespace
 extern "C" {
-#define SRC(x) do { if ((rc = (x))) { ctx->d.part_mode = 0; return rc; } } while (0)
+#define SRC(x) do { if ((rc = (x))) { ctx->d.part_mode = 0; ctx->d.pred = nullptr; ctx->d.dtp = nullptr; return rc; } } while (0)
 #define SPASS_(kern, ...) [&]() -> int { PASS(kern, ##__VA_ARGS__); return 0; }
+// deltaT from the GLOBAL velocity maximum on the device: the slab step's k_cfl_store leaves this rank's maximum in
+// flags[FLAG_VMAX], the caller's MAX all-reduce makes it the global one, and this forms the time step (DtRule: the host rule
+// of dfsph.py:113-129 in the same double expressions) for the kernels queued behind it (Dev::dtp)
+__global__ void k_dt_from_vmax(Dev d, DtRule r) {
+  PRED_GATE(d);
+  if (threadIdx.x == 0) { const float dt = dt_rule(r, __int_as_float(d.flags[FLAG_VMAX])); *r.out = dt; d.flags[FLAG_DT] = __float_as_int(dt); }
+}
 int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
                     int32_t flags, int32_t stats[2]) {
   NEED_SETUP();
@@ -262,16 +273,27 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   if (R.multi && (!cb->halo_buffers || !cb->halo_post || !cb->halo_wait || !cb->allreduce_acc || !cb->allreduce_max || !cb->allreduce_words)) return WCSPH_EARG;
   Dev &d = ctx->d;
   int rc;
+  d.pred = nullptr; d.dtp = nullptr;
   const double N = (double)n_global;
   const bool tension = (flags & 2) && !(d.tension == 0.0f && d.tension_b == 0.0f);
   if (tension && ctx->p.tension_fixed == 0 && R.multi) return ctx->fail(WCSPH_EARG, "the literal compute_tension reads the reference's raw bucket rows, which span all slabs: tension_fixed = 1 on a decomposition");
+  // a NaN error sum carried in would make `avg_density_err > err` false, i.e. zero divergence iterations, with every sum that
+  // rides on the last iteration (vorticity) left stale
+  if (!std::isfinite(ctx->avg_density_err)) return ctx->fail(WCSPH_ENONFINITE, "wcsph_slab_step: non-finite avg_density_err carried in");
   auto no_pass = []() -> int { return 0; };
-  // ---- particle_data.hash_grid.update_grid(): with the reference's GLOBAL bucket table in faithful mode (HashGrid.py:108-114)
+  // ---- particle_data.hash_grid.update_grid(): with the reference's GLOBAL bucket table in faithful mode (HashGrid.py:108-114).
+  // The all-reduce of this step's liquid histogram (count / 2 words: 40 MB per rank at C4) is POSTED as soon as the rank's own
+  // share is packed and AWAITED only where neighborCount needs it: the scan, the sort and the list build -- most of the
+  // update's time, reading neither the histogram nor neighborCount -- run while it is in flight.
   if (d.faithful && R.multi) {
     void *words = nullptr; int64_t nw = 0;
     SRC(wcsph_grid_update_begin(ctx));
     SRC(wcsph_bucket_hist_pack(ctx, &words, &nw));
-    if ((rc = cb->allreduce_words(cb->user, words, nw))) return ctx->fail(rc, "slab callback allreduce_words failed");
+    const bool split = cb->allreduce_words_post && cb->allreduce_words_wait;
+    if (split) { if ((rc = cb->allreduce_words_post(cb->user, words, nw))) return ctx->fail(rc, "slab callback allreduce_words_post failed"); }
+    else if ((rc = cb->allreduce_words(cb->user, words, nw))) return ctx->fail(rc, "slab callback allreduce_words failed");
+    SRC(wcsph_grid_update_mid(ctx));
+    if (split && (rc = cb->allreduce_words_wait(cb->user))) return ctx->fail(rc, "slab callback allreduce_words_wait failed");
     SRC(wcsph_bucket_hist_unpack(ctx));
     SRC(wcsph_grid_update_end(ctx));
   } else SRC(wcsph_grid_update(ctx));
@@ -290,115 +312,224 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   }
   ctx->pr_valid = true;                       // (pos, rho) records of every row: own rows by the density pass, ghosts just now
   SRC(SPASS_(k_vel_from_k<1>, (const float4 *)d.pk, ctx->dt)());      // warm-start velocities (dfsph.py:420-439); ghosts' kappa_v arrived above
-  double err = -0.1;
   const float dt = ctx->dt;
   R.hf_begin(); R.hf_add(d.vel, 3, 4);
   SRC(R.xp(true, SPASS_((k_drho_div<DRHO_BEGIN, true>), dt)));
-  const bool vort_div = d.n_owned >= 0;       // the vorticity sums ride on the last divergence iteration (k_drho_div_iter_vort)
-  while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
+
+  // ---- the pieces of the step; every launch honours ctx->d.pred (a gated piece does nothing when its predicate is 0), the
+  // exchanges in between are unconditional: a gated-off exchange moves a stale buffer that nobody unpacks
+  bool vort_taken = false;                    // a k_drho_div_iter_vort ran: the vorticity sums are in d_omega / cg_s
+  auto div_iter = [&]() -> int {              // divergence_iter (dfsph.py:449-477); the vorticity sums ride on it (k_drho_div_iter_vort)
+    int rc;
     R.hf_begin(); R.hf_add((const float *)d.pk + 3, 1, 4);           // k_j = b_j alpha_j, written by the density-change pass
-    SRC(R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dt, d.kappa_v)));
+    if ((rc = R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dt, d.kappa_v)))) return rc;
     R.hf_begin(); R.hf_add(d.vel, 3, 4);
-    if (vort_div) SRC(R.xp(true, SPASS_(k_drho_div_iter_vort, dt)));
-    else SRC(R.xp(true, SPASS_((k_drho_div<DRHO_ITER, true>), dt)));
-    SRC(R.allreduce(ACC_ERR));
-    SRC(R.fetch());
-    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
-    err = 0.001 * N / (double)dt;
-    ctx->dv_iter++;
-  }
-  // ---- compute_nonpressure_force() (dfsph.py:84-103)
-  ELEM(k_end_div_begin_nonpressure, dt, vort_div ? 1 : 0);
-  if (tension) {
-    RPASS(k_tension_normal);
-    R.hf_begin(); R.hf_add(d.normal, 3, 4);
-    SRC(R.xp(true, SPASS_(k_tension_accel)));
-  }
-  R.hf_begin(); R.hf_add(d.vel_guess, 3, 4);
-  if (vort_div) SRC(R.xp(true, SPASS_(k_visc_minv_residual, dt)));
-  else SRC(R.xp(true, SPASS_(k_visc_minv_residual_vort, dt)));
-  SRC(R.allreduce(ACC_DZERO));                  // the first k_visc_update takes delta_zero from the device
-  R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
-  SRC(R.xp(true, SPASS_(k_visc_Ad, dt)));
-  SRC(R.allreduce(ACC_DAD));
-  ELEM(k_visc_update, 0.0f, 1);
-  SRC(R.allreduce(ACC_DNEW));
-  SRC(R.fetch());
-  ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
-  ctx->cg_delta_old = ctx->cg_delta_zero;
-  ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
-  ctx->vs_iter = 1;
-  while (ctx->vs_iter < 100) {
-    if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero || (double)ctx->cg_delta_zero < (double)ctx->p.eps) break;
-    ELEM(k_visc_dir, ctx->cg_delta_old);        // beta = delta' (global, on the device) / delta the last iteration started with
+    if ((rc = R.xp(true, SPASS_(k_drho_div_iter_vort, dt)))) return rc;
+    return R.allreduce(ACC_ERR);
+  };
+  auto visc_open = [&](bool vort) -> int {    // end of solve_vel_divergence + compute_nonpressure_force() up to the sums of its first PCG iteration (dfsph.py:84-97)
+    int rc;
+    ELEM(k_end_div_begin_nonpressure, dt, vort ? 1 : 0);
+    if (tension) {
+      RPASS(k_tension_normal);
+      R.hf_begin(); R.hf_add(d.normal, 3, 4);
+      if ((rc = R.xp(true, SPASS_(k_tension_accel)))) return rc;
+    }
+    R.hf_begin(); R.hf_add(d.vel_guess, 3, 4);
+    if (vort) { if ((rc = R.xp(true, SPASS_(k_visc_minv_residual, dt)))) return rc; }
+    else if ((rc = R.xp(true, SPASS_(k_visc_minv_residual_vort, dt)))) return rc;
+    if ((rc = R.allreduce(ACC_DZERO))) return rc;                     // the first k_visc_update takes delta_zero from the device
     R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
-    SRC(R.xp(true, SPASS_(k_visc_Ad, dt)));
-    SRC(R.allreduce(ACC_DAD));
-    ELEM(k_visc_update, ctx->cg_delta);
-    SRC(R.allreduce(ACC_DNEW));
-    SRC(R.fetch());
-    ctx->cg_delta_old = ctx->cg_delta;
-    ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
-    ctx->vs_iter++;
-  }
-  // end_viscosity + the integration loop of compute_vorticity + the per-particle part of the CFL reduction
+    if ((rc = R.xp(true, SPASS_(k_visc_Ad, dt)))) return rc;
+    if ((rc = R.allreduce(ACC_DAD))) return rc;
+    ELEM(k_visc_update, 0.0f, 1);
+    return R.allreduce(ACC_DNEW);
+  };
   const bool cfl_here = !(d.faithful && d.nl <= 1);
-  if (cfl_here) { ELEM(k_finish_nonpressure, dt); ctx->cfl_done = true; }
-  else { ELEM(k_visc_end, dt); ELEM(k_vorticity_integrate, dt); }
-  // ---- optimize_time_step() (dfsph.py:107-129) on the GLOBAL velocity maximum
-  double vmax;
-  if (R.multi && cb->allreduce_max_bits) {
-    // the maximum over the ranks is formed on the device (a MAX all-reduce of the bit pattern, queued behind k_cfl_store) and
-    // read with the one wait this decision needs anyway.  Every rank makes the call, also one whose reference launches nothing
-    // (dfsph.py:108-111 with a single liquid particle: vel_max[0] keeps its 0)
-    if (d.faithful && d.nl <= 1) HIPCHK(hipMemsetAsync(d.flags + FLAG_VMAX, 0, sizeof(int), ctx->stream));
-    else {
-      if (ctx->cfl_done) ctx->cfl_done = false;   // k_finish_nonpressure already took the per-particle maxima
-      else ELEM(k_cfl, ctx->dt);
+  // end_viscosity + the integration loop of compute_vorticity + this rank's CFL maximum -> flags[FLAG_VMAX], made global by
+  // the caller's MAX all-reduce (device_dt: and the time step formed from it on the device, k_dt_from_vmax)
+  auto cfl_device = [&](bool device_dt) -> int {
+    if (cfl_here) {
+      ELEM(k_finish_nonpressure, dt);
       hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d, DtRule{nullptr, 0.f, 0, 0.0, 0.0, 0.0, 0.0});
+    } else {
+      // (dfsph.py:108-111 with a single liquid particle: the reference launches nothing, vel_max[0] keeps its 0; every rank
+      // still makes the collective call)
+      ELEM(k_visc_end, dt); ELEM(k_vorticity_integrate, dt);
+      HIPCHK(hipMemsetAsync(d.flags + FLAG_VMAX, 0, sizeof(int), ctx->stream));
+    }
+    LAUNCHCHK();
+    int rc;
+    if (R.multi && (rc = cb->allreduce_max_bits(cb->user, d.flags + FLAG_VMAX))) return ctx->fail(rc, "slab callback allreduce_max_bits failed");
+    if (device_dt) {
+      const int it = ctx->pr_iter > 1 ? ctx->pr_iter : 1;            // max(vs_iter = 1 on this branch, last step's pr_iter), Q6
+      hipLaunchKernelGGL(k_dt_from_vmax, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d,
+                         DtRule{ctx->dt_dev, ctx->dt, it, (double)ctx->p.eps, ctx->p.cfl_radius, ctx->p.user_max_t, ctx->p.user_min_t});
       LAUNCHCHK();
     }
-    if ((rc = cb->allreduce_max_bits(cb->user, d.flags + FLAG_VMAX))) return ctx->fail(rc, "slab callback allreduce_max_bits failed");
-    SRC(pull_scalars(ctx));
-    const int bits = ctx->h_flags[FLAG_VMAX];
-    memcpy(&ctx->vel_max0, &bits, 4);
-    R.n_wait++;
-    vmax = (double)ctx->vel_max0;
-  } else {
-    SRC(wcsph_dfsph_cfl_reduce(ctx));
-    R.n_wait++;
-    vmax = (double)ctx->vel_max0;
-    if (R.multi && (rc = cb->allreduce_max(cb->user, &vmax))) return ctx->fail(rc, "slab callback allreduce_max failed");
-  }
-  if ((double)(float)vmax > (double)ctx->p.eps) {
-    double time_step = 0.5 * 0.4 * ctx->p.cfl_radius * 2.0 / sqrt((double)(float)vmax);
-    if (time_step > ctx->p.user_max_t) time_step = ctx->p.user_max_t;
-    if (time_step < ctx->p.user_min_t) time_step = ctx->p.user_min_t;
-    const int it = ctx->vs_iter > ctx->pr_iter ? ctx->vs_iter : ctx->pr_iter;  // max(vs, max(pr, vs)), Q6
-    float d2 = ctx->dt;
-    if (it > 10) d2 = (float)((double)d2 * 0.9);
-    else if (it < 5) d2 = (float)((double)d2 * 1.1);
-    if ((double)d2 > time_step) d2 = (float)time_step;
-    ctx->dt = d2;
-  }
-  const float dtn = ctx->dt;
-  // ---- update_vel(); solve_pressure() (dfsph.py:150-164; the warm start changes no velocity in the reference, Q7)
-  ELEM(k_update_vel_warm_scale, dtn);
-  PASS(k_warm_press_vel, dtn);
-  ctx->pr_iter = 0;
-  err = 0.0;
-  R.hf_begin(); R.hf_add(d.vel, 3, 4);
-  SRC(R.xp(true, SPASS_((k_drho_press<DRHO_BEGIN, true>), dtn)));
-  while ((err > 0.001 || ctx->pr_iter < 2) && ctx->pr_iter < 100) {
+    return 0;
+  };
+  auto press_iter = [&](float dtv) -> int {   // pressure_iter (dfsph.py:518-547)
+    int rc;
     const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
     R.hf_begin(); R.hf_add((const float *)d.pk + 3, 1, 4);
-    SRC(R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dtn, d.kappa)));
+    if ((rc = R.xp(true, SPASS_(k_vel_from_k<0>, (const float4 *)d.pk, dtv, d.kappa)))) return rc;
     R.hf_begin(); R.hf_add(d.vel, 3, 4);
-    SRC(R.xp(true, SPASS_((k_drho_press<DRHO_ITER, true>), dtn)));
+    if ((rc = R.xp(true, SPASS_((k_drho_press<DRHO_ITER, true>), dtv)))) return rc;
     if (prof) { HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream)); ctx->prof_used += 2; }
+    return 0;
+  };
+  auto press_open = [&](float dtv) -> int {   // update_vel(); solve_pressure() up to its first decision (dfsph.py:150-161 forces two iterations; the warm start changes no velocity, Q7)
+    int rc;
+    ELEM(k_update_vel_warm_scale, dtv);
+    PASS(k_warm_press_vel, dtv);
+    R.hf_begin(); R.hf_add(d.vel, 3, 4);
+    if ((rc = R.xp(true, SPASS_((k_drho_press<DRHO_BEGIN, true>), dtv)))) return rc;
+    if ((rc = press_iter(dtv)) || (rc = press_iter(dtv))) return rc;
+    return R.allreduce(ACC_ERR);
+  };
+  auto host_dt_rule = [&](double vmax) {      // optimize_time_step() (dfsph.py:113-129)
+    if ((double)(float)vmax > (double)ctx->p.eps) {
+      double time_step = 0.5 * 0.4 * ctx->p.cfl_radius * 2.0 / sqrt((double)(float)vmax);
+      if (time_step > ctx->p.user_max_t) time_step = ctx->p.user_max_t;
+      if (time_step < ctx->p.user_min_t) time_step = ctx->p.user_min_t;
+      const int it = ctx->vs_iter > ctx->pr_iter ? ctx->vs_iter : ctx->pr_iter;  // max(vs, max(pr, vs)), Q6
+      float d2 = ctx->dt;
+      if (it > 10) d2 = (float)((double)d2 * 0.9);
+      else if (it < 5) d2 = (float)((double)d2 * 1.1);
+      if ((double)d2 > time_step) d2 = (float)time_step;
+      ctx->dt = d2;
+    }
+  };
+
+  // ---- Speculation (as wcsph_dfsph_step): every solver decision is taken ON THE DEVICE by the k_publish that mails
+  // its (all-reduced, hence rank-identical) error sum, and the common-case continuation -- one divergence iteration, one PCG
+  // iteration, two pressure iterations -- is queued behind it in gated segments: [A: divergence] -> [end of it + first PCG
+  // iteration, B] -> [rest of compute_nonpressure_force + CFL + deltaT on the device, C] -> [update_vel + pressure solve up to its
+  // first decision, D] -> [end of step].  The GPU never waits for the host in that case; a decision that falls the other way
+  // leaves the gated launches as no-ops (their exchanges move stale buffers nobody unpacks) and the host goes on from there one
+  // decision at a time.  Needs the device-side MAX all-reduce; the surface-tension passes keep the plain control flow.
+  const double thr_div = 0.001 * N / (double)dt;
+  enum { ST_DIV, ST_VISC, ST_CFL, ST_PRESS, ST_END } stage = ST_DIV;
+  double err = -0.1;
+  const bool spec = (flags & 4) == 0 && ctx->speculate && !tension && cfl_here && (!R.multi || cb->allreduce_max_bits) &&
+                    (double)ctx->avg_density_err > err;
+  float dtn = dt;
+  if (spec) {
+    int *pA = ctx->pred_dev + 1, *pB = ctx->pred_dev + 2, *pD = ctx->pred_dev + 0;
+    SRC(div_iter());
+    SRC(publish_async(ctx, {PRED_DIV, thr_div, 1.0, pA, nullptr}));
+    const unsigned long long seqA = ctx->mail_seq;
+    d.pred = pA;
+    SRC(visc_open(true));
+    d.pred = nullptr;
+    SRC(publish_async(ctx, {PRED_VISC, (double)ctx->p.viscosity_err, (double)ctx->p.eps, pB, pA}));
+    const unsigned long long seqB = ctx->mail_seq;
+    // the host blocks here, the GPU does not: the viscosity walks are queued behind A (profiles/r03_experiments.md (14): queueing
+    // the rest up front costs more than it hides whenever the divergence solve goes on)
+    SRC(collect_mail(ctx, true, seqA));
+    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+    err = thr_div;
+    ctx->dv_iter = 1; vort_taken = true;
+    if (ctx->h_pred) {
+      d.pred = pB;
+      SRC(cfl_device(true));
+      d.pred = nullptr;
+      SRC(publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pB}));
+      const unsigned long long seqC = ctx->mail_seq;
+      const size_t prof_mark = ctx->prof_used;
+      d.pred = pB; d.dtp = ctx->dt_dev;
+      SRC(press_open(dt));
+      d.pred = nullptr; d.dtp = nullptr;
+      SRC(publish_async(ctx, {PRED_PRESS, 0.001, N, pD, pB}));
+      const unsigned long long seqD = ctx->mail_seq;
+      d.pred = pD; d.dtp = ctx->dt_dev;
+      ELEM(k_end_press_update_pos, dt);
+      d.pred = nullptr; d.dtp = nullptr;
+      SRC(collect_mail(ctx, true, seqB));
+      ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
+      ctx->cg_delta_old = ctx->cg_delta_zero;
+      ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+      ctx->vs_iter = 1;
+      if (ctx->h_pred) {
+        SRC(collect_mail(ctx, true, seqC));
+        memcpy(&ctx->vel_max0, &ctx->h_flags[FLAG_VMAX], 4);
+        memcpy(&ctx->dt, &ctx->h_flags[FLAG_DT], 4);       // the device's deltaT is the one the queued kernels ran with: adopted
+        dtn = ctx->dt;
+        SRC(collect_mail(ctx, true, seqD));
+        R.n_wait++;                                          // the one wait of the step: its last mail
+        ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+        err = (double)ctx->avg_density_err / N;
+        ctx->pr_iter = 2;
+        stage = ctx->h_pred ? ST_END : ST_PRESS;             // ST_PRESS: go on from iteration 3
+        if (stage == ST_END) { if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; } return WCSPH_OK; }
+      } else { ctx->prof_used = prof_mark; stage = ST_VISC; R.n_wait++; }   // the PCG goes on; everything behind B did nothing
+    } else { stage = ST_DIV; R.n_wait++; }                   // the divergence solve goes on; everything behind A did nothing
+  }
+  // ---- the plain control flow: one host wait per decision (also where a speculated decision fell the other way)
+  if (stage == ST_DIV) {
+    while ((double)ctx->avg_density_err > err && ctx->dv_iter < 10) {
+      SRC(div_iter());
+      SRC(R.fetch());
+      ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+      err = thr_div;
+      ctx->dv_iter++; vort_taken = true;
+    }
+    // ---- compute_nonpressure_force() (dfsph.py:84-103)
+    SRC(visc_open(vort_taken));
+    SRC(R.fetch());
+    ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
+    ctx->cg_delta_old = ctx->cg_delta_zero;
+    ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+    ctx->vs_iter = 1;
+    stage = ST_VISC;
+  }
+  if (stage == ST_VISC) {
+    while (ctx->vs_iter < 100) {
+      if ((double)ctx->cg_delta <= (double)ctx->p.viscosity_err * (double)ctx->cg_delta_zero || (double)ctx->cg_delta_zero < (double)ctx->p.eps) break;
+      ELEM(k_visc_dir, ctx->cg_delta_old);        // beta = delta' (global, on the device) / delta the last iteration started with
+      R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
+      SRC(R.xp(true, SPASS_(k_visc_Ad, dt)));
+      SRC(R.allreduce(ACC_DAD));
+      ELEM(k_visc_update, ctx->cg_delta);
+      SRC(R.allreduce(ACC_DNEW));
+      SRC(R.fetch());
+      ctx->cg_delta_old = ctx->cg_delta;
+      ctx->cg_delta = (float)ctx->h_acc[ACC_DNEW];
+      ctx->vs_iter++;
+    }
+    // ---- optimize_time_step() (dfsph.py:107-129) on the GLOBAL velocity maximum
+    double vmax;
+    if (R.multi && cb->allreduce_max_bits) {
+      // the maximum over the ranks is formed on the device (a MAX all-reduce of the bit pattern, queued behind k_cfl_store) and
+      // read with the one wait this decision needs anyway
+      SRC(cfl_device(false));
+      SRC(pull_scalars(ctx));
+      memcpy(&ctx->vel_max0, &ctx->h_flags[FLAG_VMAX], 4);
+      R.n_wait++;
+      vmax = (double)ctx->vel_max0;
+    } else {
+      if (cfl_here) { ELEM(k_finish_nonpressure, dt); ctx->cfl_done = true; }
+      else { ELEM(k_visc_end, dt); ELEM(k_vorticity_integrate, dt); }
+      SRC(wcsph_dfsph_cfl_reduce(ctx));
+      R.n_wait++;
+      vmax = (double)ctx->vel_max0;
+      if (R.multi && (rc = cb->allreduce_max(cb->user, &vmax))) return ctx->fail(rc, "slab callback allreduce_max failed");
+    }
+    host_dt_rule(vmax);
+    dtn = ctx->dt;
+    SRC(press_open(dtn));
+    SRC(R.fetch());
+    ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];
+    err = (double)ctx->avg_density_err / N;
+    ctx->pr_iter = 2;
+    stage = ST_PRESS;
+  }
+  // ---- solve_pressure() from its third iteration on (dfsph.py:160-163)
+  while (err > 0.001 && ctx->pr_iter < 100) {
+    SRC(press_iter(dtn));
     ctx->pr_iter++;
-    if (ctx->pr_iter < 2) { err = 1.0; continue; }   // `pr_iter < 2` forces the second iteration whatever the first reports
     SRC(R.allreduce(ACC_ERR));
     SRC(R.fetch());
     ctx->avg_density_err = (float)ctx->h_acc[ACC_ERR];

@@ -229,7 +229,7 @@ __global__ void k_scatter_solid(Dev d, const float4 *pos, float4 *spos, const in
   spos[dst] = p;
 }
 
-// ---- exclusive scan over the cell counters (3 launches, 2048 elements per block) ----------
+// ---- exclusive scan over the cell counters (two launches, 2048 elements per block) ----------
 #define SCAN_PER_THREAD 8
 #define SCAN_TILE (BLOCK * SCAN_PER_THREAD)
 __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
@@ -276,6 +276,19 @@ __device__ __forceinline__ bool scan_block_active(const Dev &d, const int *bbox,
   }
   return __syncthreads_or(need) != 0;
 }
+// every thread of the block must call this; returns the block's total to every thread
+__device__ __forceinline__ int block_sum(int v) {
+  __shared__ int ws[BLOCK / WAVE];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  __syncthreads();   // (the previous user of ws, if any, is done)
+  if ((threadIdx.x & (WAVE - 1)) == 0) ws[threadIdx.x / WAVE] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int k = 0; k < BLOCK / WAVE; k++) t += ws[k];
+  return t;
+}
 __global__ void k_scan_reduce(Dev d, const int *in, int n, int *bsum, const int *bbox) {
   if (!scan_block_active(d, bbox, n)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
@@ -286,14 +299,10 @@ __global__ void k_scan_reduce(Dev d, const int *in, int n, int *bsum, const int 
   block_exclusive_scan(s, &tot);
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ void k_scan_bsums(int *bsum, int nb) {  // one block: every thread owns a contiguous chunk of the block sums
-  const int per = (nb + BLOCK - 1) / BLOCK, b = threadIdx.x * per, e = min(b + per, nb);
-  int s = 0;
-  for (int k = b; k < e; k++) s += bsum[k];
-  int tot;
-  int run = block_exclusive_scan(s, &tot);
-  for (int k = b; k < e; k++) { const int v = bsum[k]; bsum[k] = run; run += v; }
-}
+// (rounds 1-3 scanned the block sums in a one-block launch of their own, 14 us + two dependent dispatch gaps; since round 4 every
+// ACTIVE block of k_scan_final sums the block totals before it itself: <= 32 KB of coalesced, L2-resident reads per block, all
+// of a thread's loads in flight at once -- cheaper than the launch it replaces, and a block outside the occupied box skips it.
+// The one-launch alternative, decoupled look-back, lost: profiles/r04_experiments.md (3))
 // clear != 0: the counters are zeroed as they are consumed, so the next grid update needs no 65 MB memset (only
 // cells of the active blocks can be non-zero: every counted particle lies inside the occupied box or in the last bin)
 __global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, const int *bbox, int clear) {
@@ -306,8 +315,12 @@ __global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, c
     s += v[k];
     if (clear && v[k] != 0) in[base + k] = 0;
   }
+  // the sum of the block totals before this block (bsum: raw totals, k_scan_reduce)
+  int before = 0;
+  for (int k = threadIdx.x; k < (int)blockIdx.x; k += BLOCK) before += bsum[k];
   int tot;
-  int ex = block_exclusive_scan(s, &tot) + bsum[blockIdx.x];
+  int ex = block_exclusive_scan(s, &tot);
+  ex += block_sum(before);
 #pragma unroll
   for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
 }
@@ -683,8 +696,9 @@ __global__ void __launch_bounds__(BLOCK) k_slab_classify(const float *rows, long
 }
 
 // halo pack / unpack of SEVERAL fields in one launch: out[k][W] = the listed fields of original row idx[k], side by side
-struct HaloFields { int n; const float *ptr[8]; int width[8], stride[8]; int W; };
+struct HaloFields { int n; const float *ptr[8]; int width[8], stride[8]; int W; const int *pred; };   // pred: as Dev::pred (speculative slab step)
 __global__ void k_halo_pack(HaloFields h, const int *where, const int *idx, int n, float *out) {
+  if (h.pred && *h.pred == 0) return;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * h.W) return;
   const int k = t / h.W;
@@ -693,6 +707,7 @@ __global__ void k_halo_pack(HaloFields h, const int *where, const int *idx, int 
   out[t] = h.ptr[f][(size_t)where[idx[k]] * h.stride[f] + c];
 }
 __global__ void k_halo_unpack(HaloFields h, const int *where, const int *idx, int n, const float *in) {
+  if (h.pred && *h.pred == 0) return;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * h.W) return;
   const int k = t / h.W;

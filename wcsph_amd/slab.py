@@ -218,7 +218,7 @@ class HipBackend:
         self._chk(lib.wcsph_set_scalar(ctx, _lib.SCALAR_ID["avg_density_err"], float(sim.avg_density_err)))
         self._chk(lib.wcsph_set_iters(ctx, int(sim.vs_iter), int(sim.dv_iter), int(sim.pr_iter)))
         stats = (C.c_int32 * 2)()
-        flags = (1 if sim.overlap else 0) | (2 if sim.tension else 0)
+        flags = (1 if sim.overlap else 0) | (2 if sim.tension else 0) | (0 if sim.speculate else 4)
         sim._cb_exc = None
         rc = lib.wcsph_slab_step(ctx, C.byref(self._cbs), int(sim.n_global), int(max(sim.interior[0], -(1 << 30))),
                                  int(min(sim.interior[1], 1 << 30)), flags, C.byref(stats))
@@ -310,6 +310,10 @@ class SlabSim:
         # WCSPH_SLAB_NATIVE=0: drive the step phase by phase from Python (the form the checker backend of the CPU tests
         # runs, kept in step with wcsph_slab_step by tests/test_gpu_slab.py)
         self.native = os.environ.get("WCSPH_SLAB_NATIVE", "1") != "0"
+        # the native step queues the common-case continuation behind every solver decision (wcsph_slab_step); False: one host
+        # wait per decision (tests compare the two)
+        self.speculate = os.environ.get("WCSPH_SLAB_SPECULATE", "1") != "0"
+        self._words_work = None
         self._cb_exc = None
 
     def _set_cuts(self, cuts):
@@ -567,12 +571,29 @@ class SlabSim:
         def maxbits(_u, ptr):     # the CFL maximum as an int32 bit pattern on the device: no host value, no extra wait
             self._allreduce_tensor(torch.as_tensor(_DevArray(ptr, 1), device=self.device), dist.ReduceOp.MAX)
 
+        def words_post(_u, ptr, n):
+            # the bucket histogram's all-reduce, started here and awaited in words_wait: with RCCL it runs on the process
+            # group's own stream, ordered behind what the context's stream holds NOW (the packed histogram), while the
+            # library queues the scan, the sort and the list build.  Host-staged (gloo) runs have nothing to overlap with.
+            t = torch.as_tensor(_DevArray(ptr, n), device=self.device)
+            if self.comm_device != self.device:
+                self._allreduce_tensor(t)
+                self._words_work = None
+            else:
+                self._words_work = (dist.all_reduce(t, group=self.group, async_op=True), t)
+
+        def words_wait(_u):
+            if self._words_work is not None:
+                self._words_work[0].wait()          # the current (= the context's) stream waits; the host does not
+                self._words_work = None
+
         cb = _lib.SlabCallbacks()
         cb.user, cb.world = None, int(self.world)
         self._cb_keep = [_lib.CB_BUFFERS(guard(buffers)), _lib.CB_POST(guard(post)), _lib.CB_WAIT(guard(wait)),
-                         _lib.CB_ACC(guard(acc)), _lib.CB_MAX(guard(vmax)), _lib.CB_WORDS(guard(words)), _lib.CB_MAXBITS(guard(maxbits))]
+                         _lib.CB_ACC(guard(acc)), _lib.CB_MAX(guard(vmax)), _lib.CB_WORDS(guard(words)), _lib.CB_MAXBITS(guard(maxbits)),
+                         _lib.CB_WORDS(guard(words_post)), _lib.CB_WAIT(guard(words_wait))]
         (cb.halo_buffers, cb.halo_post, cb.halo_wait, cb.allreduce_acc, cb.allreduce_max, cb.allreduce_words,
-         cb.allreduce_max_bits) = self._cb_keep
+         cb.allreduce_max_bits, cb.allreduce_words_post, cb.allreduce_words_wait) = self._cb_keep
         return cb
 
     def allsum(self, v): return self._allreduce(v, dist.ReduceOp.SUM)   # noqa: E704
@@ -778,7 +799,7 @@ class SlabSim:
             B.grid_update_begin()
             self._allreduce_tensor(B.bucket_hist_packed())     # two 16-bit counts per int32 word: count/2 words on the wire
             B.bucket_hist_unpack()
-            B.grid_update_end()
+            B.grid_update_end()                                 # (runs the sort and the list build too: no explicit _mid here)
         else:
             B.grid_update()                               # particle_data.hash_grid.update_grid()
         # compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146), which
