@@ -37,6 +37,10 @@ def _close(name, a, b, tol=RTOL, floor=1e-30):
     assert err < tol, "%s: rel err %.3e (tol %.1e)" % (name, err, tol)
 
 
+def _scaled_close(K):
+    return lambda name, a, b, tol=RTOL, floor=1e-30: _close(name, a, b, tol * K, floor)
+
+
 def _row_hashes(rows, counts):
     """as tests/golden/make_reference_fixtures.py row_hashes: per row the sum, the xor and an ORDER-SENSITIVE polynomial hash
     (uint64 wrap-around: h = h * 1000003 + (j + 1)) of the entries 0 .. count-1"""
@@ -72,10 +76,32 @@ def _oracle_dfsph(f):
     return o
 
 
-@pytest.mark.parametrize("fixture", ["ref_dfsph_default_scene.npz", "ref_dfsph_perturbed_default_scene.npz"])
+# ref_dfsph_squeezed (round 4): the perturbed state with the particles of original index >= 4400 compressed to 0.9 of their
+# spacing, THREE steps.  pr_iter = 5, 2, 2 and dv_iter = 1, 6, 2: the dt rule's reading of LAST step's pr_iter (Q6) and the CFL
+# tree's prefix (Q5: original indices [0, 4096) -- the calm half) are visible in deltaT: 0.0011, 0.0011 (kept: it = 5), 0.00121.
+DFSPH_FIXTURES = ["ref_dfsph_default_scene.npz", "ref_dfsph_perturbed_default_scene.npz", "ref_dfsph_squeezed_default_scene.npz"]
+
+
+def test_squeezed_fixture_shows_q5_and_q6():
+    f = _load("ref_dfsph_squeezed_default_scene.npz")
+    assert [int(f["s%d_pressure_pr_iter" % s]) for s in range(3)] == [5, 2, 2]
+    assert [int(f["s%d_divergence_dv_iter" % s]) for s in range(3)] == [1, 6, 2]
+    dts = [float(f["s%d_dt_deltaT" % s][0]) for s in range(3)]
+    assert abs(dts[0] - 0.0011) < 1e-8 and abs(dts[1] - dts[0]) < 1e-9 and abs(dts[2] - dts[1] * 1.1) < 1e-8      # Q6: step 1 keeps dt
+    # Q5: the velocity maximum the rule saw (prefix of the original order) is far below the true one, which would have capped dt
+    v_seen = float(f["s1_dt_vel_max0"][0])
+    v_true = float((f["s1_divergence_vel"].astype(np.float64) ** 2).sum(1).max())
+    assert v_seen < 100.0 < v_true and 0.5 * 0.4 * 0.025 * 2.0 / np.sqrt(v_true) < dts[1]
+
+
+@pytest.mark.parametrize("fixture", DFSPH_FIXTURES)
 def test_oracle_reproduces_the_reference_text_dfsph(fixture):
     f = _load(fixture)
     o = _oracle_dfsph(f)
+    # the squeezed state iterates (six divergence, five pressure iterations on densities up to 1.3 rho0): summation-order
+    # differences of the f32 neighbour sums are amplified by the solvers; still well inside the north star's 1e-4
+    K = 4.0 if "squeezed" in fixture else 1.0
+    _close = _scaled_close(K)
     assert tuple(f["blockSize"]) == o.blockSize == (41, 41, 41)
     assert (int(f["n_liquid"]), int(f["n_solid"])) == (8000, 25387)
     for s in range(int(f["steps"])):
@@ -130,12 +156,14 @@ def test_oracle_reproduces_the_reference_text_sesph():
 
 # ---- the HIP library (GPU) --------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", ["ref_dfsph_default_scene.npz", "ref_dfsph_perturbed_default_scene.npz"])
+@pytest.mark.parametrize("fixture", DFSPH_FIXTURES)
 def test_hip_reproduces_the_reference_text_dfsph(fixture):
     """the reference main-loop text (dfsph.py:606-617) through wcsph_amd.dfsph, stage by stage, vs the fixture"""
     from wcsph_amd import dfsph
     f = _load(fixture)
     nl = int(f["n_liquid"])
+    K = 4.0 if "squeezed" in fixture else 1.0          # (as in the oracle test above)
+    _close = _scaled_close(K)
     pd = dfsph.init_particle(particleDim=20, neighbor_mode="faithful", liquid=f["pos0"][:nl].astype(np.float64),
                              boundary=f["pos0"][nl:].astype(np.float64),
                              **({"tension_coff": float(f["tension_coff"]), "tension_coff_b": float(f["tension_coff_b"])} if "vel0" in f.files else {}))
@@ -176,10 +204,14 @@ def test_hip_reproduces_the_reference_text_dfsph(fixture):
 
 
 @pytest.mark.gpu
-def test_hip_fused_step_reproduces_the_reference_text():
-    """the same two steps through the fused library step (wcsph_dfsph_step): end-of-step fields and iteration counts"""
+@pytest.mark.parametrize("fixture", ["ref_dfsph_perturbed_default_scene.npz", "ref_dfsph_squeezed_default_scene.npz"])
+def test_hip_fused_step_reproduces_the_reference_text(fixture):
+    """the same steps through the fused library step (wcsph_dfsph_step): end-of-step fields and iteration counts.  The squeezed
+    fixture takes every branch of the speculative control flow: the divergence solve goes on after its first iteration
+    (dv_iter = 6, 2), the pressure solve after its second (pr_iter = 5), and the dt rule reads last step's pr_iter (Q6)"""
     from wcsph_amd import dfsph
-    f = _load("ref_dfsph_perturbed_default_scene.npz")
+    f = _load(fixture)
+    _close = _scaled_close(4.0 if "squeezed" in fixture else 1.0)
     nl = int(f["n_liquid"])
     pd = dfsph.init_particle(particleDim=20, neighbor_mode="faithful", liquid=f["pos0"][:nl].astype(np.float64), boundary=f["pos0"][nl:].astype(np.float64),
                              tension_coff=float(f["tension_coff"]), tension_coff_b=float(f["tension_coff_b"]))
