@@ -12,7 +12,7 @@ Rank 0 prints ONE JSON line: M particle-steps/s for the whole job, plus
                   HIP events on the context's stream, algorithmic bytes (84 + 24 s) B per liquid particle
                    over the 8 TB/s HBM peak,
   "cpu_baseline": the reference-algorithm CPU restatement (oracle/, faithful mode, OpenMP, gcc -O3
-                  -march=native) timed on this box's host cores on the SAME configuration (C3), 2 steps.
+                  -march=native) timed on this box's host cores on the SAME configuration (C3), 5 steps.
 `value` is the configuration's first steps (the column still at rest: the cheapest state of a dam break);
 config.developed_flow reports the same measurement after 1200 steps (collapsed, splashing).
 """
@@ -54,13 +54,10 @@ def kernel_source_sha16():
 
 
 # ---- HBM traffic of the north-star kernel pair, measured in THIS run -------------------------------------------------------
-def measure_traffic_live(n, mode, timeout=240):
-    """FETCH_SIZE and WRITE_SIZE of k_vel_from_k + k_drho_press<ITER> per launch, each counter in its OWN child
-    `rocprofv3 --pmc <counter> --kernel-trace` run of tools/run_kernel_group.py (the profiler cannot attach to this process;
-    separate passes and no other trace domain, as MI355X_MICROARCH.md "HBM" / "rocprofv3" prescribes).  Bytes per
-    pressure_iter launch = 2 x FETCH_SIZE (gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads; WRITE_SIZE is
-    taken as is, uncalibrated) in KB per dispatch.
-    Returns (bytes, note) or (None, reason)."""
+def _pmc_passes(n, mode, counters, timeout=240):
+    """one child `rocprofv3 --pmc <counter> --kernel-trace` run of tools/run_kernel_group.py per counter (the profiler cannot attach
+    to this process; separate passes and no other trace domain, as MI355X_MICROARCH.md "HBM" / "rocprofv3" prescribes).
+    Returns ({counter: {kernel: average value per dispatch}}, None) or (None, reason)."""
     import glob
     import shutil
     import sqlite3
@@ -69,33 +66,73 @@ def measure_traffic_live(n, mode, timeout=240):
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="wcsph_pmc_", dir="/tmp")
-    kb = {}
+    vals = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--kernel-include-regex", "k_vel_from_k|k_drho_press", "-d", out, "-o", "pmc",
+        for group in counters:          # one rocprofv3 run per group (counters of one group share a pass)
+            out = os.path.join(tmp, group.split()[0])
+            cmd = [rocprof, "--pmc"] + group.split() + ["--kernel-trace", "--kernel-include-regex", "k_vel_from_k|k_drho_press", "-d", out, "-o", "pmc",
                    "--", sys.executable, os.path.join(ROOT, "tools", "run_kernel_group.py"), "pressure_iter", "10", str(n), mode]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
             except subprocess.TimeoutExpired:
-                return None, "rocprofv3 --pmc %s timed out" % counter
+                return None, "rocprofv3 --pmc %s timed out" % group
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
-                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
-            tot = 0.0
-            for kern in ("k_vel_from_k", "k_drho_press"):
-                rows = list(sqlite3.connect(dbs[0]).execute(
-                    "select avg(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", ("%" + kern + "%", counter)))
-                if not rows or rows[0][0] is None or rows[0][1] < 4:
-                    return None, "no %s samples for %s" % (counter, kern)
-                tot += float(rows[0][0])
-            kb[counter] = tot
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (group, r.returncode)
+            for counter in group.split():
+                vals[counter] = {}
+                for kern in ("k_vel_from_k", "k_drho_press"):
+                    rows = list(sqlite3.connect(dbs[0]).execute(
+                        "select avg(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", ("%" + kern + "%", counter)))
+                    if not rows or rows[0][0] is None or rows[0][1] < 4:
+                        return None, "no %s samples for %s" % (counter, kern)
+                    vals[counter][kern] = float(rows[0][0])
     except Exception as e:   # profiling is best effort: the bench line must come out
         return None, "live PMC pass failed: %r" % (e,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over "
-                                                                      "k_vel_from_k + k_drho_press<ITER>; 2 x FETCH + WRITE, KB per dispatch")
+    return vals, None
+
+
+TRAFFIC_NOTE = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over k_vel_from_k + "
+                "k_drho_press<ITER>; 2 x FETCH + WRITE, KB per dispatch.  The guide's x2 FETCH_SIZE correction is calibrated for wide "
+                "coalesced streams; for 16-byte GATHERS it is uncalibrated, so this is an UPPER bound (x1 would give ~0.6 of it), and "
+                "hits in the 256 MB Infinity Cache are counted: traffic_frac bounds the HBM-side rate from above, it does not measure it")
+
+
+def measure_traffic_live(n, mode, timeout=240):
+    """FETCH_SIZE and WRITE_SIZE of k_vel_from_k + k_drho_press<ITER> per launch.  Bytes per pressure_iter launch =
+    2 x FETCH_SIZE (gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads; WRITE_SIZE is taken as is) in KB per
+    dispatch.  Returns (bytes, note) or (None, reason)."""
+    vals, why = _pmc_passes(n, mode, ("FETCH_SIZE", "WRITE_SIZE"), timeout)
+    if vals is None:
+        return None, why
+    kb = {c: sum(vals[c].values()) for c in vals}
+    return int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), TRAFFIC_NOTE
+
+
+# measured on this architecture with tools/micro/valu_rate.hip and tools/micro/gather_rate.hip (profiles/r03i_gather_rate.txt)
+VALU_RATE_G = 1035.0          # G wave-instructions / s, whole chip
+GATHER_CYCLES = 16.2          # CU-cycles per 64-lane gather of 8..16-byte records that all hit the L1
+N_CU, CLOCK_GHZ = 256, 2.4
+
+
+def measure_pipes_live(n, mode, timeout=240):
+    """What the pair is bound by, next to the HBM fraction: VALU time from SQ_INSTS_VALU at the measured issue
+    rate, the vector memory pipeline's floor from the gather instruction count (16.2 CU-cycles each whatever the lanes do), and the
+    vector-L1 tag look-ups per gather instruction (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD: 16 would be ideal for 64 x 16 B)."""
+    vals, why = _pmc_passes(n, mode, ("SQ_INSTS_VALU SQ_INSTS_VMEM_RD", "TCP_TOTAL_CACHE_ACCESSES"), timeout)
+    if vals is None:
+        return {"note": why}
+    valu = sum(vals["SQ_INSTS_VALU"].values())
+    vmem = sum(vals["SQ_INSTS_VMEM_RD"].values())
+    tcp = sum(vals["TCP_TOTAL_CACHE_ACCESSES"].values())
+    return {"valu_us": round(valu / (VALU_RATE_G * 1e9) * 1e6, 1), "valu_wave_instructions": int(valu),
+            "gather_floor_us": round(vmem * GATHER_CYCLES / (N_CU * CLOCK_GHZ * 1e9) * 1e6, 1), "vmem_read_wave_instructions": int(vmem),
+            "l1_lines_per_gather": round(tcp / max(vmem, 1.0), 1), "l1_lookup_us": round(tcp / (N_CU * CLOCK_GHZ * 1e9) * 1e6, 1),
+            "note": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_VMEM_RD / TCP_TOTAL_CACHE_ACCESSES, separate passes, per pressure_iter launch (both kernels); "
+                    "valu_us at %.0f G wave-instr/s (tools/micro/valu_rate.hip), gather_floor_us = VMEM reads x %.1f CU-cycles / (%d CUs x %.1f GHz), "
+                    "l1_lookup_us = one tag look-up per clock and CU" % (VALU_RATE_G, GATHER_CYCLES, N_CU, CLOCK_GHZ)}
 
 
 # ---- CPU baseline (child process: the baseline build of the oracle, its own 17 GB of tables) -------------------------
@@ -156,7 +193,7 @@ def cpu_baseline(n_main, n_small):
     """Reference-algorithm CPU restatement (oracle/wcsph_ref.c, faithful mode, gcc -O3 -march=native -fopenmp, built on
     this host) on the headline configuration; the C2-size sample of round 1 and a 1-thread figure ride along."""
     nthreads = os.cpu_count() or 1
-    main = _run_cpu_child(n_main, 2, [nthreads, nthreads // 2, nthreads // 4], False, 900)
+    main = _run_cpu_child(n_main, 5, [nthreads, nthreads // 2, nthreads // 4], False, 1200)
     small = _run_cpu_child(n_small, 10, [nthreads, 64, 32, 16], True, 300)
     if "error" in main:
         return {"value": None, "unit": "M particle-steps/s", "cores": 0, "kind": "port", "sample": "failed: " + main["error"], "c2_sample": small}
@@ -230,9 +267,17 @@ def _main():
     if world > 1:
         from wcsph_amd import slab
         out = slab.bench_main(args)
-        if out is not None and not args.no_cpu:     # rank 0, after the process group is gone: the same CPU leg as at N = 1
+        if out is not None:                         # rank 0, after the process group is gone
             from wcsph_amd import scene
-            out["cpu_baseline"] = cpu_baseline(scene.CONFIGS.get(args.config) or int(args.config), args.cpu_n)
+            n_base = scene.CONFIGS.get(args.config) or int(args.config)
+            if not args.no_pmc:
+                # HBM-side traffic of the kernel pair on ONE GPU's load (the per-GPU configuration of this weak-scaling run as a
+                # single context on rank 0's GPU; the profiler cannot attach to the ranks)
+                traffic, note = measure_traffic_live(n_base, args.mode)
+                out["roofline"]["traffic"] = traffic
+                out["roofline"]["traffic_source"] = note + " -- taken on one GPU's load (%d^3 particles as a single context), not inside the %d-rank run" % (n_base, world)
+            if not args.no_cpu:                     # the same CPU leg as at N = 1
+                out["cpu_baseline"] = cpu_baseline(n_base, args.cpu_n)
         return out
 
     import __graft_entry__ as g
@@ -276,6 +321,7 @@ def _main():
                 traffic, traffic_note = t.get("pressure_iter_bytes_per_launch"), "%s (recorded; live pass: %s)" % (t.get("source"), traffic_note)
         except Exception:
             pass
+    pipes = {"note": "skipped (--no-pmc)"} if args.no_pmc else measure_pipes_live(n, args.mode)
     it = r["iters"]
     out = {
         "metric": "M particle-steps/sec, DFSPH dam-break", "value": round(value, 3), "unit": "M particle-steps/s",
@@ -294,9 +340,23 @@ def _main():
                      "traffic_frac": (round(traffic / (r["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                      "avg_launch_us": round(r["launch_ms"] * 1e3, 1), "launches_timed": r["launches"],
                      "timing": "HIP events around every launch group inside the timed steps", "replay_us": round(ms_replay.value * 1e3, 1),
-                     "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_source_sha16": kernel_source_sha16(), "other_kernels": extra},
+                     "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_source_sha16": kernel_source_sha16(), "other_kernels": extra,
+                     # what the pair actually runs at (it is not HBM-bound: DESIGN.md 4): VALU time, the vector memory pipeline's
+                     # instruction floor and its L1 tag look-ups, per launch, measured in this run
+                     "valu_us": pipes.get("valu_us"), "gather_floor_us": pipes.get("gather_floor_us"), "l1_lines_per_gather": pipes.get("l1_lines_per_gather"),
+                     "l1_lookup_us": pipes.get("l1_lookup_us"), "pipes": pipes},
     }
     pd.close()
+    if (args.warmup, args.steps) != (20, 100):
+        # SURVEY 8(d)'s own window -- 20 warm-up + 100 timed steps from rest -- beside whatever window this run was asked for: the
+        # column starts to collapse inside it (lists grow, neighbourhoods lose their lattice order)
+        dfw, pdw, _ = build_sim(n, args.mode)
+        rw = timed_steps(dfw, pdw, 20, 100, tsync, profile=True)
+        out["config"]["default_window"] = dict(leg(nl, rw, 100), warmup=20, steps=100, state="steps 21..120 from rest",
+                                               mean_iters={"vs": round(rw["iters"][:, 0].mean(), 2), "dv": round(rw["iters"][:, 1].mean(), 2), "pr": round(rw["iters"][:, 2].mean(), 2)},
+                                               pressure_iter_us=round(rw["launch_ms"] * 1e3, 1),
+                                               pressure_iter_frac=round(alg_bytes / (rw["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        pdw.close()
     if not args.no_developed:
         # the same workload after the column has collapsed (t ~ 1.1 s): longer lists, disordered neighbourhoods, a grid
         # box that spans the whole domain -- what a production run spends its time in
