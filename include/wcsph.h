@@ -112,6 +112,11 @@ int wcsph_device_count(void);
 int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const float *minb);
 int wcsph_get_block_size(wcsph_ctx *ctx, int32_t bs[3]);
 
+/* Field transfer in the caller's ORIGINAL particle order (ref: field.to_numpy() / from_numpy(), dfsph.py:113,129,141,162).
+ * A transfer to the host is a SYNCHRONISATION POINT: error conditions raised on the device since the last one (bucket / list
+ * overflow: -3 / -4, non-finite position: -5; sticky on the device until handed over once) are reported by ITS return code -- the
+ * data is delivered either way, the code says whether such a condition arose while it was produced.  A caller that keeps
+ * stepping after a non-zero return does what the reference does after its in-kernel `print` (HashGrid.py:73,103). */
 int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes);
 int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes);
 /* rows [i0, i0+n) of a liquid field, original order: Python-scope element access `f[i]` / `f[i] = v`
