@@ -87,23 +87,46 @@ def model(shape=(1, 2, 4), list_order="walk", align=None, seed=1, subcell=None):
             groups = []
             for l, x in enumerate(lists):
                 i = idx[l]
-                if isinstance(align, tuple):     # a partition of the five outer planes: align[d + 2] = group of plane offset d
+                if align == "plane16":
+                    g = co[x] - co[i] + 2
+                elif isinstance(align, tuple):     # a partition of the five outer planes: align[d + 2] = group of plane offset d
                     g = np.array(align)[co[x] - co[i] + 2]
                 else:
                     g = (co[x] - co[i] + 2) * (5 if align == "row" else 1) + ((cm[x] - cm[i] + 2) if align == "row" else 0)
                 groups.append(g)
             ng = (max(align) + 1) if isinstance(align, tuple) else (25 if align == "row" else 5)
-            cols = []
-            for gid in range(ng):
-                cnt = [int((g == gid).sum()) for g in groups]
-                m = max(cnt)
-                B = np.full((64, m), -1, np.int64)
-                for l, x in enumerate(lists):
-                    sel = x[groups[l] == gid]
-                    B[l, :len(sel)] = sel
-                cols.append(B)
-            A = np.concatenate(cols, 1)
-            kmax = A.shape[1]
+            if align == "plane16":
+                # alignment inside each 16-lane brick row only (a gather's coherence is a matter of the lanes that address one
+                # source row): a group pads to ITS maximum per plane, the wave runs as many slots as its longest group
+                parts = []
+                for q in range(4):
+                    cols = []
+                    for gid in range(5):
+                        cnt = [int((groups[l] == gid).sum()) for l in range(16 * q, 16 * q + 16)]
+                        m = max(cnt)
+                        B = np.full((16, m), -1, np.int64)
+                        for l in range(16):
+                            x = lists[16 * q + l]
+                            sel = x[groups[16 * q + l] == gid]
+                            B[l, :len(sel)] = sel
+                        cols.append(B)
+                    parts.append(np.concatenate(cols, 1))
+                kmax = max(p_.shape[1] for p_ in parts)
+                A = np.full((64, kmax), -1, np.int64)
+                for q, p_ in enumerate(parts):
+                    A[16 * q:16 * q + 16, :p_.shape[1]] = p_
+            else:
+                cols = []
+                for gid in range(ng):
+                    cnt = [int((g == gid).sum()) for g in groups]
+                    m = max(cnt)
+                    B = np.full((64, m), -1, np.int64)
+                    for l, x in enumerate(lists):
+                        sel = x[groups[l] == gid]
+                        B[l, :len(sel)] = sel
+                    cols.append(B)
+                A = np.concatenate(cols, 1)
+                kmax = A.shape[1]
         t8 = -(-kmax // 8)
         trips.append(t8)
         slots_used.append(kmax)
@@ -124,6 +147,8 @@ if __name__ == "__main__":
     base = None
     if len(sys.argv) > 3 and sys.argv[3] == "rest":
         runs = [dict(), dict(align="plane"), dict(shape=(0, 3, 3)), dict(shape=(1, 2, 3)), dict(shape=(2, 2, 2)), dict(shape=(1, 3, 2))]
+    elif len(sys.argv) > 3 and sys.argv[3] == "plane16":
+        runs = [dict(), dict(align="plane16"), dict(align="plane")]
     elif len(sys.argv) > 3 and sys.argv[3] == "groups":
         runs = [dict(), dict(align=(0, 0, 1, 2, 2)), dict(align=(0, 0, 0, 1, 1)), dict(align=(0, 0, 1, 1, 1)), dict(shape=(1, 3, 2)), dict(shape=(1, 2, 3), align="plane")]
     else:
