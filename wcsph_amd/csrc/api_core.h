@@ -118,7 +118,7 @@ static int check_flags(wcsph_ctx *ctx) {
   if (f & ERRBIT_BUCKET) return ctx->fail(WCSPH_EBUCKET, "more than maxInGrid particles in one hash bucket (ref: HashGrid.py:72-74)");
   if (f & ERRBIT_NEIGH) return ctx->fail(WCSPH_ENEIGH, "more than maxNeighbour neighbour-list entries (ref: HashGrid.py:100-103)");
   if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "compact neighbour list capacity (wcsph_params.list_cap, default 256 slots of one kind) exceeded");
-  if (f & ERRBIT_ROWITEMS) return ctx->fail(WCSPH_EBUCKET, "raw-row item table of the literal compute_tension full (more than 2 bucket entries per grid cell on average)");
+  if (f & ERRBIT_ROWITEMS) return ctx->fail(WCSPH_EBUCKET, "raw-row item table of the literal compute_tension too small (it is sized from its scanned total before it is filled: this should not happen)");
   if (f & ERRBIT_NONFINITE) return ctx->fail(WCSPH_ENONFINITE, "non-finite particle position (ref: dfsph.py:645-647)");
   return 0;
 }

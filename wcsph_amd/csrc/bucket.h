@@ -25,7 +25,8 @@ struct BucketTab {
   // neighbouring runs, and a row walk is 25 runs + one record gather per entry instead of 125 hashes, 125 slices
   // scattered all over the table by the hash, and two dependent look-ups per entry
   int *coff;      // [ncell + 1] exclusive offsets into citem; cells further than 2 from the liquid's box are empty
-  int *citem;     // [citem_cap]
+  int *citem;     // [citem_cap]: sum over the in-box cells of their bucket lengths -- about (cells within 2 of the liquid's box) x (particles per
+                  // bucket), i.e. the CELL count of the grown box once that box is the whole domain; sized from coff[ncell] before it is filled (api_grid.h)
   int citem_cap;
 };
 #define BK_SOLID 0x80000000u
