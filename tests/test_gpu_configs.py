@@ -115,6 +115,37 @@ def test_adhesion_branch_runs_and_matches(mode, fixed):
     g.close(); o.close()
 
 
+def test_literal_tension_item_table_grows_with_the_liquids_box():
+    """The cell-ordered raw-row table of the literal compute_tension (csrc/bucket.h) holds every in-box cell's bucket once more:
+    about (cells within 2 of the liquid's box) x (particles per bucket) items -- the CELL count of the box, not the particle
+    count.  It is sized from its scanned total and regrown when the liquid spreads (a fixed cap was an
+    out-of-bounds read waiting for a spread-out state).  A compact block first, then the same particles scattered over the
+    whole box: both against the oracle."""
+    from oracle import Oracle
+    from wcsph_amd import scene
+    from util import GpuSim, rel_err
+    liquid, solid = scene.dam_break_dfsph(12)
+    rng = np.random.default_rng(11)
+    liquid = liquid + rng.uniform(-0.2, 0.2, liquid.shape) * scene.PARTICLE_RADIUS
+    g = GpuSim(liquid, solid, mode="faithful", tension_coff=0.5, tension_coff_b=0.5, tension_fixed=0)
+    pos0 = g.pd.pos.to_numpy()
+    L = 12 * 2 * scene.PARTICLE_RADIUS
+    spread = pos0.copy()
+    spread[:len(liquid)] = rng.uniform([-L + 0.03, 0.03, -L + 0.03], [L - 0.03, 2 * L - 0.03, L - 0.03], (len(liquid), 3)).astype(np.float32)
+    for k, pos in enumerate((pos0, spread, pos0)):           # compact (small table) -> spread (regrown) -> compact again (kept)
+        o = Oracle(pos, len(liquid), 0.025, mode="faithful", bounds=(g.pd.maxboundarynp, g.pd.minboundarynp))
+        o.tension_coff, o.tension_coff_b, o.tension_fixed = 0.5, 0.5, 0
+        g.pd.pos.from_numpy(pos)
+        g.pd.hash_grid.update_grid(); o.update_grid()
+        g.call("dfsph_compute_density"); o.compute_density()
+        g.call("dfsph_clear_nonpressure"); o.clear_nonpressure()
+        g.call("dfsph_tension"); o.compute_tension()
+        assert rel_err(g.pd.normal.to_numpy(), o.normal) < 5e-5, k
+        assert rel_err(g.pd.d_vel.to_numpy(), o.d_vel) < 5e-5, k
+        o.close()
+    g.close()
+
+
 def test_nonfinite_state_is_reported():
     """ref: dfsph.py:645-647 -- the reference's only failure check is a NaN position; the library reports -5 from the
     solver entry points (a NaN error sum would otherwise read as "converged")."""
