@@ -58,13 +58,26 @@ int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
     if (fd.kind == 3) hipLaunchKernelGGL(k_unpermute3, dim3(nblk(nl)), dim3(BLOCK), 0, s, (const float4 *)fd.ptr, (const int *)d.oid, nl, ctx->stage);
     else if (fd.kind == 1 || fd.kind == -1)
       hipLaunchKernelGGL(k_unpermute1, dim3(nblk(nl)), dim3(BLOCK), 0, s, (const float *)fd.ptr, (const int *)d.oid, nl, ctx->stage);
-    else {  // cg_Minv / G rows -> [n][3][3]
+    else if (fd.kind == 9) {  // cg_Minv: six stored floats per particle -> the symmetric [n][3][3]
+      std::vector<float4> a(nl);
+      std::vector<float2> b(nl);
+      std::vector<int> oid(nl);
+      HIPCHK(hipMemcpyAsync(a.data(), d.minv_a, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(b.data(), d.minv_b, (size_t)nl * 8, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(oid.data(), d.oid, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      float *o = (float *)dst;
+      for (int i = 0; i < nl; i++) {
+        float *m = o + (size_t)oid[i] * 9;
+        m[0] = a[i].x; m[1] = a[i].y; m[2] = a[i].z; m[3] = a[i].y; m[4] = a[i].w; m[5] = b[i].x; m[6] = a[i].z; m[7] = b[i].x; m[8] = b[i].y;
+      }
+      return WCSPH_OK;
+    } else {  // G rows -> [n][3][3]
       std::vector<float4> r0(nl), r1(nl), r2(nl);
       std::vector<int> oid(nl);
-      const bool isG = fd.kind == 10;
-      HIPCHK(hipMemcpyAsync(r0.data(), isG ? ctx->surf.g0 : d.minv0, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(r1.data(), isG ? ctx->surf.g1 : d.minv1, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipMemcpyAsync(r2.data(), isG ? ctx->surf.g2 : d.minv2, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(r0.data(), ctx->surf.g0, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(r1.data(), ctx->surf.g1, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(r2.data(), ctx->surf.g2, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
       HIPCHK(hipMemcpyAsync(oid.data(), d.oid, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       float *o = (float *)dst;

@@ -53,7 +53,10 @@ struct Dev {
   int *where;                             // original -> sorted index
   int *gid;                               // slab decomposition: GLOBAL particle id of row o (nullptr: the row index is the id)
   float4 *d_vel, *d_omega, *normal, *cg_r, *cg_dir, *cg_Ad, *cg_s;
-  float4 *minv0, *minv1, *minv2;          // rows of cg_Minv
+  // cg_Minv: the inverse of a symmetric 3 x 3 block is symmetric -- six floats per particle (24 B instead of three padded rows, 48 B:
+  // the PCG update reads them and the preconditioner pass writes them, once per step each, from / to HBM)
+  float4 *minv_a;                         // (m00, m01, m02, m11)
+  float2 *minv_b;                         // (m12, m22)
   float *rho, *adv_rho, *pressure, *vel_max, *alpha, *kbuf;
   float4 *pk;                             // per-pass packed gather record (pos.xyz, payload)
   float4 *pr;                             // (pos.xyz, rho): one gather instead of two in the viscosity / vorticity / tension walks
@@ -173,6 +176,16 @@ __device__ __forceinline__ int ld_once(const int *p) {
 __device__ __forceinline__ void st_once(float4 *p, float4 v) {
   v4f_nt w = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(w, reinterpret_cast<v4f_nt *>(p));
+}
+__device__ __forceinline__ float2 ld_once(const float2 *p) {
+  typedef float v2f_nt __attribute__((ext_vector_type(2)));
+  const v2f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v2f_nt *>(p));
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st_once(float2 *p, float2 v) {
+  typedef float v2f_nt __attribute__((ext_vector_type(2)));
+  v2f_nt w = {v.x, v.y};
+  __builtin_nontemporal_store(w, reinterpret_cast<v2f_nt *>(p));
 }
 __device__ __forceinline__ void st_once(float *p, float v) {
   __builtin_nontemporal_store(v, p);

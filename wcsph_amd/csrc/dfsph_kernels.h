@@ -436,12 +436,13 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv(Dev d, float dt) {
   float A = dd * ff - ee * ee, B = -(b * ff - ee * c), C = b * ee - dd * c;
   float id = 1.0f / (a * A + b * B + c * C);
   float i11 = (a * ff - c * c) * id, i12 = -(a * ee - c * b) * id, i22 = (a * dd - b * b) * id;
-  d.minv0[i] = make_float4(A * id, B * id, C * id, 0);
-  d.minv1[i] = make_float4(B * id, i11, i12, 0);
-  d.minv2[i] = make_float4(C * id, i12, i22, 0);
+  d.minv_a[i] = make_float4(A * id, B * id, C * id, i11);
+  d.minv_b[i] = make_float2(i12, i22);
 }
 __device__ __forceinline__ float3 minv_mul(const Dev &d, int i, float3 v) {
-  float4 r0 = ld_once(d.minv0 + i), r1 = ld_once(d.minv1 + i), r2 = ld_once(d.minv2 + i);
+  const float4 ma = ld_once(d.minv_a + i);
+  const float2 mb = ld_once(d.minv_b + i);
+  const float4 r0 = make_float4(ma.x, ma.y, ma.z, 0), r1 = make_float4(ma.y, ma.w, mb.x, 0), r2 = make_float4(ma.z, mb.x, mb.y, 0);
   return f3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
 }
 // ref: dfsph.py:217-223: r = v - A(v_guess); d = Minv r; delta_zero = sum r.d
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual(Dev d, float dt) {
     float id = 1.0f / (a * A + b * B + c * C);
     float i11 = (a * ff - c * c) * id, i12 = -(a * ee - c * b) * id, i22 = (a * dd - b * b) * id;
     const float4 r0 = make_float4(A * id, B * id, C * id, 0), r1 = make_float4(B * id, i11, i12, 0), r2 = make_float4(C * id, i12, i22, 0);
-    st_once(d.minv0 + i, r0); st_once(d.minv1 + i, r1); st_once(d.minv2 + i, r2);
+    st_once(d.minv_a + i, make_float4(r0.x, r0.y, r0.z, r1.y)); st_once(d.minv_b + i, make_float2(r1.z, r2.z));
     const float3 res = xyz(ld_once(d.vel + i)) - (xi - ret * f);
     const float3 dir = f3(r0.x * res.x + r0.y * res.y + r0.z * res.z, r1.x * res.x + r1.y * res.y + r1.z * res.z,
                           r2.x * res.x + r2.y * res.y + r2.z * res.z);
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(BLOCK) k_visc_minv_residual_vort(Dev d, float 
     float id = 1.0f / (a * A + b * B + c * C);
     float i11 = (a * ff - c * c) * id, i12 = -(a * ee - c * b) * id, i22 = (a * dd - b * b) * id;
     const float4 r0 = make_float4(A * id, B * id, C * id, 0), r1 = make_float4(B * id, i11, i12, 0), r2 = make_float4(C * id, i12, i22, 0);
-    d.minv0[i] = r0; d.minv1[i] = r1; d.minv2[i] = r2;
+    d.minv_a[i] = make_float4(r0.x, r0.y, r0.z, r1.y); d.minv_b[i] = make_float2(r1.z, r2.z);
     const float3 res = xyz(d.vel[i]) - (xi - ret * f);
     const float3 dir = f3(r0.x * res.x + r0.y * res.y + r0.z * res.z, r1.x * res.x + r1.y * res.y + r1.z * res.z,
                           r2.x * res.x + r2.y * res.y + r2.z * res.z);
