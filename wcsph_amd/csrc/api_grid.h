@@ -14,7 +14,7 @@ static int bucket_hist_launches(wcsph_ctx *ctx, hipStream_t s2) {
     hipLaunchKernelGGL(k_hash_bin, dim3((nh + BLOCK * HB_ROWS - 1) / (BLOCK * HB_ROWS)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh,
                        ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf);
     hipLaunchKernelGGL(k_bin_hist, dim3(ctx->hb_nbins), dim3(1024), 0, s2, d, ctx->hb_cap, ctx->hb_bins, (const int *)ctx->hb_buf, ctx->bcount_l);
-    hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins);
+    hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh) < 512 ? nblk(nh) : 512), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins);
   } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
   return 0;
 }
@@ -95,7 +95,7 @@ static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box) {
   Dev &d = ctx->d;
   const int nb = ctx->n_regions;
   if (!box) {
-    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk(d.table_size)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk((d.table_size + 3) / 4)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
     if (d.nl > 0) {
       if (d.max_in_grid <= 255)
         hipLaunchKernelGGL(k_cellval_occ<unsigned char>, dim3(nb), dim3(BLOCK), 0, s, d, (const unsigned char *)ctx->bcount8, (const int *)ctx->region_occ, ctx->cellval);

@@ -151,15 +151,17 @@ __global__ void __launch_bounds__(1024) k_bin_hist(Dev d, int cap, int *bins, co
   for (int k = threadIdx.x; k < (1 << HB_SHIFT) && b0 + k < d.table_size; k += 1024) bl[b0 + k] = tab[k];
 }
 // the atomics path, only when a range list overflowed (also leaves the lists empty for the next update)
+// (grid-stride over a SMALL grid: in the usual case every block of this launch only reads the flag and leaves)
 __global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *pw, int n, int *bcount, int nbins, int *bins) {
   if (!bins[HB_FLAG]) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nbins) bins[i] = 0;
-  if (i >= n) return;
-  const int w = pw[i];
-  if (w < 0) return;
-  const int gx = (w & 1023) + d.x0;
-  if (gx >= d.own_lo && gx < d.own_hi) atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(n, nbins); i += gridDim.x * blockDim.x) {
+    if (i < nbins) bins[i] = 0;
+    if (i >= n) continue;
+    const int w = pw[i];
+    if (w < 0) continue;
+    const int gx = (w & 1023) + d.x0;
+    if (gx >= d.own_lo && gx < d.own_hi) atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
+  }
 }
 // one block: reduce the per-block boxes of k_cell_assign into out[6] = {xmin,ymin,zmin,xmax,ymax,zmax} (max < 0: empty)
 __global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out) {
@@ -420,15 +422,32 @@ __global__ void __launch_bounds__(ALIAS_TB) k_alias_fill(Dev d, const int *cell_
 // bcount8: the same counts as bytes (saturated at 255) -- a 3 MB table that stays in the 4 MB L2 of every XCD, where the
 // 12 MB of ints do not: k_cellval_occ's gathers are random (used while max_in_grid <= 255: every legal count fits)
 // The liquid histogram is zeroed as it is consumed (the next grid update needs no 12 MB memset).
-__global__ void k_bucket_sum(Dev d, const int *bs, int *bl, int *bcount, unsigned char *bcount8, int *flags) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= d.table_size) return;
-  const int l = bl[b];
-  if (l != 0) bl[b] = 0;
-  const int v = bs[b] + l;
-  bcount[b] = v;
-  bcount8[b] = (unsigned char)min(v, 255);
-  if (v > d.max_in_grid) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
+// Four buckets per thread (16-byte loads and stores, one 4-byte store of the four byte counts); the int table is written
+// past the caches (read again only on demand: gridCount.to_numpy(), the bucket rows, the slab histogram's scratch).
+__global__ void __launch_bounds__(BLOCK) k_bucket_sum(Dev d, const int *bs, int *bl, int *bcount, unsigned char *bcount8, int *flags) {
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int T = d.table_size;
+  if (b >= T) return;
+  bool over = false;
+  if (b + 4 <= T) {
+    const int4 l = *reinterpret_cast<const int4 *>(bl + b), s = *reinterpret_cast<const int4 *>(bs + b);
+    if (l.x | l.y | l.z | l.w) *reinterpret_cast<int4 *>(bl + b) = make_int4(0, 0, 0, 0);
+    const int4 v = make_int4(s.x + l.x, s.y + l.y, s.z + l.z, s.w + l.w);
+    __builtin_nontemporal_store(v.x, bcount + b); __builtin_nontemporal_store(v.y, bcount + b + 1);
+    __builtin_nontemporal_store(v.z, bcount + b + 2); __builtin_nontemporal_store(v.w, bcount + b + 3);
+    *reinterpret_cast<unsigned *>(bcount8 + b) = (unsigned)min(v.x, 255) | ((unsigned)min(v.y, 255) << 8) | ((unsigned)min(v.z, 255) << 16) | ((unsigned)min(v.w, 255) << 24);
+    over = max(max(v.x, v.y), max(v.z, v.w)) > d.max_in_grid;
+  } else {
+    for (int k = b; k < T; k++) {
+      const int l = bl[k];
+      if (l != 0) bl[k] = 0;
+      const int v = bs[k] + l;
+      bcount[k] = v;
+      bcount8[k] = (unsigned char)min(v, 255);
+      over |= v > d.max_in_grid;
+    }
+  }
+  if (over) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
 }
 // Restricted to where the liquid is: the grid is cut into REGIONS of BC0 x BC1 x BCZ cells (outer x middle x z of
 // the tile order = 4 x 2 x 1 tiles).  k_cell_assign flags the regions that hold particles; k_cellval_occ gathers
