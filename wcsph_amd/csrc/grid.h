@@ -310,12 +310,23 @@ __global__ void k_scan_reduce(Dev d, const int *in, int n, int *bsum, const int 
 __global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, const int *bbox, int clear) {
   if (!scan_block_active(d, bbox, n)) return;
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  static_assert(SCAN_PER_THREAD == 8, "two 16-byte accesses per thread");
+  const bool whole = base + SCAN_PER_THREAD <= n;   // (only the last block has threads past the end)
   int v[SCAN_PER_THREAD], s = 0;
+  if (whole) {
+    const int4 a = *reinterpret_cast<const int4 *>(in + base), b = *reinterpret_cast<const int4 *>(in + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) {
-    v[k] = (base + k < n) ? in[base + k] : 0;
-    s += v[k];
-    if (clear && v[k] != 0) in[base + k] = 0;
+    for (int k = 0; k < SCAN_PER_THREAD; k++) s += v[k];
+    // consumed: one 32-byte clear per thread that counted anything, not one predicated 4-byte store per non-empty cell
+    if (clear && s != 0) { *reinterpret_cast<int4 *>(in + base) = make_int4(0, 0, 0, 0); *reinterpret_cast<int4 *>(in + base + 4) = make_int4(0, 0, 0, 0); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+      v[k] = (base + k < n) ? in[base + k] : 0;
+      s += v[k];
+      if (clear && v[k] != 0) in[base + k] = 0;
+    }
   }
   // the sum of the block totals before this block (bsum: raw totals, k_scan_reduce)
   int before = 0;
@@ -323,8 +334,15 @@ __global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, c
   int tot;
   int ex = block_exclusive_scan(s, &tot);
   ex += block_sum(before);
+  if (whole) {
+    int4 a, b;
+    a.x = ex; a.y = a.x + v[0]; a.z = a.y + v[1]; a.w = a.z + v[2];
+    b.x = a.w + v[3]; b.y = b.x + v[4]; b.z = b.y + v[5]; b.w = b.z + v[6];
+    *reinterpret_cast<int4 *>(out + base) = a; *reinterpret_cast<int4 *>(out + base + 4) = b;
+  } else {
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+    for (int k = 0; k < SCAN_PER_THREAD; k++) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+  }
 }
 
 // slab decomposition, faithful mode: the per-step liquid histogram travels as two 16-bit counts per int32 word (an int32
