@@ -10,11 +10,12 @@ static int bucket_hist_launches(wcsph_ctx *ctx, hipStream_t s2) {
   Dev &d = ctx->d;
   const int nh = d.nl < d.n_owned ? d.nl : d.n_owned;
   if (nh > 0 && ctx->hb_bins) {
-    HIPCHK(hipMemsetAsync(ctx->hb_bins + HB_FLAG, 0, sizeof(int), s2));
+    if (ctx->hb_gen == 0x7fffffff) { HIPCHK(hipMemsetAsync(ctx->hb_bins + HB_FLAG, 0, sizeof(int), s2)); ctx->hb_gen = 0; }   // (wrap-around)
+    const int gen = ++ctx->hb_gen;
     hipLaunchKernelGGL(k_hash_bin, dim3((nh + BLOCK * HB_ROWS - 1) / (BLOCK * HB_ROWS)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh,
-                       ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf);
-    hipLaunchKernelGGL(k_bin_hist, dim3(ctx->hb_nbins), dim3(1024), 0, s2, d, ctx->hb_cap, ctx->hb_bins, (const int *)ctx->hb_buf, ctx->bcount_l);
-    hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh) < 512 ? nblk(nh) : 512), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins);
+                       ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf, gen);
+    hipLaunchKernelGGL(k_bin_hist, dim3(ctx->hb_nbins), dim3(1024), 0, s2, d, ctx->hb_cap, ctx->hb_bins, (const int *)ctx->hb_buf, ctx->bcount_l, gen);
+    hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh) < 512 ? nblk(nh) : 512), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins, gen);
   } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
   return 0;
 }

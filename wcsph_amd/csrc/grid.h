@@ -101,12 +101,13 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist(Dev d, const int *pw, int
 // LDS, reserves its share of every range's list with ONE device atomic per range and writes the bucket ids there.
 // k_bin_hist: one workgroup per range counts its list in an LDS table of 2^HB_SHIFT ints and writes this step's liquid
 // histogram of the range, zeros included, coalesced.  A list that does not fit its buffer raises bins[HB_FLAG]: k_bin_hist
-// then writes nothing and the gated k_bucket_hist takes the histogram with atomics (the flag is cleared before every k_hash_bin).
+// then writes nothing and the gated k_bucket_hist takes the histogram with atomics.  The flag is raised to the update's
+// generation number `gen` (a host counter): nothing has to clear it between updates.
 #define HB_SHIFT 15
 #define HB_MAXBINS 1024   /* tables up to 33.5 M buckets (a 16 M + 4 M particle decomposition has 20 M) */
 #define HB_FLAG HB_MAXBINS
 #define HB_ROWS 16
-__global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n, int nbins, int cap, int *bins, int *binbuf) {
+__global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n, int nbins, int cap, int *bins, int *binbuf, int gen) {
   __shared__ int cnt[HB_MAXBINS], base[HB_MAXBINS];
   for (int b = threadIdx.x; b < nbins; b += BLOCK) cnt[b] = 0;
   __syncthreads();
@@ -133,12 +134,12 @@ __global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n,
     if (h[r] < 0) continue;
     const int b = h[r] >> HB_SHIFT, o = base[b] + at[r];
     if (o < cap) binbuf[(size_t)b * cap + o] = h[r];
-    else bins[HB_FLAG] = 1;
+    else bins[HB_FLAG] = gen;
   }
 }
-__global__ void __launch_bounds__(1024) k_bin_hist(Dev d, int cap, int *bins, const int *binbuf, int *bl) {
+__global__ void __launch_bounds__(1024) k_bin_hist(Dev d, int cap, int *bins, const int *binbuf, int *bl, int gen) {
   __shared__ int tab[1 << HB_SHIFT];
-  if (bins[HB_FLAG]) return;                       // grid-uniform: an overflowing list -> the atomics path
+  if (bins[HB_FLAG] == gen) return;                // grid-uniform: an overflowing list -> the atomics path
   const int b = blockIdx.x;
   for (int k = threadIdx.x; k < (1 << HB_SHIFT); k += 1024) tab[k] = 0;
   __syncthreads();
@@ -152,8 +153,8 @@ __global__ void __launch_bounds__(1024) k_bin_hist(Dev d, int cap, int *bins, co
 }
 // the atomics path, only when a range list overflowed (also leaves the lists empty for the next update)
 // (grid-stride over a SMALL grid: in the usual case every block of this launch only reads the flag and leaves)
-__global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *pw, int n, int *bcount, int nbins, int *bins) {
-  if (!bins[HB_FLAG]) return;
+__global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *pw, int n, int *bcount, int nbins, int *bins, int gen) {
+  if (bins[HB_FLAG] != gen) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(n, nbins); i += gridDim.x * blockDim.x) {
     if (i < nbins) bins[i] = 0;
     if (i >= n) continue;
@@ -295,10 +296,14 @@ __global__ void k_scan_reduce(Dev d, const int *in, int n, int *bsum, const int 
   if (!scan_block_active(d, bbox, n)) { if (threadIdx.x == 0) bsum[blockIdx.x] = 0; return; }
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   int s = 0;
+  if (base + SCAN_PER_THREAD <= n) {
+    const int4 a = *reinterpret_cast<const int4 *>(in + base), b = *reinterpret_cast<const int4 *>(in + base + 4);
+    s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+  } else {
 #pragma unroll
-  for (int k = 0; k < SCAN_PER_THREAD; k++) s += (base + k < n) ? in[base + k] : 0;
-  int tot;
-  block_exclusive_scan(s, &tot);
+    for (int k = 0; k < SCAN_PER_THREAD; k++) s += (base + k < n) ? in[base + k] : 0;
+  }
+  const int tot = block_sum(s);
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 // (rounds 1-3 scanned the block sums in a one-block launch of their own, 14 us + two dependent dispatch gaps; since round 4 every
