@@ -142,7 +142,7 @@ enum { PRED_NONE = 0, PRED_PRESS = 1, PRED_DIV = 2, PRED_VISC = 3, PRED_PASS = 4
 struct PredSpec { int kind; double thr, n; int *out; const int *gate; };
 #define MAIL_RING 8   /* publishes that may be in flight before the host reads the first of them */
 struct HostMail { double acc[8]; int flags[4]; unsigned long long seq; int pred; int pad_; };
-__global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned long long seq, PredSpec ps) {
+__device__ __forceinline__ void publish_body(const double *acc, int *flags, HostMail *m, unsigned long long seq, const PredSpec &ps) {
   const int t = threadIdx.x;
   if (ps.gate && *ps.gate == 0) { if (t == 0 && ps.out) *ps.out = 0; return; }
   // one wave: lane t holds stripe t of every slot (eight independent loads in flight), the totals are formed by the same
@@ -169,16 +169,33 @@ __global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned l
     m->pred = stop;
     if (ps.out) *ps.out = stop;
   } else if (t >= 8 && t < 12) {
-    m->flags[t - 8] = flags[t - 8];
+    // (a device-scope load: k_cfl_store_publish's own lane 0 has just written two of these words)
+    m->flags[t - 8] = __hip_atomic_load(&flags[t - 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t - 8 == FLAG_ERR) flags[FLAG_ERR] = 0;   // handed over: reported exactly once
   }
   __syncthreads();
   if (t == 0) { __threadfence_system(); __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
+__global__ void k_publish(const double *acc, int *flags, HostMail *m, unsigned long long seq, PredSpec ps) {
+  publish_body(acc, flags, m, seq, ps);
+}
+// the CFL reduction's one-wave tail (k_cfl_store) and the mail that carries its result, in one dispatch
+__global__ void k_cfl_store_publish(Dev d, DtRule r, HostMail *m, unsigned long long seq, PredSpec ps) {
+  if (!(d.pred && *d.pred == 0)) cfl_store_body(d, r);
+  __syncthreads();
+  publish_body(d.acc, d.flags, m, seq, ps);
+}
 static int publish_async(wcsph_ctx *ctx, PredSpec ps = {PRED_NONE, 0.0, 1.0, nullptr, nullptr}) {
   const unsigned long long seq = ++ctx->mail_seq;
   HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw) + seq % MAIL_RING;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->d.acc, ctx->d.flags, m, seq, ps);
+  LAUNCHCHK();
+  return 0;
+}
+static int cfl_store_publish_async(wcsph_ctx *ctx, const DtRule &r, PredSpec ps) {   // ctx->d.pred gates the CFL part, ps.gate the mail
+  const unsigned long long seq = ++ctx->mail_seq;
+  HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw) + seq % MAIL_RING;
+  hipLaunchKernelGGL(k_cfl_store_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->d, r, m, seq, ps);
   LAUNCHCHK();
   return 0;
 }

@@ -352,10 +352,11 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
         ELEM(k_finish_nonpressure, ctx->dt);
         // deltaT is formed on the device too: vs_iter = 1 on this branch (gated by "one PCG iteration sufficed"), pr_iter is last step's
         const int it = ctx->pr_iter > 1 ? ctx->pr_iter : 1;
-        hipLaunchKernelGGL(k_cfl_store, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d,
-                           DtRule{ctx->dt_dev, ctx->dt, it, (double)ctx->p.eps, ctx->p.cfl_radius, ctx->p.user_max_t, ctx->p.user_min_t});
+        // (the one-wave tail of the CFL reduction and the mail that carries its result: one dispatch)
+        rc = cfl_store_publish_async(ctx, DtRule{ctx->dt_dev, ctx->dt, it, (double)ctx->p.eps, ctx->p.cfl_radius, ctx->p.user_max_t, ctx->p.user_min_t},
+                                     {PRED_PASS, 0.0, 1.0, nullptr, pB});
         ctx->d.pred = nullptr;
-        if ((rc = publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pB}))) return rc;
+        if (rc) return rc;
         seqC = ctx->mail_seq;
         // ... and the pressure solve up to its first decision (update_vel, warm start, begin, two iterations: dfsph.py:150-161
         // forces two), still gated by B, taking deltaT from the device; its end gated by its own decision (mail D)

@@ -705,8 +705,7 @@ __device__ __forceinline__ float dt_rule(const DtRule &r, float vmax0) {
   }
   return dt;
 }
-__global__ void k_cfl_store(Dev d, DtRule r) {
-  PRED_GATE(d);
+__device__ __forceinline__ void cfl_store_body(const Dev &d, const DtRule &r) {   // one wave
   int v = d.flags[4 + threadIdx.x];
   d.flags[4 + threadIdx.x] = 0;
 #pragma unroll
@@ -716,6 +715,10 @@ __global__ void k_cfl_store(Dev d, DtRule r) {
     if (d.nl > 0 && d.n_owned > 0) d.vel_max[d.where[0]] = __int_as_float(v);
     if (r.out) { const float dt = dt_rule(r, __int_as_float(v)); *r.out = dt; d.flags[FLAG_DT] = __float_as_int(dt); }
   }
+}
+__global__ void k_cfl_store(Dev d, DtRule r) {
+  PRED_GATE(d);
+  cfl_store_body(d, r);
 }
 
 // wcsph_dfsph_step only: end_viscosity (dfsph.py:339-343) + the integration loop of compute_vorticity (:329-330) + the
