@@ -116,6 +116,39 @@ def test_divergence_kernels(mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("open_gate", [True, False])
+def test_warmstart_pressure_velocity_pass_behind_its_flag(mode, open_gate):
+    """warmstart_pressure (dfsph.py:487-508): the velocity pass only acts on particles with adv_rho > rho_L0 (Q7: in the
+    reference's units that practically never happens), so the library launches it as a small grid that leaves at once unless
+    the elementwise launch before it saw the gate open (flags[FLAG_WARM]).  Here the gate is opened by hand for a third of the
+    particles (and left shut): kappa is rescaled either way, the velocities change only behind an open gate, as the oracle's."""
+    g, o = make_pair(8, mode, jitter=0.4)
+    nl = g.pd.liquid_count
+    rng = np.random.default_rng(5)
+    g.call("dfsph_reset_param"); o.reset_param()
+    set_state(g, o, vel=_random_vel(nl, scale=0.1))
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    g.call("dfsph_compute_density"); o.compute_density()
+    g.call("dfsph_compute_coff"); o.compute_dfsph_coff()
+    adv = np.where(rng.random(nl) < 0.33, 2000.0, 0.9).astype(np.float32) if open_gate else np.full(nl, 0.9, np.float32)
+    set_state(g, o, adv_rho=adv, kappa=(rng.standard_normal(nl) * 1e-3).astype(np.float32),
+              kappa_v=(rng.standard_normal(nl) * 1e-3).astype(np.float32))
+    v0 = g.pd.vel.to_numpy().copy()
+    for rep in range(2):   # twice: the flag of the first call must not leak into the second (generation numbers)
+        g.call("dfsph_warmstart_pressure"); o.warmstart_pressure()
+        assert rel_err(g.kappa.to_numpy(), o.kappa) < TOL
+        assert rel_err(g.pd.vel.to_numpy(), o.vel) < 2 * TOL
+        moved = np.abs(g.pd.vel.to_numpy() - v0).max(axis=1) > 0
+        assert moved.any() == open_gate and not moved[adv < 1000.0].any()
+        if rep == 0:
+            adv = np.full(nl, 0.9, np.float32)             # shut again: the second call must change no velocity
+            set_state(g, o, adv_rho=adv)
+            v0 = g.pd.vel.to_numpy().copy()
+            open_gate = False
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_pressure_kernels(mode):
     g, o = make_pair(8, mode, jitter=0.4)
     nl = g.pd.liquid_count

@@ -24,6 +24,7 @@ struct wcsph_ctx {
   unsigned char *bcount8 = nullptr;
   int *region_occ = nullptr;      // neighborCount regions that hold particles: flagged by k_cell_assign, cleared by k_ncount_box
   int grid_stage = 0;             // split grid update (api_grid.h): 1 cells assigned, 2 sorted, 3 lists built; 0 none in progress
+  int warm_gen = 0;              // generation number of flags[FLAG_WARM] (api_dfsph.h update_vel_warm_start)
   int hb_gen = 0;                // generation number of the binned histogram's overflow flag (grid.h k_hash_bin)
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand

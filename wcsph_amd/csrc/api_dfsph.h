@@ -105,12 +105,28 @@ int wcsph_dfsph_divergence_iter(wcsph_ctx *ctx) {
 }
 int wcsph_dfsph_end_divergence(wcsph_ctx *ctx) { NEED_SETUP(); ELEM(k_end_div, ctx->dt); return WCSPH_OK; }
 
+// the velocity pass of warmstart_pressure as a small launch that does nothing unless the elementwise launch before it (same
+// adv_rho) saw the gate adv_rho > rho_L0 open and raised flags[FLAG_WARM] to this generation number (dfsph.py:487-508, Q7)
+static int warm_press_vel_flagged(wcsph_ctx *ctx, int gen) {
+  if (ctx->d.nl > 0) {
+    const int nb = nblk8(ctx->d.nl);
+    hipLaunchKernelGGL(k_warm_press_vel_flagged, dim3(nb < 1024 ? nb : 1024), dim3(BLOCK), 0, ctx->stream, ctx->d, ctx->dt, gen);
+  }
+  ctx->d.rev ^= 1;   // (as PASS: the alternation of the neighbour passes stays what it was)
+  LAUNCHCHK();
+  return 0;
+}
+static int next_warm_gen(wcsph_ctx *ctx) { return ctx->warm_gen = ctx->warm_gen == 0x7fffffff ? 1 : ctx->warm_gen + 1; }
 int wcsph_dfsph_warmstart_pressure(wcsph_ctx *ctx) {
   NEED_GRID();
-  if (ctx->warm_scaled) ctx->warm_scaled = false;   // wcsph_dfsph_step: done by k_update_vel_warm_scale
-  else ELEM(k_warm_press_scale, ctx->dt);
-  PASS(k_warm_press_vel, ctx->dt);
-  return WCSPH_OK;
+  if (ctx->warm_scaled) {   // wcsph_dfsph_step without speculation: the scale was done by k_update_vel_warm_scale (no flag taken)
+    ctx->warm_scaled = false;
+    PASS(k_warm_press_vel, ctx->dt);
+    return WCSPH_OK;
+  }
+  const int gen = next_warm_gen(ctx);
+  ELEM(k_warm_press_scale, ctx->dt, gen);
+  return warm_press_vel_flagged(ctx, gen);
 }
 int wcsph_dfsph_begin_pressure(wcsph_ctx *ctx) { NEED_GRID(); HOT_DRHO_PRESS(DRHO_BEGIN, ctx->dt); return WCSPH_OK; }
 int wcsph_dfsph_pressure_iter(wcsph_ctx *ctx) {
@@ -206,6 +222,13 @@ int wcsph_dfsph_update_pos(wcsph_ctx *ctx) {
 }
 
 // ---- host-side control ------------------------------------------------------------------------
+// wcsph_dfsph_step: update_vel + the scale of warmstart_pressure (one elementwise launch) + its velocity pass as a small launch that
+// does nothing unless the first one saw the gate adv_rho > rho_L0 open (dfsph.py:487-508, Q7)
+static int update_vel_warm_start(wcsph_ctx *ctx) {
+  const int gen = next_warm_gen(ctx);
+  ELEM(k_update_vel_warm_scale, ctx->dt, gen);
+  return warm_press_vel_flagged(ctx, gen);
+}
 // init_viscosity_para + the first compute_viscosity_force, up to the publish of their sums (dfsph.py:90-97).  gate != nullptr:
 // queued speculatively behind the decision that sets *gate (solve_divergence), every launch gated by it.
 static int nonpressure_visc_open(wcsph_ctx *ctx, const int *gate, PredSpec ps) {
@@ -363,8 +386,7 @@ int wcsph_dfsph_solve_divergence(wcsph_ctx *ctx) {  // ref: dfsph.py:131-146
         int *pD = ctx->pred_dev + 0;
         ctx->spec_prof_mark = ctx->prof_used;   // in-situ timing: the event pairs of iterations that turn out gated off are dropped
         ctx->d.pred = pB; ctx->d.dtp = ctx->dt_dev;
-        ELEM(k_update_vel_warm_scale, ctx->dt);
-        PASS(k_warm_press_vel, ctx->dt);
+        if ((rc = update_vel_warm_start(ctx))) return rc;
         PASS((k_drho_press<DRHO_BEGIN, true>), ctx->dt);
         rc = pressure_iter_fused(ctx);
         if (!rc) rc = pressure_iter_fused(ctx);
@@ -485,7 +507,7 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
     ctx->pr_iter = 2;
     if (ctx->h_pred) { ctx->fuse_elem = false; return WCSPH_OK; }   // two iterations sufficed and the step's last kernel has run
     ctx->pr_resume = true;                                            // go on from iteration 3, one decision at a time
-  } else if (fuse) { ELEM(k_update_vel_warm_scale, ctx->dt); ctx->warm_scaled = true; }
+  } else if (fuse) { ELEM(k_update_vel_warm_scale, ctx->dt, 0); ctx->warm_scaled = true; }
   else if ((rc = wcsph_dfsph_update_vel(ctx))) return rc;
   rc = wcsph_dfsph_solve_pressure(ctx);
   ctx->fuse_elem = false; ctx->warm_scaled = false;

@@ -73,7 +73,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   if (d.nbr_cap < 1) d.nbr_cap = 1;
   DALLOC(d.nbl, (size_t)d.nbr_stride * (d.nbr_cap / 8)); DALLOC(d.nbs, (size_t)d.nbr_stride * (d.nbr_cap / 8));
   DALLOC(d.spos, (size_t)d.ns);
-  DALLOC(d.acc, 8 * ACC_STRIPES); DALLOC(d.flags, 4 + ACC_STRIPES);   // [4..]: striped vmax
+  DALLOC(d.acc, 8 * ACC_STRIPES); DALLOC(d.flags, 4 + ACC_STRIPES + 4);   // [4..]: striped vmax, then FLAG_WARM
   size_t nmax = nl > (size_t)d.ns ? nl : (size_t)d.ns;
   DALLOC(ctx->pw, nmax); DALLOC(ctx->slot, nmax);
   size_t stage_n = (nl + d.ns) * 3 > nl * 9 ? (nl + d.ns) * 3 : nl * 9;

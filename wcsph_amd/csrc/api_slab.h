@@ -143,7 +143,7 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_VEL_ITER: HOT_VEL(0, ctx->d.kbuf, dt, ctx->d.n_owned < ctx->d.nl); break;
     case WCSPH_PH_DRHO_DIV_ITER: if (ctx->d.part_mode != 2 && (rc = zero_acc(ctx, ACC_ERR))) return rc; HOT_DRHO_DIV(DRHO_ITER, dt); break;
     case WCSPH_PH_END_DIV: ELEM(k_end_div, dt); break;
-    case WCSPH_PH_WARM_PRESS_SCALE: ELEM(k_warm_press_scale, dt); break;
+    case WCSPH_PH_WARM_PRESS_SCALE: ELEM(k_warm_press_scale, dt, 0); break;
     case WCSPH_PH_WARM_PRESS_VEL: PASS(k_warm_press_vel, dt); break;
     case WCSPH_PH_DRHO_PRESS_BEGIN: HOT_DRHO_PRESS(DRHO_BEGIN, dt); break;
     case WCSPH_PH_MAKE_K_PRESS: ELEM(k_make_k, ctx->d.kappa, 1.0f); break;
@@ -180,7 +180,7 @@ int wcsph_phase(wcsph_ctx *ctx, int ph) {
     case WCSPH_PH_UPDATE_VEL: ELEM(k_update_vel, dt); break;
     case WCSPH_PH_UPDATE_POS: ELEM(k_update_pos, dt); break;
     case WCSPH_PH_END_DIV_BEGIN_NONPRESSURE: ELEM(k_end_div_begin_nonpressure, dt, 0); break;
-    case WCSPH_PH_UPDATE_VEL_WARM_SCALE: ELEM(k_update_vel_warm_scale, dt); break;
+    case WCSPH_PH_UPDATE_VEL_WARM_SCALE: ELEM(k_update_vel_warm_scale, dt, 0); break;
     case WCSPH_PH_END_PRESS_UPDATE_POS: ELEM(k_end_press_update_pos, dt); break;
     default: return ctx->fail(WCSPH_EARG, "unknown phase id");
   }
@@ -382,7 +382,7 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   };
   auto press_open = [&](float dtv) -> int {   // update_vel(); solve_pressure() up to its first decision (dfsph.py:150-161 forces two iterations; the warm start changes no velocity, Q7)
     int rc;
-    ELEM(k_update_vel_warm_scale, dtv);
+    ELEM(k_update_vel_warm_scale, dtv, 0);
     PASS(k_warm_press_vel, dtv);
     R.hf_begin(); R.hf_add(d.vel, 3, 4);
     if ((rc = R.xp(true, SPASS_((k_drho_press<DRHO_BEGIN, true>), dtv)))) return rc;

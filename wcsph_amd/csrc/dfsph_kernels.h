@@ -287,16 +287,14 @@ __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, f
 
 // ref: dfsph.py:487-508 warmstart_pressure, literal (Q7: the gate adv_rho > rho_L0 practically never
 // opens; the solid branch reads kappa_v).  kappa is rescaled first (:490).
-__global__ void k_warm_press_scale(Dev d, float dt) {
+// gen != 0: also raises flags[FLAG_WARM] = gen where the gate of the velocity pass opens (k_warm_press_vel_flagged)
+__global__ void k_warm_press_scale(Dev d, float dt, int gen) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || !owned(d, i)) return;
   d.kappa[i] = fmaxf(d.kappa[i] / dt / dt, -0.5f * d.rho_L0 * d.rho_L0);
+  if (gen && d.adv_rho[i] > d.rho_L0) d.flags[FLAG_WARM] = gen;
 }
-__global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
-  PRED_GATE(d);
-  DT_OVERRIDE(d, dt);
-  LOAD_I
-  if (!own) return;
+__device__ __forceinline__ void warm_press_vel_one(const Dev &d, int i, float4 pi, float dt) {
   if (!(d.adv_rho[i] > d.rho_L0)) return;
   const float ki = d.kappa[i], kvi = d.kappa_v[i];
   float3 acc = f3(0, 0, 0);
@@ -311,6 +309,25 @@ __global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
   float4 v = d.vel[i];
   v.x += acc.x; v.y += acc.y; v.z += acc.z;
   d.vel[i] = v;
+}
+__global__ void __launch_bounds__(BLOCK) k_warm_press_vel(Dev d, float dt) {
+  PRED_GATE(d);
+  DT_OVERRIDE(d, dt);
+  LOAD_I
+  if (!own) return;
+  warm_press_vel_one(d, i, pi, dt);
+}
+// wcsph_dfsph_step: k_update_vel_warm_scale, which runs just before with the same adv_rho, raises flags[FLAG_WARM] to the step's
+// generation number when ANY particle passes the gate above (Q7: practically never); otherwise the workgroups of this small
+// grid-stride launch read one word and leave (the full-size launch costs ~10 us per step for nothing)
+__global__ void __launch_bounds__(BLOCK) k_warm_press_vel_flagged(Dev d, float dt, int gen) {
+  PRED_GATE(d);
+  if (d.flags[FLAG_WARM] != gen) return;
+  DT_OVERRIDE(d, dt);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.nl; i += gridDim.x * blockDim.x) {
+    const float4 pi = d.pos[i];
+    if (owned(d, i) && part_ok(d, pi)) warm_press_vel_one(d, i, pi, dt);
+  }
 }
 
 // ref: dfsph.py:480-484, 549-552
@@ -789,7 +806,8 @@ __global__ void k_end_div_begin_nonpressure(Dev d, float dt, int vort) {
   d.vel_guess[i] = make_float4(g.x + v.x, g.y + v.y, g.z + v.z, 0);   // gathered by the viscosity walk launched next
 }
 // update_vel (dfsph.py:572-575) + the kappa rescale that opens warmstart_pressure (:490)
-__global__ void k_update_vel_warm_scale(Dev d, float dt) {
+// gen != 0: also raises flags[FLAG_WARM] = gen where the warm start's gate opens (k_warm_press_vel_flagged)
+__global__ void k_update_vel_warm_scale(Dev d, float dt, int gen) {
   PRED_GATE(d);
   DT_OVERRIDE(d, dt);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -797,6 +815,7 @@ __global__ void k_update_vel_warm_scale(Dev d, float dt) {
   float4 v = ld_once(d.vel + i), a = ld_once(d.d_vel + i);
   d.vel[i] = make_float4(v.x + a.x * dt, v.y + a.y * dt, v.z + a.z * dt, 0);   // gathered by the pressure solve
   st_once(d.kappa + i, fmaxf(ld_once(d.kappa + i) / dt / dt, -0.5f * d.rho_L0 * d.rho_L0));
+  if (gen && d.adv_rho[i] > d.rho_L0) d.flags[FLAG_WARM] = gen;
 }
 // end of solve_pressure (dfsph.py:549-552) + update_pos (:577-580)
 __global__ void k_end_press_update_pos(Dev d, float dt) {
