@@ -96,6 +96,7 @@ enum wcsph_scalar {
   WCSPH_S_DELTA_T = 0, WCSPH_S_AVG_DENSITY_ERR, WCSPH_S_CG_DELTA, WCSPH_S_CG_DELTA_OLD, WCSPH_S_CG_DELTA_ZERO,
   WCSPH_S_VISCOSITY, WCSPH_S_VISCOSITY_B, WCSPH_S_TENSION, WCSPH_S_TENSION_B, WCSPH_S_VEL_MAX0,
   WCSPH_S_RHO_ERR,     /* pcisph.py:58 rho_err */
+  WCSPH_S_TABLE_UPDATES_IN_PLACE,   /* read only, diagnostics: grid updates of this context that updated the reference bucket table in place instead of rebuilding it (api_grid.h grid_assign) */
   WCSPH_S__COUNT
 };
 

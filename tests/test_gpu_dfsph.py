@@ -6,6 +6,7 @@ max magnitude from identical inputs; the north-star bound is 1e-4 on density."""
 import numpy as np
 import pytest
 
+from oracle import Oracle
 from util import make_pair, rel_err, set_state
 
 pytestmark = pytest.mark.gpu
@@ -394,6 +395,100 @@ def test_speculative_step_falls_back_when_a_solver_goes_on(n, steps, squeeze):
     a = np.array(seen)
     assert a[:, 0].max() >= 2 and a[:, 1].max() >= 2 and a[:, 2].max() >= 3, seen   # every fallback was taken
     pd.close(); o.close()
+
+
+def _rebuilt_counts(g, nl, max_in_grid=64):
+    """gridCount / neighborCount / overflow of a FRESH oracle on the library's current positions (a full rebuild by definition)"""
+    o2 = Oracle(g.pd.pos.to_numpy(), nl, 0.025, mode="faithful", maxInGrid=max_in_grid)
+    o2.update_grid()
+    out = (np.array(o2.gridCount), np.array(o2.neighborCount), o2.overflow_grid)
+    o2.close()
+    return out
+
+
+def test_bucket_table_updated_in_place_equals_a_rebuilt_one():
+    """One faithful context between two of its own grid updates: k_cell_assign moves the counts of the particles that changed
+    their cell (old cell: pos.w) instead of rebuilding the reference's bucket table (api_grid.h grid_assign).  A violent scene
+    (random velocities: a tenth of the particles change cells per step), 40 fused steps and an explicit update_grid() every
+    fourth step: gridCount (expanded from the byte table on demand) and neighborCount equal those of an oracle freshly built
+    on the same positions, every time; a position upload in between (which falls back to a rebuild) changes nothing."""
+    from wcsph_amd import dfsph
+    g, o = make_pair(10, "faithful", jitter=0.4)
+    o.close()
+    nl = g.pd.liquid_count
+    g.call("dfsph_reset_param")
+    g.pd.vel.from_numpy(_random_vel(nl, scale=1.5))
+    changed = 0
+    prev = None
+    for s in range(40):
+        g.call("dfsph_step")
+        if s % 4 == 3:
+            g.pd.hash_grid.update_grid()
+            gc, nc, ovf = _rebuilt_counts(g, nl)
+            assert ovf == 0
+            np.testing.assert_array_equal(g.pd.hash_grid.gridCount, gc, err_msg="step %d" % s)
+            np.testing.assert_array_equal(g.pd.hash_grid.neighborCount.to_numpy()[:nl], nc[:nl], err_msg="step %d" % s)
+            if prev is not None:
+                changed += int((gc != prev).sum())
+            prev = gc
+        if s == 21:   # a position upload: the next update rebuilds, the ones after it update in place again
+            p = g.pd.pos.to_numpy(); p[:nl] += np.float32(1e-3); g.pd.pos.from_numpy(p)
+    assert changed > 100          # the table did change under the test
+    assert g.scalar("table_updates_in_place") >= 46     # 40 steps + 10 explicit updates, less the first and the rebuild after the upload
+    g.close()
+
+
+def test_bucket_cap_with_the_table_updated_in_place():
+    """The reference's cap (HashGrid.py:72-74, here an error) while the table is updated in place: a bucket AT the cap that one
+    particle leaves and another enters in the same update is not an error (whichever atomic lands first), one particle more is.
+    Particles are moved by update_pos (a position upload would make the next update a rebuild).  The table has one bucket per
+    particle, so cells alias: the layout is searched (on the oracle) for one whose four cells have buckets of their own."""
+    from wcsph_amd._lib import WcsphError
+    import util
+    R, CAP = 0.025, 4
+    zs = np.arange(50, dtype=np.float32) * np.float32(2 * R)
+    solid = np.concatenate([np.stack([np.full(50, 1.9, np.float32), np.zeros(50, np.float32), zs], 1), [[0.0, 0.5, 0.0]]]).astype(np.float32)
+
+    def counts(liq):
+        o2 = Oracle(np.concatenate([liq, solid]).astype(np.float32), len(liq), R, mode="faithful", maxInGrid=CAP)
+        o2.update_grid()
+        out = (np.array(o2.gridCount), o2.overflow_grid)
+        o2.close()
+        return out
+
+    for shift in range(40):
+        cell = lambda k: np.array([0.07 + (0.25 + 0.05 * shift) * k / 3.0, 0.17, 0.07 + 0.05 * (shift % 7)])   # noqa: E731
+        liquid = np.array([cell(0) + [0.002 * t, 0, 0] for t in range(4)] + [cell(1), cell(2)], np.float32)
+        step1 = liquid.copy(); step1[0] = cell(3); step1[4] = cell(0) + [0.004, 0.002, 0]
+        step2 = step1.copy(); step2[5] = cell(0) + [0.006, 0.004, 0]
+        (g0, o0), (g1, o1), (g2, o2) = counts(liquid), counts(step1), counts(step2)
+        if o0 == 0 and g0.max() == CAP and o1 == 0 and g1.max() == CAP and o2 > 0:
+            break
+    else:
+        pytest.fail("no layout with four un-aliased cells found")
+    g = util.GpuSim(liquid, solid, mode="faithful", maxInGrid=CAP)
+    nl = len(liquid)
+    g.pd.hash_grid.update_grid(); g.pd.sync()
+    np.testing.assert_array_equal(g.pd.hash_grid.gridCount, g0)
+
+    def move(target):
+        p = g.pd.pos.to_numpy()[:nl]
+        g.pd.vel.from_numpy(((target - p) / np.float32(0.01)).astype(np.float32))
+        g.deltaT[0] = 0.01
+        g.call("dfsph_update_pos")
+        g.pd.hash_grid.update_grid()
+
+    move(step1)                 # particle 0 leaves A for D, particle 4 (from B) enters A: A stays at the cap
+    g.pd.sync()
+    gc, ovf = counts(g.pd.pos.to_numpy()[:nl])
+    assert ovf == 0 and gc.max() == CAP
+    np.testing.assert_array_equal(g.pd.hash_grid.gridCount, gc)
+    assert g.scalar("table_updates_in_place") == 1
+    move(step2)                 # particle 5 (from C) enters A as well: five in a bucket of four
+    with pytest.raises(WcsphError) as e:
+        g.pd.sync()
+    assert e.value.code == -3
+    g.close()
 
 
 def test_neighbor_count_follows_moving_particles_update_after_update():

@@ -37,6 +37,13 @@ class GpuSim:
         self.lib.wcsph_get_iters(self.pd._need_ctx(), C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
 
+    def scalar(self, name):
+        import ctypes as C
+        v = C.c_float()
+        ctx = self.pd._need_ctx()
+        self._lib.check(ctx, self.lib.wcsph_get_scalar(ctx, self._lib.SCALAR_ID[name], C.byref(v)))
+        return v.value
+
     def close(self):
         self.pd.close()
 

@@ -24,6 +24,11 @@ struct wcsph_ctx {
   unsigned char *bcount8 = nullptr;
   int *region_occ = nullptr;      // neighborCount regions that hold particles: flagged by k_cell_assign, cleared by k_ncount_box
   int grid_stage = 0;             // split grid update (api_grid.h): 1 cells assigned, 2 sorted, 3 lists built; 0 none in progress
+  bool hist_valid = false;       // bcount8 == static + liquid histogram of the cells in pos.w (left by a complete forked update): the next one may update it in place
+  bool hist_inc = false;         // the update in progress does so
+  int n_hist_inc = 0;            // how many updates did (WCSPH_S_TABLE_UPDATES_IN_PLACE)
+  bool bcount_int_valid = false; // the int table (gridCount) matches the byte table (k_bucket_sum wrote both; k_bucket_expand on demand)
+  int hchk_gen = 0;              // generation number of flags[FLAG_HCHK]
   int warm_gen = 0;              // generation number of flags[FLAG_WARM] (api_dfsph.h update_vel_warm_start)
   int hb_gen = 0;                // generation number of the binned histogram's overflow flag (grid.h k_hash_bin)
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ

@@ -117,7 +117,7 @@ int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t byt
   else hipLaunchKernelGGL(k_permute1, dim3(nblk(nl)), dim3(BLOCK), 0, s, (float *)fd.ptr, (const int *)d.where, nl, (const float *)ctx->stage);
   LAUNCHCHK();
   HIPCHK(hipStreamSynchronize(s));
-  if (field == WCSPH_F_POS) ctx->grid_valid = false;  // cells are stale until the next grid update
+  if (field == WCSPH_F_POS) ctx->grid_valid = ctx->hist_valid = false;  // cells are stale until the next grid update
   ctx->pr_valid = false;
   return WCSPH_OK;
 }
@@ -158,7 +158,7 @@ int wcsph_field_rows_from_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n,
   hipLaunchKernelGGL(k_rows_in, dim3(nblk(n * per)), dim3(BLOCK), 0, ctx->stream, (float *)fd.ptr, stride, per, (const int *)ctx->d.where, i0, n, (const float *)ctx->stage);
   LAUNCHCHK();
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (field == WCSPH_F_POS) ctx->grid_valid = false;
+  if (field == WCSPH_F_POS) ctx->grid_valid = ctx->hist_valid = false;
   ctx->pr_valid = false;
   return WCSPH_OK;
 }
@@ -181,13 +181,14 @@ int wcsph_field_scatter_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, in
   if (fd.kind == 3) hipLaunchKernelGGL(k_scatter_rows3, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, (float4 *)fd.ptr, (const int *)ctx->d.where, d_idx, n, (const float *)d_src);
   else hipLaunchKernelGGL(k_scatter_rows1, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, (float *)fd.ptr, (const int *)ctx->d.where, d_idx, n, (const float *)d_src);
   LAUNCHCHK();
-  if (field == WCSPH_F_POS) ctx->grid_valid = false;
+  if (field == WCSPH_F_POS) ctx->grid_valid = ctx->hist_valid = false;
   ctx->pr_valid = false;
   return WCSPH_OK;
 }
 int wcsph_set_owned(wcsph_ctx *ctx, int32_t n_owned) {
   if (!ctx || n_owned < 0 || n_owned > ctx->d.nl) return WCSPH_EARG;
   ctx->d.n_owned = n_owned;
+  ctx->hist_valid = false;   // which rows the bucket table counts has changed
   return WCSPH_OK;
 }
 
@@ -205,6 +206,7 @@ int wcsph_get_scalar(wcsph_ctx *ctx, int id, float *v) {
     case WCSPH_S_TENSION_B: *v = ctx->d.tension_b; break;
     case WCSPH_S_VEL_MAX0: *v = ctx->vel_max0; break;
     case WCSPH_S_RHO_ERR: *v = ctx->rho_err; break;
+    case WCSPH_S_TABLE_UPDATES_IN_PLACE: *v = (float)ctx->n_hist_inc; break;
     default: return ctx->fail(WCSPH_EARG, "unknown scalar id");
   }
   return WCSPH_OK;

@@ -28,6 +28,15 @@ static int bucket_hist_launches(wcsph_ctx *ctx, hipStream_t s2) {
 // build, gains nothing: profiles/r03_experiments.md (21)).  On a slab decomposition the histogram is all-reduced between
 // the two halves and stays where it was.
 static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box);
+// HashGrid.gridCount as ints (bucket rows, gridCount.to_numpy()): current after a rebuilding update, expanded from the byte table
+// after an incremental one
+static int ensure_bcount_int(wcsph_ctx *ctx) {
+  if (ctx->bcount_int_valid || !ctx->d.faithful) return 0;
+  hipLaunchKernelGGL(k_bucket_expand, dim3(nblk(ctx->d.table_size)), dim3(BLOCK), 0, ctx->stream, (const unsigned char *)ctx->bcount8, ctx->bcount, ctx->d.table_size);
+  LAUNCHCHK();
+  ctx->bcount_int_valid = true;
+  return 0;
+}
 // The update in four parts.  ONE context: assign (fork) -> sort (fork) -> lists -> join.  A slab of a decomposition in faithful
 // mode: assign [+ this rank's share of the bucket histogram] -> the histogram's all-reduce is POSTED -> sort + lists run while it
 // is in flight (they read neither the histogram nor neighborCount) -> the all-reduce is awaited -> counts (wcsph_slab_step).
@@ -45,16 +54,24 @@ static int grid_assign(wcsph_ctx *ctx, bool fork = false) {
     if (ctx->hb_bins) HIPCHK(hipMemsetAsync(ctx->hb_bins, 0, (HB_MAXBINS + 1) * sizeof(int), s));
   }
   ctx->hist_dirty = true;
+  // One faithful context between two of its own complete updates: the byte table of the bucket occupancy is UPDATED by
+  // k_cell_assign (particles that changed their cell: ~5 % of them per step at rest, 10-20 % in the developed flow) instead of
+  // being rebuilt by the histogram kernels + k_bucket_sum (50 us alone at C3).  Anything else -- the first update, a slab of a
+  // decomposition, an update that did not run to its end, a cap a byte cannot hold with a margin -- rebuilds it.
+  ctx->hist_inc = fork && ctx->hist_valid && d.max_in_grid <= 200 && d.n_owned >= d.nl && ctx->win_x1 < 0;
+  ctx->hist_valid = false;
+  const int gen = ctx->hist_inc ? (ctx->hchk_gen = ctx->hchk_gen == 0x7fffffff ? 1 : ctx->hchk_gen + 1) : 0;
+  if (ctx->hist_inc) { ctx->bcount_int_valid = false; ctx->n_hist_inc++; }
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
                        (int *)nullptr, ctx->bbox_part, d.n_owned,
-                       d.faithful ? ctx->region_occ : (int *)nullptr);
+                       d.faithful ? ctx->region_occ : (int *)nullptr, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr, gen);
   if (d.faithful && !fork) { int rc_ = bucket_hist_launches(ctx, s); if (rc_) return rc_; }   // slab halves: on this stream, before the all-reduce
   if (fork) {
     hipStream_t s2 = ctx->side_stream;
     HIPCHK(hipEventRecord(ctx->ev_assign, s));
     HIPCHK(hipStreamWaitEvent(s2, ctx->ev_assign, 0));
-    { int rc_ = bucket_hist_launches(ctx, s2); if (rc_) return rc_; }
+    if (!ctx->hist_inc) { int rc_ = bucket_hist_launches(ctx, s2); if (rc_) return rc_; }
     neighbor_count_launches(ctx, s2, false);
   }
   LAUNCHCHK();
@@ -66,7 +83,11 @@ static int grid_sort(wcsph_ctx *ctx, bool fork = false) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
+  if (ctx->hist_inc)
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox,
+                       (const unsigned char *)ctx->bcount8, d.table_size, d.max_in_grid, d.flags, ctx->hchk_gen);
+  else
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
   if (fork) {   // the box sums read the cell table and the occupied box
@@ -96,7 +117,10 @@ static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box) {
   Dev &d = ctx->d;
   const int nb = ctx->n_regions;
   if (!box) {
-    hipLaunchKernelGGL(k_bucket_sum, dim3(nblk((d.table_size + 3) / 4)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
+    if (!ctx->hist_inc) {   // (an incremental update has left the byte table current: grid_assign)
+      hipLaunchKernelGGL(k_bucket_sum, dim3(nblk((d.table_size + 3) / 4)), dim3(BLOCK), 0, s, d, (const int *)ctx->bcount_s, ctx->bcount_l, ctx->bcount, ctx->bcount8, d.flags);
+      ctx->bcount_int_valid = true;
+    }
     if (d.nl > 0) {
       if (d.max_in_grid <= 255)
         hipLaunchKernelGGL(k_cellval_occ<unsigned char>, dim3(nb), dim3(BLOCK), 0, s, d, (const unsigned char *)ctx->bcount8, (const int *)ctx->region_occ, ctx->cellval);
@@ -127,6 +151,8 @@ static int grid_finish(wcsph_ctx *ctx, bool fork) {
   if (fork) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));   // join: whatever follows may read neighborCount and the flags
   ctx->d.rev ^= 1;
   ctx->hist_dirty = false;   // k_bucket_sum / k_ncount_box have left the histogram and the region flags zeroed
+  ctx->hist_valid = fork;    // the byte table matches the cells the sort has just written to pos.w: the next update may update it in place
+  ctx->hist_inc = false;
   ctx->grid_valid = true;
   ctx->bk_valid = false;
   ctx->grid_stage = 0;
@@ -208,7 +234,8 @@ static int bucket_build(wcsph_ctx *ctx) {
     DALLOC(ctx->bk.item, (size_t)ctx->capacity + d.ns + 1); DALLOC(ctx->bk.swhere, (size_t)d.ns + 1);
     if (d.ns > 0) hipLaunchKernelGGL(k_bk_swhere, dim3(nblk(d.ns)), dim3(BLOCK), 0, s, d, ctx->bk);
   }
-  int rc = run_scan(ctx, ctx->bcount, T + 1, ctx->bk.start, nullptr, 0);   // bcount = gridCount of this step (grid update)
+  int rc = ensure_bcount_int(ctx);
+  if (!rc) rc = run_scan(ctx, ctx->bcount, T + 1, ctx->bk.start, nullptr, 0);   // bcount = gridCount of this step (grid update)
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(ctx->bk.cursor, ctx->bk.start, (size_t)T * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (d.nl > 0) hipLaunchKernelGGL(k_bk_scatter_liquid, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, ctx->bk);
@@ -254,6 +281,7 @@ int wcsph_hashgrid_count_to_host(wcsph_ctx *ctx, int32_t *dst, int64_t n) {   //
   NEED_GRID();
   if (!dst || n != ctx->d.table_size) return ctx->fail(WCSPH_EARG, "wcsph_hashgrid_count_to_host: n must be the hash table size");
   if (!ctx->d.faithful) return ctx->fail(WCSPH_EARG, "HashGrid.gridCount is the reference table: faithful neighbour mode only");
+  { int rc_ = ensure_bcount_int(ctx); if (rc_) return rc_; }
   HIPCHK(hipMemcpyAsync(dst, ctx->bcount, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return WCSPH_OK;

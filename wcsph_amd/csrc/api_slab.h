@@ -63,7 +63,7 @@ int wcsph_halo_unpack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, c
   if (n <= 0) return WCSPH_OK;
   hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(n * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, d_idx, n, (const float *)d_in);
   LAUNCHCHK();
-  for (int k = 0; k < n_fields; k++) if (fields[k] == WCSPH_F_POS) ctx->grid_valid = false;
+  for (int k = 0; k < n_fields; k++) if (fields[k] == WCSPH_F_POS) ctx->grid_valid = ctx->hist_valid = false;
   ctx->pr_valid = false;
   return WCSPH_OK;
 }
@@ -76,7 +76,7 @@ int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const flo
     hipLaunchKernelGGL(k_load_state, dim3(nblk(n_total)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows, n_total, 0);
     LAUNCHCHK();
   }
-  ctx->grid_valid = false;
+  ctx->grid_valid = ctx->hist_valid = false;
   return WCSPH_OK;
 }
 int wcsph_load_state_split(wcsph_ctx *ctx, int32_t n_owned, const float *d_owned_rows, int32_t n_ghost, const float *d_ghost_rows) {
@@ -87,7 +87,7 @@ int wcsph_load_state_split(wcsph_ctx *ctx, int32_t n_owned, const float *d_owned
   if (n_owned > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_owned)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_owned_rows, n_owned, 0);
   if (n_ghost > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_ghost)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_ghost_rows, n_ghost, n_owned);
   LAUNCHCHK();
-  ctx->grid_valid = false;
+  ctx->grid_valid = ctx->hist_valid = false;
   return WCSPH_OK;
 }
 int wcsph_store_state(wcsph_ctx *ctx, float *d_rows) {

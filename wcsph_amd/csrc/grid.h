@@ -44,7 +44,14 @@ __device__ __forceinline__ int region_of_cell(const Dev &d, int w) {   // w: pac
 // occ != nullptr: the particle's neighborCount region is flagged (k_ncount_box clears the flags it consumes).
 // bbox != nullptr: also this block's bounding box of the occupied cells -> bbox[6 * blockIdx.x ..] (no atomics: the
 // particles are x-sorted, so a shared max would be raised by nearly every block); k_bbox_final reduces them.
-__global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox, int count_limit, int *occ = nullptr) {
+// inc8 != nullptr (one faithful context, between two of its own updates: api_grid.h grid_assign): the byte table of the reference
+// bucket occupancy is kept UP TO DATE instead of being rebuilt -- a particle's previous cell travels with it in pos.w (the sort
+// writes it there, every position update keeps it), so only a particle that changed its cell touches the table: one count less
+// in its old bucket, one more in the new one (32-bit atomics on the containing word).  An increment that finds the bucket at the cap
+// raises flags[FLAG_HCHK] = gen: k_bbox_final then re-checks the table (the order of the atomics is arbitrary: a bucket that one
+// particle leaves and another enters in the same update may pass the cap for a moment).
+__global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox, int count_limit, int *occ = nullptr,
+                                                      unsigned *inc8 = nullptr, int gen = 0) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
   if (i < n) {
@@ -56,6 +63,20 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
     if (!finite) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NONFINITE);
     st_once(pw + i, w);
     st_once(slot + i, atomicAdd(&cnt[lin], 1));
+    if (inc8 && i < count_limit) {
+      const int wo = __float_as_int(p.w);
+      if (wo != w) {
+        if (wo >= 0) {
+          const int h = ref_hash((wo & 1023) + d.x0, (wo >> 10) & 1023, wo >> 20, d.table_size);
+          atomicSub(&inc8[h >> 2], 1u << ((h & 3) * 8));
+        }
+        if (w >= 0) {
+          const int h = ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size), sh = (h & 3) * 8;
+          const unsigned old = atomicAdd(&inc8[h >> 2], 1u << sh);
+          if (((old >> sh) & 255u) >= (unsigned)d.max_in_grid) d.flags[FLAG_HCHK] = gen;
+        }
+      }
+    }
     if (w >= 0) {
       // reference bucket occupancy: every particle is counted ONCE across the ranks of a slab decomposition -- liquid
       // particles by their owner (ghost rows sit behind the owned ones before the sort), boundary particles by the rank
@@ -165,7 +186,16 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *p
   }
 }
 // one block: reduce the per-block boxes of k_cell_assign into out[6] = {xmin,ymin,zmin,xmax,ymax,zmax} (max < 0: empty)
-__global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out) {
+// b8 != nullptr (incremental bucket table, see k_cell_assign): when an increment met a bucket at the cap in this update
+// (flags[FLAG_HCHK] == gen), the table is re-checked here, after all of the update's atomics: any count above the cap is the
+// reference's error (HashGrid.py:72-74); one workgroup over 3 MB, but only then.
+__global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out, const unsigned char *b8 = nullptr, int T = 0, int cap = 0,
+                                                     int *flags = nullptr, int gen = 0) {
+  if (b8 && flags[FLAG_HCHK] == gen) {
+    bool over = false;
+    for (int b = threadIdx.x; b < T; b += BLOCK) over |= (int)b8[b] > cap;
+    if (over) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
+  }
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
   for (int b = threadIdx.x; b < nparts; b += BLOCK)
 #pragma unroll
@@ -471,6 +501,12 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sum(Dev d, const int *bs, int 
     }
   }
   if (over) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
+}
+// the int table (HashGrid.gridCount as the reference holds it) from the byte table, on demand, while the latter is the one kept
+// up to date (every legal count fits a byte: the incremental path requires max_in_grid <= 200)
+__global__ void __launch_bounds__(BLOCK) k_bucket_expand(const unsigned char *b8, int *bcount, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < T) bcount[b] = (int)b8[b];
 }
 // Restricted to where the liquid is: the grid is cut into REGIONS of BC0 x BC1 x BCZ cells (outer x middle x z of
 // the tile order = 4 x 2 x 1 tiles).  k_cell_assign flags the regions that hold particles; k_cellval_occ gathers
