@@ -516,25 +516,36 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_expand(const unsigned char *b8
 // its cells.  The cost follows the liquid's volume, not its bounding box (a separable five-launch version over the
 // occupied box, round 1: 100 us at C3 at rest, 290 us once the dam has spread over the domain).
 // one block per region that is or touches an occupied one: cellval[plain index] = gridCount[hash(cell)]
+// A region that only TOUCHES occupied ones gathers just the cells k_ncount_box will read from it: those within two cells of
+// an occupied neighbour (a face, edge or corner shell instead of the whole 1024 cells; a third of the launch's regions at C3 at
+// rest are of that kind, more once the liquid is a thin layer).
 template <class T>
 __global__ void __launch_bounds__(BLOCK) k_cellval_occ(Dev d, const T *bcount, const int *occ, int *cellval) {
   const Regions R = regions_of(d);
   const int bz = blockIdx.x % R.nbz, q = blockIdx.x / R.nbz, r1 = q % R.nb1, r0 = q / R.nb1;
-  __shared__ int need;
-  if (threadIdx.x == 0) need = 0;
+  __shared__ unsigned occ27;   // bit (e0 + 1) * 9 + (e1 + 1) * 3 + (ez + 1): the neighbour region (e0, e1, ez) holds particles
+  if (threadIdx.x == 0) occ27 = 0;
   __syncthreads();
   if (threadIdx.x < 27) {
     const int e0 = r0 + threadIdx.x / 9 - 1, e1 = r1 + (threadIdx.x / 3) % 3 - 1, ez = bz + threadIdx.x % 3 - 1;
-    if ((unsigned)e0 < (unsigned)R.nb0 && (unsigned)e1 < (unsigned)R.nb1 && (unsigned)ez < (unsigned)R.nbz && occ[(e0 * R.nb1 + e1) * R.nbz + ez]) need = 1;
+    if ((unsigned)e0 < (unsigned)R.nb0 && (unsigned)e1 < (unsigned)R.nb1 && (unsigned)ez < (unsigned)R.nbz && occ[(e0 * R.nb1 + e1) * R.nbz + ez])
+      atomicOr(&occ27, 1u << threadIdx.x);
   }
   __syncthreads();
-  if (!need) return;
+  const unsigned m = occ27;
+  if (!m) return;
   const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
 #pragma unroll
   for (int k = 0; k < BC0 * BC1 * BCZ / BLOCK; k++) {
     const int t = threadIdx.x + k * BLOCK;
-    const int z = bz * BCZ + t % BCZ, u = t / BCZ, a1 = r1 * BC1 + u % BC1, a0 = r0 * BC0 + u / BC1;
-    if (a0 < n0 && a1 < n1 && z < d.nz) {
+    const int lz = t % BCZ, u = t / BCZ, l1 = u % BC1, l0 = u / BC1;
+    const int z = bz * BCZ + lz, a1 = r1 * BC1 + l1, a0 = r0 * BC0 + l0;
+    // which neighbour regions' 2-cell halos this cell lies in: per axis bit 0 = the lower neighbour, 1 = this region, 2 = the upper one
+    const unsigned mz = 2u | (lz < 2 ? 1u : 0u) | (lz >= BCZ - 2 ? 4u : 0u), m1 = 2u | (l1 < 2 ? 1u : 0u) | (l1 >= BC1 - 2 ? 4u : 0u),
+                   m0 = 2u | (l0 < 2 ? 1u : 0u) | (l0 >= BC0 - 2 ? 4u : 0u);
+    const unsigned s1 = ((m1 & 1u) ? mz : 0u) | ((m1 & 2u) ? mz << 3 : 0u) | ((m1 & 4u) ? mz << 6 : 0u);
+    const unsigned sel = ((m0 & 1u) ? s1 : 0u) | ((m0 & 2u) ? s1 << 9 : 0u) | ((m0 & 4u) ? s1 << 18 : 0u);
+    if ((m & sel) && a0 < n0 && a1 < n1 && z < d.nz) {
       const int x = d.perm ? a1 : a0, y = d.perm ? a0 : a1;
       cellval[(x * d.ny + y) * d.nz + z] = (int)bcount[ref_hash(x + d.x0, y, z, d.table_size)];
     }
