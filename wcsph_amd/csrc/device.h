@@ -267,6 +267,12 @@ __device__ __forceinline__ double acc_total(const double *slot) {
   return tot;
 }
 
+// gather of element j of a kernel-argument array with a 32-bit byte offset: lets the compiler use the
+// `global_load vdst, voffset, saddr` form (one VGPR per address, one shift) instead of 64-bit pointer arithmetic
+template <class T>
+__device__ __forceinline__ T nb_ld(const T *base, int j) {
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)j * (unsigned)sizeof(T));
+}
 // The cell walk (grid update only).  fl(j, r, r2, m) is called for every liquid list entry j != i
 // inside the support (r = x_i - x_j, m = multiplicity of the entry in the reference's bucket multiset),
 // fs(j, r, r2, m) likewise for solid entries.  Entries outside the support contribute exactly zero
@@ -317,13 +323,13 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
       if (j >= end) { j = j2; end = end2; j2 = end2; }                                            \
       if (j < end) {                                                                              \
         /* the next candidate's position is requested before this one is tested */               \
-        float4 pj = POS[j];                                                                       \
+        float4 pj = nb_ld(POS, j);                                                                \
         for (;;) {                                                                                \
           int jn = j + 1, endn = end;                                                             \
           if (jn >= end) { jn = j2; endn = end2; j2 = end2; }                                     \
           const bool more = jn < endn;                                                            \
           float4 pn = pj;                                                                         \
-          if (more) pn = POS[jn];                                                                 \
+          if (more) pn = nb_ld(POS, jn);                                                          \
           const float3 r = xi - xyz(pj);                                                          \
           const float r2 = dot3(r, r);                                                            \
           if (r2 <= d.list_r2 && (SELF)) CALL(j, r, r2, 1.0f);                                    \
@@ -388,8 +394,10 @@ struct NbWriter {
   }
   __device__ __forceinline__ void entry(int j) {
     int dd = j - run;
-    while (dd >= NB_HOP) { slot(NB_HOP); dd -= NB_HOP; }
-    while (dd <= -NB_HOP) { slot(-NB_HOP); dd += NB_HOP; }
+    if (!NB_IS_ENTRY(dd)) {   // one test for both directions: the hop loops are rare (the jump to another outer tile plane of a large grid)
+      while (dd >= NB_HOP) { slot(NB_HOP); dd -= NB_HOP; }
+      while (dd <= -NB_HOP) { slot(-NB_HOP); dd += NB_HOP; }
+    }
     slot(dd);
     run = j;
   }
@@ -422,12 +430,6 @@ __device__ __forceinline__ void nb_pin(T &v) {
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(T) / 4); q += 4) asm volatile("" : "+v"(w[q]));
   }
-}
-// gather of element j of a kernel-argument array with a 32-bit byte offset: lets the compiler use the
-// `global_load vdst, voffset, saddr` form (one VGPR per address, one shift) instead of 64-bit pointer arithmetic
-template <class T>
-__device__ __forceinline__ T nb_ld(const T *base, int j) {
-  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)j * (unsigned)sizeof(T));
 }
 #define NB_LO(w) ((int)(short)((w) & 0xffffu))
 #define NB_HI(w) ((int)(w) >> 16)
