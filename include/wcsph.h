@@ -131,8 +131,8 @@ int wcsph_set_iters(wcsph_ctx *ctx, int32_t vs_iter, int32_t dv_iter, int32_t pr
 
 /* ---- HashGrid ------------------------------------------------------------------------ */
 /* ref: HashGrid.update_grid (HashGrid.py:56-85): rebuild cells + per-particle neighbour multiset.
- * Everything the call queues is ordered on the context's stream when it returns: in faithful mode the bucket histogram and
- * neighborCount kernels run on an internal side stream beside the sort and the list build and are joined before the return. */
+ * Everything the call queues is on the context's stream.  In faithful mode one context keeps the reference's bucket table up to date
+ * between two of its own updates (a particle's previous cell travels in pos.w) instead of rebuilding it. */
 int wcsph_grid_update(wcsph_ctx *ctx);
 /* ref: HashGrid.neighbor / neighborCount (HashGrid.py:24-25,88-106): materialise the explicit list the
  * reference stores, original indices, for particles [i0, i0+n): counts[n], lists[n][cap] (-1 padded) */

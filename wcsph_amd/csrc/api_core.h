@@ -7,8 +7,6 @@ struct wcsph_ctx {
   hipStream_t stream = nullptr, own_stream = nullptr;
   // faithful mode, one context: the reference bucket histogram and neighborCount (k_bucket_hist .. k_ncount_box) run on a
   // side stream beside the counting sort and the list build, which need neither (wcsph_grid_update)
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_assign = nullptr, ev_scan = nullptr, ev_side = nullptr;
   std::string err;
   bool is_setup = false, grid_valid = false;
   // double buffers of the persistent fields (the *_b set is the scatter target)
@@ -24,7 +22,7 @@ struct wcsph_ctx {
   unsigned char *bcount8 = nullptr;
   int *region_occ = nullptr;      // neighborCount regions that hold particles: flagged by k_cell_assign, cleared by k_ncount_box
   int grid_stage = 0;             // split grid update (api_grid.h): 1 cells assigned, 2 sorted, 3 lists built; 0 none in progress
-  bool hist_valid = false;       // bcount8 == static + liquid histogram of the cells in pos.w (left by a complete forked update): the next one may update it in place
+  bool hist_valid = false;       // bcount8 == static + liquid histogram of the cells in pos.w (left by a complete update of one context): the next one may update it in place
   bool hist_inc = false;         // the update in progress does so
   int n_hist_inc = 0;            // how many updates did (WCSPH_S_TABLE_UPDATES_IN_PLACE)
   bool bcount_int_valid = false; // the int table (gridCount) matches the byte table (k_bucket_sum wrote both; k_bucket_expand on demand)

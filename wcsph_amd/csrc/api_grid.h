@@ -19,14 +19,12 @@ static int bucket_hist_launches(wcsph_ctx *ctx, hipStream_t s2) {
   } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
   return 0;
 }
-// fork (wcsph_grid_update of ONE faithful context): the bucket histogram is not taken inside k_cell_assign -- its 2 M random
-// device-scope atomics are 71 of that kernel's 88 us at C3 -- but by k_bucket_hist on the side stream, followed there by the
-// bucket sums, gridCount[hash(cell)] and (once the scan is done) the neighborCount box sums, while this stream scans,
-// sorts and builds the lists: none of those reads the histogram or neighborCount.  grid_end() joins.  What this buys is
-// the holes of the one-block kernels (k_bbox_final and, until round 4, k_scan_bsums: ~21 us of an otherwise idle GPU per step), 1-1.5 % of the
-// step at C3 -- full-chip kernels of two streams time-slice, they do not add up (forking behind the sort, beside the list
-// build, gains nothing: profiles/r03_experiments.md (21)).  On a slab decomposition the histogram is all-reduced between
-// the two halves and stays where it was.
+// The bucket histogram is not taken inside k_cell_assign (its 2 M random device-scope atomics were 71 of that kernel's 88 us at
+// C3) but by kernels of its own.  (Rounds 3-4 ran them, the bucket sums and the neighborCount box sums on a side stream beside the
+// scan, the sort and the list build.  Since the table is updated in place that side work is two kernels, 57 us alone at C3, and the two
+// cross-stream waits of the fork cost more than the overlap hides: 8 000 particles 0.217 -> 0.203 ms per step without it, C2 0.252 ->
+// 0.243, C3 1.653 -> 1.646 at rest and 3.30 -> 3.28 developed -- profiles/r04u_busy_small.txt, r04u_ab_fork_threshold.txt,
+// r04u_ab_fork_c3.txt.  One stream now.)
 static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box);
 // HashGrid.gridCount as ints (bucket rows, gridCount.to_numpy()): current after a rebuilding update, expanded from the byte table
 // after an incremental one
@@ -37,10 +35,10 @@ static int ensure_bcount_int(wcsph_ctx *ctx) {
   ctx->bcount_int_valid = true;
   return 0;
 }
-// The update in four parts.  ONE context: assign (fork) -> sort (fork) -> lists -> join.  A slab of a decomposition in faithful
+// The update in four parts.  ONE context: assign -> sort -> counts -> lists.  A slab of a decomposition in faithful
 // mode: assign [+ this rank's share of the bucket histogram] -> the histogram's all-reduce is POSTED -> sort + lists run while it
 // is in flight (they read neither the histogram nor neighborCount) -> the all-reduce is awaited -> counts (wcsph_slab_step).
-static int grid_assign(wcsph_ctx *ctx, bool fork = false) {
+static int grid_assign(wcsph_ctx *ctx, bool single = false) {   // single: wcsph_grid_update() of ONE context, not a slab's halves
   Dev &d = ctx->d;
   hipStream_t s = ctx->stream;
   // ctx->cnt is all zero here: k_scan_final clears the counters it consumes.  The error flags are NOT cleared here: a
@@ -58,7 +56,7 @@ static int grid_assign(wcsph_ctx *ctx, bool fork = false) {
   // k_cell_assign (particles that changed their cell: ~5 % of them per step at rest, 10-20 % in the developed flow) instead of
   // being rebuilt by the histogram kernels + k_bucket_sum (50 us alone at C3).  Anything else -- the first update, a slab of a
   // decomposition, an update that did not run to its end, a cap a byte cannot hold with a margin -- rebuilds it.
-  ctx->hist_inc = fork && ctx->hist_valid && d.max_in_grid <= 200 && d.n_owned >= d.nl && ctx->win_x1 < 0;
+  ctx->hist_inc = single && d.faithful && ctx->hist_valid && d.max_in_grid <= 200 && d.n_owned >= d.nl && ctx->win_x1 < 0;
   ctx->hist_valid = false;
   const int gen = ctx->hist_inc ? (ctx->hchk_gen = ctx->hchk_gen == 0x7fffffff ? 1 : ctx->hchk_gen + 1) : 0;
   if (ctx->hist_inc) { ctx->bcount_int_valid = false; ctx->n_hist_inc++; }
@@ -66,20 +64,13 @@ static int grid_assign(wcsph_ctx *ctx, bool fork = false) {
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
                        (int *)nullptr, ctx->bbox_part, d.n_owned,
                        d.faithful ? ctx->region_occ : (int *)nullptr, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr, gen);
-  if (d.faithful && !fork) { int rc_ = bucket_hist_launches(ctx, s); if (rc_) return rc_; }   // slab halves: on this stream, before the all-reduce
-  if (fork) {
-    hipStream_t s2 = ctx->side_stream;
-    HIPCHK(hipEventRecord(ctx->ev_assign, s));
-    HIPCHK(hipStreamWaitEvent(s2, ctx->ev_assign, 0));
-    if (!ctx->hist_inc) { int rc_ = bucket_hist_launches(ctx, s2); if (rc_) return rc_; }
-    neighbor_count_launches(ctx, s2, false);
-  }
+  if (d.faithful && !ctx->hist_inc) { int rc_ = bucket_hist_launches(ctx, s); if (rc_) return rc_; }   // (a slab: before the all-reduce)
   LAUNCHCHK();
   ctx->grid_stage = 1;
   return 0;
 }
 // the counting sort: occupied box, exclusive scan of the cell counters, every persistent field to its cell-sorted place
-static int grid_sort(wcsph_ctx *ctx, bool fork = false) {
+static int grid_sort(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
@@ -90,13 +81,6 @@ static int grid_sort(wcsph_ctx *ctx, bool fork = false) {
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
-  if (fork) {   // the box sums read the cell table and the occupied box
-    HIPCHK(hipEventRecord(ctx->ev_scan, s));
-    HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_scan, 0));
-    neighbor_count_launches(ctx, ctx->side_stream, true);
-    HIPCHK(hipEventRecord(ctx->ev_side, ctx->side_stream));
-  }
-
   if (d.nl > 0) {
     SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.pressure, d.oid,
                      ctx->pos_b, ctx->vel_b, ctx->vel_guess_b, ctx->omega_b, ctx->kappa_b, ctx->kappa_v_b, ctx->pressure_b, ctx->oid_b, d.where};
@@ -131,7 +115,7 @@ static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box) {
     hipLaunchKernelGGL(k_ncount_box, dim3(nb), dim3(BLOCK), 0, s, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
   }
 }
-// raw neighbour-list length (HashGrid.neighborCount) on the context's stream (a forked update has them on the side stream)
+// raw neighbour-list length (HashGrid.neighborCount)
 static int grid_counts(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   if (d.faithful) { neighbor_count_launches(ctx, ctx->stream, false); neighbor_count_launches(ctx, ctx->stream, true); }
@@ -147,11 +131,10 @@ static int grid_lists(wcsph_ctx *ctx) {
   ctx->grid_stage = 3;
   return 0;
 }
-static int grid_finish(wcsph_ctx *ctx, bool fork) {
-  if (fork) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0));   // join: whatever follows may read neighborCount and the flags
+static int grid_finish(wcsph_ctx *ctx, bool single) {
   ctx->d.rev ^= 1;
   ctx->hist_dirty = false;   // k_bucket_sum / k_ncount_box have left the histogram and the region flags zeroed
-  ctx->hist_valid = fork;    // the byte table matches the cells the sort has just written to pos.w: the next update may update it in place
+  ctx->hist_valid = single && ctx->d.faithful && ctx->d.nl > 0;   // the byte table matches the cells the sort has just written to pos.w: the next update may update it in place
   ctx->hist_inc = false;
   ctx->grid_valid = true;
   ctx->bk_valid = false;
@@ -160,15 +143,11 @@ static int grid_finish(wcsph_ctx *ctx, bool fork) {
 }
 int wcsph_grid_update(wcsph_ctx *ctx) {
   NEED_SETUP();
-  const bool fork = ctx->d.faithful && ctx->d.nl > 0;
-  int rc = grid_assign(ctx, fork);
-  if (!rc) rc = grid_sort(ctx, fork);
-  if (!rc && !fork) rc = grid_counts(ctx);
+  int rc = grid_assign(ctx, true);
+  if (!rc) rc = grid_sort(ctx);
+  if (!rc) rc = grid_counts(ctx);
   if (!rc) rc = grid_lists(ctx);
-  if (!rc) rc = grid_finish(ctx, fork);
-  // an error return after the fork: nothing may stay queued on the side stream that the next update's memsets
-  // and launches on the context's stream would race with
-  if (rc && fork) (void)hipStreamSynchronize(ctx->side_stream);
+  if (!rc) rc = grid_finish(ctx, true);
   return rc;
 }
 // slab decomposition, faithful neighbour mode: the drivers all-reduce the liquid bucket histogram between the halves

@@ -22,10 +22,6 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
     return ctx->fail(WCSPH_EARG, "tension_fixed=0 (the literal loop of dfsph.py:264-305) runs over the reference's raw bucket lists: faithful neighbour mode only");
   HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
-  HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&ctx->ev_assign, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&ctx->ev_scan, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
   Dev &d = ctx->d;
   memset(&d, 0, sizeof d);
   d.nl = p->n_liquid; d.ns = p->n_solid; d.n_owned = p->n_liquid;
@@ -91,14 +87,11 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
 int wcsph_destroy(wcsph_ctx *ctx) {
   if (!ctx) return WCSPH_EARG;
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
-  if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
-  if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
-  for (hipEvent_t e : {ctx->ev_assign, ctx->ev_scan, ctx->ev_side}) if (e) hipEventDestroy(e);
   delete ctx;
   return WCSPH_OK;
 }
