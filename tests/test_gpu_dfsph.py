@@ -492,10 +492,9 @@ def test_bucket_cap_with_the_table_updated_in_place():
 
 
 def test_neighbor_count_follows_moving_particles_update_after_update():
-    """Faithful mode, one context: the bucket histogram / neighborCount kernels of a grid update run on a side stream beside
-    the sort and the list build and are joined at its end (wcsph_grid_update).  Twelve updates in a row on moving
-    particles, each read back at once: neighborCount and gridCount equal the oracle's every time (a missing join, or a
-    histogram / region flag left over from the previous update, shows up here)."""
+    """Faithful mode, one context: twelve grid updates in a row on moving particles (positions uploaded: every update rebuilds
+    the bucket table), each read back at once: neighborCount and gridCount equal the oracle's every time (a histogram / region
+    flag left over from the previous update, or -- while rounds 3-4 ran these kernels on a side stream -- a missing join, shows up here)."""
     g, o = make_pair(8, "faithful", jitter=0.4)
     rng = np.random.default_rng(11)
     pos = g.pd.pos.to_numpy().copy()
