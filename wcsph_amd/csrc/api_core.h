@@ -26,7 +26,6 @@ struct wcsph_ctx {
   bool hist_inc = false;         // the update in progress does so
   int n_hist_inc = 0;            // how many updates did (WCSPH_S_TABLE_UPDATES_IN_PLACE)
   bool bcount_int_valid = false; // the int table (gridCount) matches the byte table (k_bucket_sum wrote both; k_bucket_expand on demand)
-  int hchk_gen = 0;              // generation number of flags[FLAG_HCHK]
   int warm_gen = 0;              // generation number of flags[FLAG_WARM] (api_dfsph.h update_vel_warm_start)
   int hb_gen = 0;                // generation number of the binned histogram's overflow flag (grid.h k_hash_bin)
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ

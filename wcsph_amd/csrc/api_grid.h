@@ -58,12 +58,11 @@ static int grid_assign(wcsph_ctx *ctx, bool single = false) {   // single: wcsph
   // decomposition, an update that did not run to its end, a cap a byte cannot hold with a margin -- rebuilds it.
   ctx->hist_inc = single && d.faithful && ctx->hist_valid && d.max_in_grid <= 200 && d.n_owned >= d.nl && ctx->win_x1 < 0;
   ctx->hist_valid = false;
-  const int gen = ctx->hist_inc ? (ctx->hchk_gen = ctx->hchk_gen == 0x7fffffff ? 1 : ctx->hchk_gen + 1) : 0;
   if (ctx->hist_inc) { ctx->bcount_int_valid = false; ctx->n_hist_inc++; }
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
                        (int *)nullptr, ctx->bbox_part, d.n_owned,
-                       d.faithful ? ctx->region_occ : (int *)nullptr, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr, gen);
+                       d.faithful ? ctx->region_occ : (int *)nullptr, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr);
   if (d.faithful && !ctx->hist_inc) { int rc_ = bucket_hist_launches(ctx, s); if (rc_) return rc_; }   // (a slab: before the all-reduce)
   LAUNCHCHK();
   ctx->grid_stage = 1;
@@ -74,11 +73,7 @@ static int grid_sort(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
-  if (ctx->hist_inc)
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox,
-                       (const unsigned char *)ctx->bcount8, d.table_size, d.max_in_grid, d.flags, ctx->hchk_gen);
-  else
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
+  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
   if (d.nl > 0) {

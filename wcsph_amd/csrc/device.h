@@ -90,7 +90,7 @@ struct Dev {
 };
 
 enum { ACC_ERR = 0, ACC_DAD = 1, ACC_DNEW = 2, ACC_DZERO = 3 };
-enum { FLAG_ERR = 0, FLAG_VMAX = 1, FLAG_DT = 2, FLAG_WARM = 4 + 64, FLAG_HCHK = 4 + 64 + 1 };   // [4, 68): striped vmax; FLAG_WARM: generation number of the last step whose warm-start gate opened; FLAG_HCHK: of the last grid update whose incremental bucket table met the cap   // FLAG_DT: bits of the deltaT k_cfl_store formed (speculative steps)
+enum { FLAG_ERR = 0, FLAG_VMAX = 1, FLAG_DT = 2, FLAG_WARM = 4 + 64 };   // [4, 68): striped vmax; FLAG_WARM: generation number of the last step whose warm-start gate opened   // FLAG_DT: bits of the deltaT k_cfl_store formed (speculative steps)
 enum { ERRBIT_BUCKET = 1, ERRBIT_NEIGH = 2, ERRBIT_LISTCAP = 4, ERRBIT_NONFINITE = 8, ERRBIT_ROWITEMS = 16 };
 
 __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }

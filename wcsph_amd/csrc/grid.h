@@ -47,11 +47,11 @@ __device__ __forceinline__ int region_of_cell(const Dev &d, int w) {   // w: pac
 // inc8 != nullptr (one faithful context, between two of its own updates: api_grid.h grid_assign): the byte table of the reference
 // bucket occupancy is kept UP TO DATE instead of being rebuilt -- a particle's previous cell travels with it in pos.w (the sort
 // writes it there, every position update keeps it), so only a particle that changed its cell touches the table: one count less
-// in its old bucket, one more in the new one (32-bit atomics on the containing word).  An increment that finds the bucket at the cap
-// raises flags[FLAG_HCHK] = gen: k_bbox_final then re-checks the table (the order of the atomics is arbitrary: a bucket that one
-// particle leaves and another enters in the same update may pass the cap for a moment).
+// in its old bucket, one more in the new one (32-bit atomics on the containing word, no value returned).  The cap is checked by
+// k_cellval_occ, which reads the count of every cell that holds a particle AFTER all of the update's atomics (a bucket that one
+// particle leaves and another enters in the same update may pass the cap for a moment, whichever atomic lands first).
 __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox, int count_limit, int *occ = nullptr,
-                                                      unsigned *inc8 = nullptr, int gen = 0) {
+                                                      unsigned *inc8 = nullptr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
   if (i < n) {
@@ -71,9 +71,8 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
           atomicSub(&inc8[h >> 2], 1u << ((h & 3) * 8));
         }
         if (w >= 0) {
-          const int h = ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size), sh = (h & 3) * 8;
-          const unsigned old = atomicAdd(&inc8[h >> 2], 1u << sh);
-          if (((old >> sh) & 255u) >= (unsigned)d.max_in_grid) d.flags[FLAG_HCHK] = gen;
+          const int h = ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size);
+          atomicAdd(&inc8[h >> 2], 1u << ((h & 3) * 8));
         }
       }
     }
@@ -186,16 +185,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *p
   }
 }
 // one block: reduce the per-block boxes of k_cell_assign into out[6] = {xmin,ymin,zmin,xmax,ymax,zmax} (max < 0: empty)
-// b8 != nullptr (incremental bucket table, see k_cell_assign): when an increment met a bucket at the cap in this update
-// (flags[FLAG_HCHK] == gen), the table is re-checked here, after all of the update's atomics: any count above the cap is the
-// reference's error (HashGrid.py:72-74); one workgroup over 3 MB, but only then.
-__global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out, const unsigned char *b8 = nullptr, int T = 0, int cap = 0,
-                                                     int *flags = nullptr, int gen = 0) {
-  if (b8 && flags[FLAG_HCHK] == gen) {
-    bool over = false;
-    for (int b = threadIdx.x; b < T; b += BLOCK) over |= (int)b8[b] > cap;
-    if (over) atomicOr(&flags[FLAG_ERR], ERRBIT_BUCKET);
-  }
+__global__ void __launch_bounds__(BLOCK) k_bbox_final(const int *part, int nparts, int *out) {
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
   for (int b = threadIdx.x; b < nparts; b += BLOCK)
 #pragma unroll
@@ -547,7 +537,10 @@ __global__ void __launch_bounds__(BLOCK) k_cellval_occ(Dev d, const T *bcount, c
     const unsigned sel = ((m0 & 1u) ? s1 : 0u) | ((m0 & 2u) ? s1 << 9 : 0u) | ((m0 & 4u) ? s1 << 18 : 0u);
     if ((m & sel) && a0 < n0 && a1 < n1 && z < d.nz) {
       const int x = d.perm ? a1 : a0, y = d.perm ? a0 : a1;
-      cellval[(x * d.ny + y) * d.nz + z] = (int)bcount[ref_hash(x + d.x0, y, z, d.table_size)];
+      const int v = (int)bcount[ref_hash(x + d.x0, y, z, d.table_size)];
+      cellval[(x * d.ny + y) * d.nz + z] = v;
+      // the reference's cap (HashGrid.py:72-74) where the table is updated in place: every cell that holds a particle is read here
+      if (v > d.max_in_grid) atomicOr(&d.flags[FLAG_ERR], ERRBIT_BUCKET);
     }
   }
 }
