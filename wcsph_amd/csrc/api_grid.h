@@ -46,10 +46,10 @@ static int grid_assign(wcsph_ctx *ctx, bool single = false) {   // single: wcsph
   ctx->pr_valid = false;   // rows are re-sorted
   // the liquid bucket histogram and the region flags are zero here: their consumers (k_bucket_sum, k_ncount_box) clear
   // them -- unless the previous update did not run to its end
-  if (d.faithful && ctx->hist_dirty) {
-    HIPCHK(hipMemsetAsync(ctx->bcount_l, 0, (size_t)d.table_size * sizeof(int), s));
+  if (ctx->hist_dirty) {
     HIPCHK(hipMemsetAsync(ctx->region_occ, 0, (size_t)ctx->n_regions * sizeof(int), s));
-    if (ctx->hb_bins) HIPCHK(hipMemsetAsync(ctx->hb_bins, 0, (HB_MAXBINS + 1) * sizeof(int), s));
+    if (d.faithful) HIPCHK(hipMemsetAsync(ctx->bcount_l, 0, (size_t)d.table_size * sizeof(int), s));
+    if (d.faithful && ctx->hb_bins) HIPCHK(hipMemsetAsync(ctx->hb_bins, 0, (HB_MAXBINS + 1) * sizeof(int), s));
   }
   ctx->hist_dirty = true;
   // One faithful context between two of its own complete updates: the byte table of the bucket occupancy is UPDATED by
@@ -62,7 +62,7 @@ static int grid_assign(wcsph_ctx *ctx, bool single = false) {   // single: wcsph
   if (d.nl > 0)
     hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
                        (int *)nullptr, ctx->bbox_part, d.n_owned,
-                       d.faithful ? ctx->region_occ : (int *)nullptr, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr);
+                       ctx->region_occ, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr);
   if (d.faithful && !ctx->hist_inc) { int rc_ = bucket_hist_launches(ctx, s); if (rc_) return rc_; }   // (a slab: before the all-reduce)
   LAUNCHCHK();
   ctx->grid_stage = 1;
@@ -114,7 +114,10 @@ static void neighbor_count_launches(wcsph_ctx *ctx, hipStream_t s, bool box) {
 static int grid_counts(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   if (d.faithful) { neighbor_count_launches(ctx, ctx->stream, false); neighbor_count_launches(ctx, ctx->stream, true); }
-  else if (d.nl > 0) hipLaunchKernelGGL(k_ncount_clean, dim3(nblk(d.nl)), dim3(BLOCK), 0, ctx->stream, d);
+  else if (d.nl > 0) {   // clean: the same box sums over the cells' own occupancy (no hash table)
+    hipLaunchKernelGGL(k_cellval_clean, dim3(ctx->n_regions), dim3(BLOCK), 0, ctx->stream, d, (const int *)ctx->region_occ, ctx->cellval);
+    hipLaunchKernelGGL(k_ncount_box, dim3(ctx->n_regions), dim3(BLOCK), 0, ctx->stream, d, (const int *)ctx->cellval, (const int *)ctx->region_occ);
+  }
   LAUNCHCHK();
   return 0;
 }

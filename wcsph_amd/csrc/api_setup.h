@@ -160,12 +160,13 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
 #endif
       DALLOC(ctx->hb_bins, HB_MAXBINS + 1); DALLOC(ctx->hb_buf, (size_t)ctx->hb_nbins * ctx->hb_cap);
     }   // [T] stays 0: the scan's end sentinel
-    DALLOC(ctx->cellval, d.ncell); DALLOC(ctx->bcount8, d.table_size + 1);
-    {
-      const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
-      ctx->n_regions = ((n0 + BC0 - 1) / BC0) * ((n1 + BC1 - 1) / BC1) * ((d.nz + BCZ - 1) / BCZ);
-      DALLOC(ctx->region_occ, (size_t)ctx->n_regions);
-    }
+    DALLOC(ctx->bcount8, d.table_size + 1);
+  }
+  {  // neighborCount by regions (grid.h k_ncount_box), both neighbour modes
+    DALLOC(ctx->cellval, d.ncell);
+    const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
+    ctx->n_regions = ((n0 + BC0 - 1) / BC0) * ((n1 + BC1 - 1) / BC1) * ((d.nz + BCZ - 1) / BCZ);
+    DALLOC(ctx->region_occ, (size_t)ctx->n_regions);
   }
   // liquids: identity order until the first grid update
   std::vector<float4> tmp((size_t)(d.nl > d.ns ? d.nl : d.ns));

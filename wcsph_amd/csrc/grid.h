@@ -544,6 +544,45 @@ __global__ void __launch_bounds__(BLOCK) k_cellval_occ(Dev d, const T *bcount, c
     }
   }
 }
+// clean neighbour mode: the cell's own occupancy (liquid + boundary particles) instead of gridCount[hash(cell)]; the same
+// regions, the same shell rule, the reference's cap on the cell (ref: HashGrid.py:72-74 without the aliasing)
+__global__ void __launch_bounds__(BLOCK) k_cellval_clean(Dev d, const int *occ, int *cellval) {
+  const Regions R = regions_of(d);
+  const int bz = blockIdx.x % R.nbz, q = blockIdx.x / R.nbz, r1 = q % R.nb1, r0 = q / R.nb1;
+  __shared__ unsigned occ27;
+  if (threadIdx.x == 0) occ27 = 0;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int e0 = r0 + threadIdx.x / 9 - 1, e1 = r1 + (threadIdx.x / 3) % 3 - 1, ez = bz + threadIdx.x % 3 - 1;
+    if ((unsigned)e0 < (unsigned)R.nb0 && (unsigned)e1 < (unsigned)R.nb1 && (unsigned)ez < (unsigned)R.nbz && occ[(e0 * R.nb1 + e1) * R.nbz + ez])
+      atomicOr(&occ27, 1u << threadIdx.x);
+  }
+  __syncthreads();
+  const unsigned m = occ27;
+  if (!m) return;
+  const int n0 = d.perm ? d.ny : d.nx, n1 = d.perm ? d.nx : d.ny;
+#pragma unroll
+  for (int k = 0; k < BC0 * BC1 * BCZ / BLOCK; k++) {
+    const int t = threadIdx.x + k * BLOCK;
+    const int lz = t % BCZ, u = t / BCZ, l1 = u % BC1, l0 = u / BC1;
+    const int z = bz * BCZ + lz, a1 = r1 * BC1 + l1, a0 = r0 * BC0 + l0;
+    const unsigned mz = 2u | (lz < 2 ? 1u : 0u) | (lz >= BCZ - 2 ? 4u : 0u), m1 = 2u | (l1 < 2 ? 1u : 0u) | (l1 >= BC1 - 2 ? 4u : 0u),
+                   m0 = 2u | (l0 < 2 ? 1u : 0u) | (l0 >= BC0 - 2 ? 4u : 0u);
+    const unsigned s1 = ((m1 & 1u) ? mz : 0u) | ((m1 & 2u) ? mz << 3 : 0u) | ((m1 & 4u) ? mz << 6 : 0u);
+    const unsigned sel = ((m0 & 1u) ? s1 : 0u) | ((m0 & 2u) ? s1 << 9 : 0u) | ((m0 & 4u) ? s1 << 18 : 0u);
+    if ((m & sel) && a0 < n0 && a1 < n1 && z < d.nz) {
+      const int x = d.perm ? a1 : a0, y = d.perm ? a0 : a1;
+      const int c = cell_lin(d, x, y, z);
+      // the liquid cell table is current only within two cells of the occupied box (the scan skips the rest: scan_block_active);
+      // a cell farther out holds no liquid particle and is read by no box sum of one that does
+      const int *bb = d.bbox;
+      const bool near = x >= bb[0] - 2 && x <= bb[3] + 2 && y >= bb[1] - 2 && y <= bb[4] + 2 && z >= bb[2] - 2 && z <= bb[5] + 2;
+      const int v = (near ? d.cs_l[c + 1] - d.cs_l[c] : 0) + d.cs_s[c + 1] - d.cs_s[c];
+      cellval[(x * d.ny + y) * d.nz + z] = v;
+      if (v > d.max_in_grid) atomicOr(&d.flags[FLAG_ERR], ERRBIT_BUCKET);
+    }
+  }
+}
 __global__ void __launch_bounds__(BLOCK) k_ncount_box(Dev d, const int *cellval, const int *occ) {
   __shared__ int b0[(BC0 + 4) * (BC1 + 4) * (BCZ + 4)];
   __shared__ int b1[(BC0 + 4) * (BC1 + 4) * BCZ];
@@ -615,33 +654,6 @@ __global__ void __launch_bounds__(BLOCK) k_ncount_box(Dev d, const int *cellval,
   }
   if (threadIdx.x == 0) const_cast<int *>(occ)[blockIdx.x] = 0;   // k_cellval_occ, the other reader, has finished
 }
-// clean: every particle of the in-box 5x5x5 cells once, minus the particle itself
-__global__ void k_ncount_clean(Dev d) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl) return;
-  int w = __float_as_int(d.pos[i].w);
-  int cnt = 0;
-  if (w >= 0) {
-    int cx = w & 1023, cy = (w >> 10) & 1023, cz = w >> 20;
-    int z0 = max(cz - 2, 0), z1 = min(cz + 2, d.nz - 1) + 1;
-    for (int dx = -2; dx <= 2; dx++) {
-      int x = cx + dx;
-      if ((unsigned)x >= (unsigned)d.nx) continue;
-      for (int dy = -2; dy <= 2; dy++) {
-        int y = cy + dy;
-        if ((unsigned)y >= (unsigned)d.ny) continue;
-        const RowPieces rl = row_pieces(d, d.cs_l, x, y, z0, z1), rs = row_pieces(d, d.cs_s, x, y, z0, z1);
-        cnt += (rl.hi0 - rl.lo0) + (rl.hi1 - rl.lo1) + (rs.hi0 - rs.lo0) + (rs.hi1 - rs.lo1);
-      }
-    }
-    cnt -= 1;
-    int c = cell_lin(d, cx, cy, cz);
-    if (d.cs_l[c + 1] - d.cs_l[c] + d.cs_s[c + 1] - d.cs_s[c] > d.max_in_grid) atomicOr(&d.flags[FLAG_ERR], ERRBIT_BUCKET);
-  }
-  if (cnt > d.max_neighbour) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NEIGH);
-  d.ncount[i] = cnt;
-}
-
 // Compact per-step neighbour lists: the in-support entries of the reference's neighbour row, with the
 // bucket-multiset multiplicity expanded into repeated entries (ref: HashGrid.py:88-106).
 // (Measured and rejected, r02: parking the plane's 20 cell-table ranges in LDS and testing candidates four at a time
