@@ -397,13 +397,13 @@ def test_speculative_step_falls_back_when_a_solver_goes_on(n, steps, squeeze):
     pd.close(); o.close()
 
 
-def _rebuilt_counts(g, nl, max_in_grid=64):
-    """gridCount / neighborCount / overflow of a FRESH oracle on the library's current positions (a full rebuild by definition)"""
-    o2 = Oracle(g.pd.pos.to_numpy(), nl, 0.025, mode="faithful", maxInGrid=max_in_grid)
-    o2.update_grid()
-    out = (np.array(o2.gridCount), np.array(o2.neighborCount), o2.overflow_grid)
-    o2.close()
-    return out
+def _rebuilt_counts(g, o):
+    """gridCount / neighborCount / overflow of the oracle's update_grid() on the library's current positions (a rebuild by
+    definition; the SAME oracle throughout: the grid box is that of the initial positions, as the library's)"""
+    o.pos[...] = g.pd.pos.to_numpy()
+    before = o.overflow_grid
+    o.update_grid()
+    return np.array(o.gridCount), np.array(o.neighborCount), o.overflow_grid - before
 
 
 def test_bucket_table_updated_in_place_equals_a_rebuilt_one():
@@ -414,7 +414,6 @@ def test_bucket_table_updated_in_place_equals_a_rebuilt_one():
     on the same positions, every time; a position upload in between (which falls back to a rebuild) changes nothing."""
     from wcsph_amd import dfsph
     g, o = make_pair(10, "faithful", jitter=0.4)
-    o.close()
     nl = g.pd.liquid_count
     g.call("dfsph_reset_param")
     g.pd.vel.from_numpy(_random_vel(nl, scale=1.5))
@@ -424,7 +423,7 @@ def test_bucket_table_updated_in_place_equals_a_rebuilt_one():
         g.call("dfsph_step")
         if s % 4 == 3:
             g.pd.hash_grid.update_grid()
-            gc, nc, ovf = _rebuilt_counts(g, nl)
+            gc, nc, ovf = _rebuilt_counts(g, o)
             assert ovf == 0
             np.testing.assert_array_equal(g.pd.hash_grid.gridCount, gc, err_msg="step %d" % s)
             np.testing.assert_array_equal(g.pd.hash_grid.neighborCount.to_numpy()[:nl], nc[:nl], err_msg="step %d" % s)
@@ -435,7 +434,7 @@ def test_bucket_table_updated_in_place_equals_a_rebuilt_one():
             p = g.pd.pos.to_numpy(); p[:nl] += np.float32(1e-3); g.pd.pos.from_numpy(p)
     assert changed > 100          # the table did change under the test
     assert g.scalar("table_updates_in_place") >= 46     # 40 steps + 10 explicit updates, less the first and the rebuild after the upload
-    g.close()
+    g.close(); o.close()
 
 
 def test_bucket_cap_with_the_table_updated_in_place():
