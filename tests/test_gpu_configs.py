@@ -37,13 +37,99 @@ def _one_step(n, mode, need_gb, liquid=None, boundary=None, steps=1, **attrs):
         assert abs(dt - o.deltaT) <= 1e-6 * o.deltaT
         np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)   # exact raw list length
     rho = pd.rho.to_numpy()
-    assert np.abs(rho - o.rho).max() / o.rho.max() < 1e-4          # north star: per-particle density error <= 1e-4
+    assert np.abs(rho - o.rho).max() / o.rho.max() < 1e-5          # north star: per-particle density error <= 1e-4
     assert np.abs(pd.pos.to_numpy()[:nl] - o.pos[:nl]).max() < 2e-6
     v = pd.vel.to_numpy()
-    assert np.abs(v - o.vel).max() < 2e-3 * max(np.abs(o.vel).max(), 1e-3)
+    # from rest the fields are small (|v| ~ g dt): the bound is relative to the field's own maximum, as in test_reference_fixtures
+    assert np.abs(v - o.vel).max() < 1e-4 * max(np.abs(o.vel).max(), 1e-3)
     for name, a, b in (("kappa", dfsph.kappa.to_numpy(), o.kappa), ("kappa_v", dfsph.kappa_v.to_numpy(), o.kappa_v)):
-        assert np.abs(a - b).max() <= 2e-3 * max(np.abs(b).max(), 1e-6), name     # DFSPH's "pressure" fields (Q14)
+        assert np.abs(a - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-6), name     # DFSPH's "pressure" fields (Q14)
     return pd, o, dfsph
+
+
+# ---- the same sizes on a LIVE state (VERDICT r04 "missing" 3): from rest v = 0 and omega = 0, most neighbour sums are identically
+# zero and the solvers run their minimum iteration counts; here every term of every pass contributes ---------------------------------
+def live_state(n, squeeze=False, seed=20240901):
+    """The state of tests/golden/make_reference_fixtures.py `perturb()` (positions jittered by +-0.2 R, a smooth velocity and spin
+    field) at particleDim = n, the wavelengths scaled with the block so that the fields keep the fixture's shape; squeeze: the
+    x >= 0 half of the block compressed to 0.9 of its spacing about its centroid (`squeeze_half`), so that the divergence and
+    the pressure solver iterate."""
+    from wcsph_amd import scene
+    liquid, solid = scene.dam_break_dfsph(n)
+    rng = np.random.default_rng(seed)
+    liquid = liquid + rng.uniform(-0.2, 0.2, liquid.shape) * scene.PARTICLE_RADIUS
+    if squeeze:
+        sel = np.arange(len(liquid)) >= (n // 2) * n * n           # x-planes n/2 .. n-1 (index order: dfsph.py:69-73)
+        c = liquid[sel].mean(0)
+        liquid[sel] = c + 0.9 * (liquid[sel] - c)
+    liquid = liquid.astype(np.float32).astype(np.float64)
+    s = 20.0 / n
+    x, y, z = (liquid[:, k] * s for k in range(3))
+    vel = 0.5 * np.stack([np.sin(3.0 * y), np.cos(2.0 * x + z) - 0.3, np.sin(x - 2.0 * z)], 1)
+    omega = 0.2 * np.stack([np.cos(4.0 * z), np.sin(3.0 * x), np.cos(2.0 * y + x)], 1)
+    return liquid, solid, vel.astype(np.float32), omega.astype(np.float32)
+
+
+def _quantiles(name, a, b, floor=1e-30):
+    """per-particle error relative to the field's maximum: (max, 0.9999 quantile, particles beyond 5e-5)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), floor)
+    d = np.abs(a - b).reshape(len(a), -1).max(axis=1) / scale
+    q = (float(d.max()), float(np.quantile(d, 0.9999)), int((d > 5e-5).sum()))
+    print("live-state parity %-10s max %.2e  q9999 %.2e  beyond 5e-5: %d of %d" % ((name,) + q + (len(d),)))
+    return q
+
+
+def _live_steps(n, mode, need_gb, steps, squeeze, expect_iterating=False):
+    if _host_gb() < need_gb:
+        pytest.skip("oracle needs ~%d GB of free host memory for this size" % need_gb)
+    from oracle import Oracle
+    from wcsph_amd import dfsph
+    liquid, solid, vel0, omega0 = live_state(n, squeeze)
+    pd = dfsph.init_particle(particleDim=n, neighbor_mode=mode, liquid=liquid, boundary=solid)
+    nl = pd.liquid_count
+    o = Oracle(pd.pos.to_numpy(), nl, 0.025, mode=mode)
+    dfsph.reset_param(); o.reset_param()
+    pd.vel.from_numpy(vel0); pd.omega.from_numpy(omega0)
+    o.vel[...] = vel0; o.omega[...] = omega0
+    iters = []
+    for s in range(steps):
+        dt = dfsph.step()
+        o.dfsph_step()
+        iters.append((o.vs_iter, o.dv_iter, o.pr_iter))
+        assert (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter) == iters[-1], (s, iters)
+        assert abs(dt - o.deltaT) <= 1e-6 * (s + 1) * o.deltaT
+        np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)   # exact raw list length
+        # Every particle to the tolerances of the reference-text fixtures (tests/test_reference_fixtures.py: rho 1e-5, solver
+        # fields 5e-5 of the field's maximum) -- except the handful the reference's own discontinuities may flip at this
+        # size: `if adv_rho[i] > 0` (dfsph.py:421) and `max(.., 0)` (:391) give a particle whose sum is zero to rounding the
+        # whole warm-start kick or none, depending on the order its ~35 terms were summed in (the library's list order is the
+        # sort's, the oracle's the reference's; tests/test_gpu_developed_state.py).  Such a particle and its neighbourhood may
+        # exceed 5e-5; nobody may exceed 1e-3 and the 0.9999 quantile stays inside 5e-5.
+        few = 3 + 40
+        rq = _quantiles("rho", pd.rho.to_numpy(), o.rho)
+        assert rq[0] < 1e-5 * (s + 1), rq                                                         # north star: <= 1e-4
+        for name, a, b in (("vel", pd.vel.to_numpy(), o.vel), ("kappa", dfsph.kappa.to_numpy(), o.kappa), ("kappa_v", dfsph.kappa_v.to_numpy(), o.kappa_v),
+                           ("omega", pd.omega.to_numpy(), o.omega), ("vel_guess", pd.vel_guess.to_numpy(), o.vel_guess), ("adv_rho", pd.adv_rho.to_numpy(), o.adv_rho)):
+            q = _quantiles(name, a, b, 1e-6)
+            assert q[1] <= 5e-5 * (s + 1) and q[2] <= few * (s + 1) and q[0] < 1e-3, (name, s, q)
+        assert np.abs(pd.pos.to_numpy()[:nl] - o.pos[:nl]).max() < 2e-6 * (s + 1)
+    if expect_iterating:
+        assert max(i[2] for i in iters) > 2 or max(i[1] for i in iters) > 1, iters              # the solvers did iterate
+    print("live-state iteration counts (vs, dv, pr):", iters)
+    pd.close(); o.close()
+
+
+@pytest.mark.parametrize("mode", ["faithful", "clean"])
+def test_C2_100k_live_squeezed_steps(mode):
+    """C2 (46^3) from the perturbed state with a 0.9-squeezed half: both solvers iterate; two steps, every field."""
+    _live_steps(46, mode, 3, 2, squeeze=True, expect_iterating=True)
+
+
+def test_C3_2M_perturbed_step():
+    """The headline configuration on a live state: 126^3 jittered by +-0.2 R with the smooth velocity / spin field of the
+    reference-text fixtures scaled to the block; two full steps against the oracle (ref: dfsph.py:606-617)."""
+    _live_steps(126, "faithful", 24, 2, squeeze=False)
 
 
 @pytest.mark.parametrize("mode", ["faithful", "clean"])

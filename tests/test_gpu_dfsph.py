@@ -490,6 +490,67 @@ def test_bucket_cap_with_the_table_updated_in_place():
     g.close()
 
 
+@pytest.mark.parametrize("how", ["rebuild_clamps", "in_place_saturates"])
+def test_bucket_table_heals_after_a_cap_error(how):
+    """the byte table of the bucket occupancy must not stay wrong after a cap error that the caller steps past
+    (include/wcsph.h allows that).  rebuild_clamps: 300 particles in one cell at the first update -- k_bucket_sum clamps the
+    byte at 255 and reports -3.  in_place_saturates: 60 in the cell, then 200 more arrive by update_pos -- the in-place
+    update (k_cell_assign) saturates the byte at 255 instead of carrying into the next bucket's count, and reports -3.
+    Either way the update after the report REBUILDS the table: once the crowd has left, gridCount and neighborCount equal
+    those of an oracle built on the same positions (ref: HashGrid.py:67-76)."""
+    from wcsph_amd._lib import WcsphError
+    import util
+    R = 0.025
+    solid = np.array([[-0.1, -0.1, -0.1], [2.0, 2.0, 2.0]], np.float32)
+    n = 300
+    k = np.arange(n)
+    site = np.stack([0.12 + 0.1 * (k % 15), 0.12 + 0.1 * ((k // 15) % 15), 1.02 + 0.1 * (k // 225)], 1).astype(np.float32)
+    crowd = (np.array([0.52, 0.52, 0.52], np.float32) + 1e-4 * np.stack([k % 7, (k // 7) % 7, k // 49], 1)).astype(np.float32)
+    stay = 50
+    apart = site.copy(); apart[:stay] = crowd[:stay]              # what is left once the crowd has gone: 50 in the cell (cap 64)
+    if how == "rebuild_clamps":
+        start, packed = crowd.copy(), None
+    else:
+        start = site.copy(); start[:60] = crowd[:60]
+        packed = site.copy(); packed[:260] = crowd[:260]
+    g = util.GpuSim(start, solid, mode="faithful")
+    g.pd.hash_grid.update_grid()
+
+    def move(target):
+        p = g.pd.pos.to_numpy()[:n]
+        g.pd.vel.from_numpy(((target - p) / np.float32(0.01)).astype(np.float32))
+        g.deltaT[0] = 0.01
+        g.call("dfsph_update_pos")
+        g.pd.hash_grid.update_grid()
+
+    if packed is not None:
+        g.pd.sync()                                                # 60 in the cell: no error yet
+        move(packed)                                               # 260: the byte saturates
+        assert g.scalar("table_updates_in_place") == 1
+    with pytest.raises(WcsphError) as e:
+        g.pd.sync()
+    assert e.value.code in (-3, -4)                                # (the 300-entry lists of the crowd trip their own cap as well)
+    move(apart)
+    for _ in range(3):                                             # every condition is handed over once
+        try:
+            g.pd.sync()
+            break
+        except WcsphError:
+            g.pd.hash_grid.update_grid()
+    pos = g.pd.pos.to_numpy()
+    o2 = Oracle(pos, n, R, mode="faithful", bounds=(g.pd.maxboundarynp, g.pd.minboundarynp))
+    o2.update_grid()
+    assert o2.overflow_grid == 0
+    np.testing.assert_array_equal(g.pd.hash_grid.gridCount, o2.gridCount)
+    np.testing.assert_array_equal(g.pd.hash_grid.neighborCount.to_numpy()[:n], np.array(o2.neighborCount)[:n])
+    move(apart + np.float32(0.003))                                # and the table is updated in place again afterwards
+    g.pd.sync()
+    o2.pos[:n] = g.pd.pos.to_numpy()[:n]
+    o2.update_grid()
+    np.testing.assert_array_equal(g.pd.hash_grid.gridCount, o2.gridCount)
+    g.close(); o2.close()
+
+
 def test_neighbor_count_follows_moving_particles_update_after_update():
     """Faithful mode, one context: twelve grid updates in a row on moving particles (positions uploaded: every update rebuilds
     the bucket table), each read back at once: neighborCount and gridCount equal the oracle's every time (a histogram / region

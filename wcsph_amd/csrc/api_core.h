@@ -119,6 +119,9 @@ static int dalloc(wcsph_ctx *ctx, T **p, size_t n) {
 
 static int check_flags(wcsph_ctx *ctx) {
   int f = ctx->h_flags[FLAG_ERR];
+  // a bucket beyond the cap: the byte table may be clamped (k_bucket_sum at 255) or saturated (k_cell_assign) -- it is REBUILT by the
+  // next grid update instead of being updated in place, and by every one after it for as long as the condition is reported
+  if (f & ERRBIT_BUCKET) ctx->hist_valid = false;
   if (f & ERRBIT_BUCKET) return ctx->fail(WCSPH_EBUCKET, "more than maxInGrid particles in one hash bucket (ref: HashGrid.py:72-74)");
   if (f & ERRBIT_NEIGH) return ctx->fail(WCSPH_ENEIGH, "more than maxNeighbour neighbour-list entries (ref: HashGrid.py:100-103)");
   if (f & ERRBIT_LISTCAP) return ctx->fail(WCSPH_ENEIGH, "compact neighbour list capacity (wcsph_params.list_cap, default 256 slots of one kind) exceeded");

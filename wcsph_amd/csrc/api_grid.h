@@ -56,7 +56,11 @@ static int grid_assign(wcsph_ctx *ctx, bool single = false) {   // single: wcsph
   // k_cell_assign (particles that changed their cell: ~5 % of them per step at rest, 10-20 % in the developed flow) instead of
   // being rebuilt by the histogram kernels + k_bucket_sum (50 us alone at C3).  Anything else -- the first update, a slab of a
   // decomposition, an update that did not run to its end, a cap a byte cannot hold with a margin -- rebuilds it.
-  ctx->hist_inc = single && d.faithful && ctx->hist_valid && d.max_in_grid <= 200 && d.n_owned >= d.nl && ctx->win_x1 < 0;
+  // (the default owned column range: a rebuild counts only particles inside [own_lo, own_hi), wcsph_set_owned_columns; the in-place
+  // update moves every row's count.  In-place mode checks the cap where particles are, in and next to occupied regions
+  // (k_cellval_occ); a rebuild checks every bucket (k_bucket_sum).)
+  ctx->hist_inc = single && d.faithful && ctx->hist_valid && d.max_in_grid <= 200 && d.n_owned >= d.nl && ctx->win_x1 < 0 &&
+                  d.own_lo <= 0 && d.own_hi >= ctx->bs[0];
   ctx->hist_valid = false;
   if (ctx->hist_inc) { ctx->bcount_int_valid = false; ctx->n_hist_inc++; }
   if (d.nl > 0)

@@ -111,7 +111,13 @@ int wcsph_sync(wcsph_ctx *ctx) {
 static int run_scan(wcsph_ctx *ctx, int *in, int n, int *out, const int *bbox, int clear = 0) {
   int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, ctx->stream, ctx->d, (const int *)in, n, ctx->bsum, bbox);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, ctx->d, in, n, (const int *)ctx->bsum, out, bbox, clear);
+  const int *bpre = nullptr;
+  if (nb > SCAN_BPRE_MIN) {   // (bsum holds 2 * (scan_blocks + 1) words: the totals, then their exclusive prefix)
+    int *pre = ctx->bsum + ctx->scan_blocks + 1;
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, (const int *)ctx->bsum, nb, pre);
+    bpre = pre;
+  }
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, ctx->stream, ctx->d, in, n, (const int *)ctx->bsum, out, bbox, clear, bpre);
   LAUNCHCHK();
   return 0;
 }
@@ -146,7 +152,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
   d.minx = minb[0]; d.miny = minb[1]; d.minz = minb[2];
   const int nscan = d.ncell_p + 2;
   ctx->scan_blocks = ((nscan > d.table_size + 2 ? nscan : d.table_size + 2) + SCAN_TILE - 1) / SCAN_TILE;   // also scans the bucket table (bucket.h)
-  DALLOC(ctx->cnt, nscan); DALLOC(d.cs_l, nscan); DALLOC(d.cs_s, nscan); DALLOC(ctx->bsum, ctx->scan_blocks + 1);
+  DALLOC(ctx->cnt, nscan); DALLOC(d.cs_l, nscan); DALLOC(d.cs_s, nscan); DALLOC(ctx->bsum, 2 * ((size_t)ctx->scan_blocks + 1));
   DALLOC(d.cell_info, d.ncell_p);
   DALLOC(d.bbox, 8); DALLOC(ctx->bbox_part, 6 * (size_t)(nblk(ctx->capacity) + 1));
   if (d.faithful) {

@@ -72,7 +72,11 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
         }
         if (w >= 0) {
           const int h = ref_hash((w & 1023) + d.x0, (w >> 10) & 1023, w >> 20, d.table_size);
-          atomicAdd(&inc8[h >> 2], 1u << ((h & 3) * 8));
+          // saturating: a byte at 255 stays there (the add is taken back) instead of carrying into the next bucket's count, and the
+          // cap is reported; the host then rebuilds the table at the next update (api_core.h check_flags)
+          const unsigned sh = (h & 3) * 8;
+          const unsigned old = atomicAdd(&inc8[h >> 2], 1u << sh);
+          if (((old >> sh) & 255u) == 255u) { atomicSub(&inc8[h >> 2], 1u << sh); atomicOr(&d.flags[FLAG_ERR], ERRBIT_BUCKET); }
         }
       }
     }
@@ -332,7 +336,22 @@ __global__ void k_scan_reduce(Dev d, const int *in, int n, int *bsum, const int 
 // The one-launch alternative, decoupled look-back, lost: profiles/r04_experiments.md (3))
 // clear != 0: the counters are zeroed as they are consumed, so the next grid update needs no 65 MB memset (only
 // cells of the active blocks can be non-zero: every counted particle lies inside the occupied box or in the last bin)
-__global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, const int *bbox, int clear) {
+// Grids with many scan blocks (> SCAN_BPRE_MIN: beyond ~16 M cells) would have every active block re-read up to MBs of block
+// totals: there the totals are prefix-summed once by a one-block launch (k_scan_bsums) and k_scan_final reads one word (bpre).
+#define SCAN_BPRE_MIN 8192
+__global__ void __launch_bounds__(1024) k_scan_bsums(const int *bsum, int nb, int *bpre) {
+  __shared__ int part[1024];
+  const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, nb);
+  int s = 0;
+  for (int k = lo; k < hi; k++) s += bsum[k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < 1024; k++) { const int t = part[k]; part[k] = run; run += t; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int k = lo; k < hi; k++) { bpre[k] = run; run += bsum[k]; }
+}
+__global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, const int *bbox, int clear, const int *bpre = nullptr) {
   if (!scan_block_active(d, bbox, n)) return;
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   static_assert(SCAN_PER_THREAD == 8, "two 16-byte accesses per thread");
@@ -355,7 +374,8 @@ __global__ void k_scan_final(Dev d, int *in, int n, const int *bsum, int *out, c
   }
   // the sum of the block totals before this block (bsum: raw totals, k_scan_reduce)
   int before = 0;
-  for (int k = threadIdx.x; k < (int)blockIdx.x; k += BLOCK) before += bsum[k];
+  if (bpre) { if (threadIdx.x == 0) before = bpre[blockIdx.x]; }
+  else for (int k = threadIdx.x; k < (int)blockIdx.x; k += BLOCK) before += bsum[k];
   int tot;
   int ex = block_exclusive_scan(s, &tot);
   ex += block_sum(before);
