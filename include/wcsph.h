@@ -263,6 +263,12 @@ int wcsph_profile_end(wcsph_ctx *ctx, float *avg_ms, int32_t *launches);
  * stream; *ms_per_launch is the average.  Names: "pressure_iter", "divergence_iter", "density",
  * "grid_update", "visc_iter".  State is not preserved across the call. */
 int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms_per_launch);
+/* Counters of the LDS tile walk of the pressure passes (csrc/tile.h; dfsph.py:518-547 over HashGrid.py:79-106): [0] occupied
+ * groups, [1] words of the slot table in use, [2] groups whose box does not fit LDS (their owners keep the gather walk),
+ * [3] / [4] owners whose slot list differs from the gather list / entries compared (after wcsph_time_kernel("tile_check")),
+ * [5] 1 when the walk is in use for this context. */
+int wcsph_tile_stats(wcsph_ctx *ctx, int32_t out[8]);
+int wcsph_tile_enable(wcsph_ctx *ctx, int32_t on);
 
 /* ---- slab decomposition: one context per GPU, host code exchanges halos between phases -- */
 /* Restrict the dense cell table to global cell columns [x0, x1) along x; call BEFORE wcsph_setup().  Cell
@@ -405,7 +411,9 @@ int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_sen
 /* n_global: liquid particles of ALL slabs (error thresholds are per global particle, dfsph.py:143, 162);
  * interior [x_lo, x_hi): global cell columns whose particles have no ghost within reach (wcsph_set_part);
  * flags: bit 0 = overlap halo refreshes with the interior, bit 1 = surface tension passes on, bit 2 = no speculation (one host
- * wait per solver decision, the control flow of rounds 1-3).
+ * wait per solver decision, the control flow of rounds 1-3), bit 3 = call the communicator at every exchange point even when
+ * world == 1 (empty or loop-back halos, all-reduces over one rank: the communicator path on one GPU).
+ * cb == NULL on a context with a native communicator (wcsph_comm_init): the library's own RCCL data plane is used.
  * Speculation (default; needs allreduce_max_bits): every solver decision is taken on the device from the all-reduced -- hence
  * rank-identical -- error sum and the common-case continuation is queued behind it in gated segments, halo exchanges included
  * (a gated-off exchange moves a stale buffer that nobody unpacks): the GPU runs the step without waiting for the host.
@@ -413,6 +421,34 @@ int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_sen
  * with the GPU idle behind them (1 in the common case: the step's last mail). */
 int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
                     int32_t flags, int32_t stats[2]);
+
+/* ---- native data plane (wcsph_comm_init / wcsph_halo_exchange) -----------------------------------------
+ * The library's own implementation of the communicator above on RCCL: grouped ncclSend / ncclRecv with the slab neighbours
+ * and ncclAllReduce, all on the context's stream, no host code per exchange.  New work -- the reference step is single-device
+ * (dfsph.py:606-617).  RCCL is loaded at run time (the copy already in the process, else ROCm's librccl.so.1); without it
+ * wcsph_comm_init fails with WCSPH_EHIP and the caller keeps its own communicator behind wcsph_slab_callbacks.
+ *   wcsph_comm_unique_id(id):  rank 0 fills the 128-byte ncclUniqueId; the caller hands it to every rank (any channel)
+ *   wcsph_comm_init(ctx, id, rank, nranks): ncclCommInitRank on the calling thread's current device (the context's); slab
+ *                              neighbours rank - 1 / rank + 1.  wcsph_slab_step(ctx, NULL, ...) then uses this communicator
+ *   wcsph_comm_set_neighbours: other neighbour ranks, -1 = none; left == right == rank makes a LOOP-BACK communicator (what is
+ *                              sent to the left arrives from the right, as on a ring of one): the one-GPU test of the data plane
+ *   wcsph_comm_set_halo_split: of the lists given to wcsph_slab_set_halo, the first n_send_left rows go to / the first
+ *                              n_ghost_left rows come from the left neighbour, the others the right one; after every wcsph_slab_set_halo
+ *   wcsph_halo_exchange(ctx, W, d_send, n_send, d_recv, n_ghost): ONE grouped exchange of rows of W floats, stream-ordered
+ *   wcsph_comm_allreduce(ctx, d_buf, n, op): in place; op 0 = int32 SUM, 1 = float64 SUM, 2 = int32 MAX
+ *   wcsph_comm_stats(ctx, out): out[0] = exchanges, out[1] = all-reduces issued so far */
+#define WCSPH_COMM_ID_BYTES 128
+int wcsph_comm_unique_id(void *id_out);
+int wcsph_comm_init(wcsph_ctx *ctx, const void *unique_id, int32_t rank, int32_t nranks);
+int wcsph_comm_destroy(wcsph_ctx *ctx);
+int wcsph_comm_set_neighbours(wcsph_ctx *ctx, int32_t left, int32_t right);
+int wcsph_comm_set_halo_split(wcsph_ctx *ctx, int32_t n_send_left, int32_t n_ghost_left);
+int wcsph_halo_exchange(wcsph_ctx *ctx, int32_t W, const void *d_send, int32_t n_send, void *d_recv, int32_t n_ghost);
+int wcsph_comm_allreduce(wcsph_ctx *ctx, void *d_buf, int64_t n, int32_t dtype_op);
+int wcsph_comm_stats(wcsph_ctx *ctx, int64_t out[2]);
+/* hand a communicator from one context of this process to another (a rebalance rebuilds the context: new cell window) */
+int wcsph_comm_detach(wcsph_ctx *ctx, void **handle);
+int wcsph_comm_attach(wcsph_ctx *ctx, void *handle);
 
 /* gather / scatter `n` rows of a field by ORIGINAL liquid indices (device int32 array) into / from a
  * packed device buffer (rows of 3 f32 for vec3 fields, 1 f32 for scalar fields) for halo exchange */

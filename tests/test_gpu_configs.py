@@ -99,7 +99,14 @@ def _live_steps(n, mode, need_gb, steps, squeeze, expect_iterating=False):
         iters.append((o.vs_iter, o.dv_iter, o.pr_iter))
         assert (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter) == iters[-1], (s, iters)
         assert abs(dt - o.deltaT) <= 1e-6 * (s + 1) * o.deltaT
-        np.testing.assert_array_equal(pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)   # exact raw list length
+        # exact raw list length on identical positions (step 0).  Later the positions agree to ~1e-7 and a particle that close to a
+        # cell face lands in the neighbouring cell on one side only (about one particle in 1e5 per step on a jittered state: the
+        # from-rest lattice of _one_step has none); it changes the raw count of the ~50 particles whose 5x5x5 block it enters or leaves
+        nc, nco = pd.hash_grid.neighborCount.to_numpy(), np.asarray(o.neighborCount)
+        if s == 0:
+            np.testing.assert_array_equal(nc, nco)
+        else:
+            assert int((nc != nco).sum()) <= 64 + 1e-3 * nl * s and int(np.abs(nc - nco).max()) <= 8, (int((nc != nco).sum()), int(np.abs(nc - nco).max()))
         # Every particle to the tolerances of the reference-text fixtures (tests/test_reference_fixtures.py: rho 1e-5, solver
         # fields 5e-5 of the field's maximum) -- except the handful the reference's own discontinuities may flip at this
         # size: `if adv_rho[i] > 0` (dfsph.py:421) and `max(.., 0)` (:391) give a particle whose sum is zero to rounding the
@@ -108,10 +115,13 @@ def _live_steps(n, mode, need_gb, steps, squeeze, expect_iterating=False):
         # exceed 5e-5; nobody may exceed 1e-3 and the 0.9999 quantile stays inside 5e-5.
         few = 3 + 40
         rq = _quantiles("rho", pd.rho.to_numpy(), o.rho)
-        assert rq[0] < 1e-5 * (s + 1), rq                                                         # north star: <= 1e-4
+        assert rq[0] < (1e-5 if s == 0 else 5e-5), rq                                             # north star: <= 1e-4
+        vmax = float(np.abs(o.vel).max())
         for name, a, b in (("vel", pd.vel.to_numpy(), o.vel), ("kappa", dfsph.kappa.to_numpy(), o.kappa), ("kappa_v", dfsph.kappa_v.to_numpy(), o.kappa_v),
                            ("omega", pd.omega.to_numpy(), o.omega), ("vel_guess", pd.vel_guess.to_numpy(), o.vel_guess), ("adv_rho", pd.adv_rho.to_numpy(), o.adv_rho)):
-            q = _quantiles(name, a, b, 1e-6)
+            # (at the end of a step vel_guess holds a small difference of velocities: its rounding floor is one ulp of |vel|,
+            # 6e-8 absolute whatever its own maximum is -- tools/diag_live_parity.py -- so it is measured on the velocity's scale)
+            q = _quantiles(name, a, b, vmax if name == "vel_guess" else 1e-6)
             assert q[1] <= 5e-5 * (s + 1) and q[2] <= few * (s + 1) and q[0] < 1e-3, (name, s, q)
         assert np.abs(pd.pos.to_numpy()[:nl] - o.pos[:nl]).max() < 2e-6 * (s + 1)
     if expect_iterating:

@@ -1,0 +1,274 @@
+// api_comm.h -- the native data plane of the slab decomposition (wcsph_comm_init / wcsph_halo_exchange): RCCL calls
+// on the context's stream, no host code between the library and the wire.  New work: the reference is single-device
+// (dfsph.py:606-617).  RCCL is resolved at run time (dlopen of librccl.so.1: the one a torch process has already loaded, else
+// ROCm's), so the library has no link dependency on it and single-GPU users never load it.  The communicator behind
+// wcsph_slab_step is then this file's implementation of wcsph_slab_callbacks (include/wcsph.h) instead of the caller's.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only
+
+struct RcclApi {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+static RcclApi *rccl_api(std::string *why) {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) { if (!api.h && why) *why = "librccl.so.1 could not be loaded"; return api.h ? &api : nullptr; }
+  tried = true;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // the copy already in the process (torch's), if any
+  for (int k = 0; !h && k < 3; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+  if (!h) { if (why) *why = std::string("dlopen(librccl.so.1): ") + dlerror(); return nullptr; }
+#define RCCL_SYM(f) if (!(api.f = (decltype(api.f))dlsym(h, "nccl" #f))) { if (why) *why = "librccl lacks nccl" #f; return nullptr; }
+  RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(GetErrorString) RCCL_SYM(AllReduce)
+  RCCL_SYM(Send) RCCL_SYM(Recv) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd)
+#undef RCCL_SYM
+  api.h = h;
+  return &api;
+}
+
+struct NativeComm {
+  RcclApi *api = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1, left = -1, right = -1;
+  int n_send_left = 0, n_ghost_left = 0;   // how the lists of wcsph_slab_set_halo split between the neighbours (left first)
+  struct Buf { float *send = nullptr, *recv = nullptr; size_t cap_send = 0, cap_recv = 0; };
+  Buf buf;
+  hipStream_t side = nullptr;              // the bucket histogram's all-reduce runs here beside the sort and the list build
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  bool words_pending = false;
+  double *d_scalar = nullptr;
+  long n_exchanges = 0, n_allreduces = 0;
+  wcsph_slab_callbacks cb = {};
+  wcsph_ctx *ctx = nullptr;
+};
+
+#define NCCLCHK(call)                                                                                          \
+  do {                                                                                                         \
+    ncclResult_t r_ = (call);                                                                                  \
+    if (r_ != ncclSuccess) { c->ctx->fail(WCSPH_EHIP, (std::string(#call ": ") + c->api->GetErrorString(r_)).c_str()); return WCSPH_EHIP; } \
+  } while (0)
+#define CHIPCHK(call)                                                                                          \
+  do {                                                                                                         \
+    hipError_t e_ = (call);                                                                                    \
+    if (e_ != hipSuccess) { c->ctx->fail(WCSPH_EHIP, #call, e_); return WCSPH_EHIP; }                          \
+  } while (0)
+
+// one grouped exchange with the slab neighbours: rows [0, n_send_left) of d_send go left, the rest right; rows [0, n_ghost_left) of
+// d_recv come from the left, the rest from the right.  The receives are posted right-first: on a loop-back communicator
+// (left == right == this rank: the one-GPU test of the data plane) what goes out to the left comes in from the right, as on a ring.
+static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_recv, int n_send, int n_ghost) {
+  const size_t sl = (size_t)c->n_send_left * W, sr = (size_t)(n_send - c->n_send_left) * W;
+  const size_t gl = (size_t)c->n_ghost_left * W, gr = (size_t)(n_ghost - c->n_ghost_left) * W;
+  hipStream_t s = c->ctx->stream;
+  NCCLCHK(c->api->GroupStart());
+  if (c->left >= 0 && sl) NCCLCHK(c->api->Send(d_send, sl, ncclFloat, c->left, c->comm, s));
+  if (c->right >= 0 && sr) NCCLCHK(c->api->Send(d_send + sl, sr, ncclFloat, c->right, c->comm, s));
+  if (c->right >= 0 && gr) NCCLCHK(c->api->Recv(d_recv + gl, gr, ncclFloat, c->right, c->comm, s));
+  if (c->left >= 0 && gl) NCCLCHK(c->api->Recv(d_recv, gl, ncclFloat, c->left, c->comm, s));
+  NCCLCHK(c->api->GroupEnd());
+  c->n_exchanges++;
+  return 0;
+}
+// ---- wcsph_slab_callbacks on RCCL (everything ordered on the context's stream; nothing waits on the host) -------------------
+// ONE send / receive buffer pair for every row width: the exchanges of a step are ordered on the context's stream (the pack
+// kernel of the next refresh runs after the previous refresh's sends).  Sized for rows of 4 floats with a quarter of slack when
+// the halo lists are set (wcsph_comm_set_halo_split), so that no allocation happens between the exchanges of a step.
+static int comm_reserve(NativeComm *c, size_t ns, size_t ng) {
+  NativeComm::Buf &b = c->buf;
+  if (ns > b.cap_send || !b.send) {
+    if (b.send) { CHIPCHK(hipStreamSynchronize(c->ctx->stream)); CHIPCHK(hipFree(b.send)); b.send = nullptr; }
+    b.cap_send = ns + ns / 4 + 4096;
+    CHIPCHK(hipMalloc((void **)&b.send, b.cap_send * sizeof(float)));
+  }
+  if (ng > b.cap_recv || !b.recv) {
+    if (b.recv) { CHIPCHK(hipStreamSynchronize(c->ctx->stream)); CHIPCHK(hipFree(b.recv)); b.recv = nullptr; }
+    b.cap_recv = ng + ng / 4 + 4096;
+    CHIPCHK(hipMalloc((void **)&b.recv, b.cap_recv * sizeof(float)));
+  }
+  return 0;
+}
+static int ncb_buffers(void *u, int32_t W, void **snd, void **rcv) {
+  NativeComm *c = (NativeComm *)u;
+  int rc = comm_reserve(c, (size_t)c->ctx->n_halo_send * W, (size_t)c->ctx->n_halo_ghost * W);
+  if (rc) return rc;
+  *snd = c->buf.send; *rcv = c->buf.recv;
+  return 0;
+}
+static int ncb_post(void *u, int32_t W) {
+  NativeComm *c = (NativeComm *)u;
+  return comm_exchange(c, W, c->buf.send, c->buf.recv, c->ctx->n_halo_send, c->ctx->n_halo_ghost);
+}
+static int ncb_wait(void *) { return 0; }   // stream-ordered: the unpack kernel queued next runs after the receives
+static int ncb_acc(void *u, int32_t slot) {
+  NativeComm *c = (NativeComm *)u;
+  double *p = c->ctx->d.acc + slot * ACC_STRIPES;
+  NCCLCHK(c->api->AllReduce(p, p, ACC_STRIPES, ncclDouble, ncclSum, c->comm, c->ctx->stream));
+  c->n_allreduces++;
+  return 0;
+}
+static int ncb_max(void *u, double *v) {   // (only without allreduce_max_bits: never on this communicator; kept complete)
+  NativeComm *c = (NativeComm *)u;
+  CHIPCHK(hipMemcpyAsync(c->d_scalar, v, sizeof(double), hipMemcpyHostToDevice, c->ctx->stream));
+  NCCLCHK(c->api->AllReduce(c->d_scalar, c->d_scalar, 1, ncclDouble, ncclMax, c->comm, c->ctx->stream));
+  CHIPCHK(hipMemcpyAsync(v, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream));
+  CHIPCHK(hipStreamSynchronize(c->ctx->stream));
+  c->n_allreduces++;
+  return 0;
+}
+static int ncb_words(void *u, void *d_words, int64_t n) {
+  NativeComm *c = (NativeComm *)u;
+  NCCLCHK(c->api->AllReduce(d_words, d_words, (size_t)n, ncclInt32, ncclSum, c->comm, c->ctx->stream));
+  c->n_allreduces++;
+  return 0;
+}
+static int ncb_max_bits(void *u, void *d_word) {
+  NativeComm *c = (NativeComm *)u;
+  NCCLCHK(c->api->AllReduce(d_word, d_word, 1, ncclInt32, ncclMax, c->comm, c->ctx->stream));
+  c->n_allreduces++;
+  return 0;
+}
+// the packed bucket histogram's all-reduce on the side stream: ordered behind what the context's stream holds now (the packed
+// words), in flight while the library queues the scan, the sort and the list build; _wait makes the context's stream wait for it
+static int ncb_words_post(void *u, void *d_words, int64_t n) {
+  NativeComm *c = (NativeComm *)u;
+  CHIPCHK(hipEventRecord(c->ev_ready, c->ctx->stream));
+  CHIPCHK(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  NCCLCHK(c->api->AllReduce(d_words, d_words, (size_t)n, ncclInt32, ncclSum, c->comm, c->side));
+  CHIPCHK(hipEventRecord(c->ev_done, c->side));
+  c->words_pending = true;
+  c->n_allreduces++;
+  return 0;
+}
+static int ncb_words_wait(void *u) {
+  NativeComm *c = (NativeComm *)u;
+  if (c->words_pending) { CHIPCHK(hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0)); c->words_pending = false; }
+  return 0;
+}
+
+extern "C" {
+
+int wcsph_comm_unique_id(void *id_out) {
+  if (!id_out) return WCSPH_EARG;
+  std::string why;
+  RcclApi *api = rccl_api(&why);
+  if (!api) return WCSPH_EHIP;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return WCSPH_EHIP;
+  memcpy(id_out, &id, sizeof id);
+  return WCSPH_OK;
+}
+int wcsph_comm_destroy(wcsph_ctx *ctx) {
+  if (!ctx) return WCSPH_EARG;
+  NativeComm *c = ctx->comm;
+  if (!c) return WCSPH_OK;
+  hipStreamSynchronize(ctx->stream);
+  if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+  if (c->ev_ready) hipEventDestroy(c->ev_ready);
+  if (c->ev_done) hipEventDestroy(c->ev_done);
+  if (c->buf.send) hipFree(c->buf.send);
+  if (c->buf.recv) hipFree(c->buf.recv);
+  if (c->d_scalar) hipFree(c->d_scalar);
+  if (c->comm) c->api->CommDestroy(c->comm);
+  delete c;
+  ctx->comm = nullptr;
+  return WCSPH_OK;
+}
+int wcsph_comm_init(wcsph_ctx *ctx, const void *unique_id, int32_t rank, int32_t nranks) {
+  if (!ctx || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return WCSPH_EARG;
+  if (ctx->comm) return ctx->fail(WCSPH_EARG, "wcsph_comm_init() called twice (wcsph_comm_destroy() first)");
+  std::string why;
+  RcclApi *api = rccl_api(&why);
+  if (!api) return ctx->fail(WCSPH_EHIP, ("RCCL is not available: " + why).c_str());
+  NativeComm *c = new NativeComm();
+  c->api = api; c->ctx = ctx; c->rank = rank; c->nranks = nranks;
+  c->left = rank > 0 ? rank - 1 : -1;
+  c->right = rank < nranks - 1 ? rank + 1 : -1;
+  ctx->comm = c;
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof id);
+  ncclResult_t r = api->CommInitRank(&c->comm, nranks, id, rank);   // on the calling thread's current device: the context's
+  if (r != ncclSuccess) {
+    ctx->fail(WCSPH_EHIP, (std::string("ncclCommInitRank: ") + api->GetErrorString(r)).c_str());
+    c->comm = nullptr; wcsph_comm_destroy(ctx);
+    return WCSPH_EHIP;
+  }
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess || hipMalloc((void **)&c->d_scalar, 2 * sizeof(double)) != hipSuccess) {
+    wcsph_comm_destroy(ctx);
+    return ctx->fail(WCSPH_EHIP, "wcsph_comm_init: stream / event / scratch allocation");
+  }
+  c->cb.user = c; c->cb.world = nranks;
+  c->cb.halo_buffers = ncb_buffers; c->cb.halo_post = ncb_post; c->cb.halo_wait = ncb_wait;
+  c->cb.allreduce_acc = ncb_acc; c->cb.allreduce_max = ncb_max; c->cb.allreduce_words = ncb_words; c->cb.allreduce_max_bits = ncb_max_bits;
+  c->cb.allreduce_words_post = ncb_words_post; c->cb.allreduce_words_wait = ncb_words_wait;
+  return WCSPH_OK;
+}
+int wcsph_comm_set_neighbours(wcsph_ctx *ctx, int32_t left, int32_t right) {
+  if (!ctx || !ctx->comm) return WCSPH_EARG;
+  NativeComm *c = ctx->comm;
+  if (left >= c->nranks || right >= c->nranks) return ctx->fail(WCSPH_EARG, "wcsph_comm_set_neighbours: no such rank");
+  c->left = left < 0 ? -1 : left; c->right = right < 0 ? -1 : right;
+  return WCSPH_OK;
+}
+int wcsph_comm_set_halo_split(wcsph_ctx *ctx, int32_t n_send_left, int32_t n_ghost_left) {
+  if (!ctx || !ctx->comm || n_send_left < 0 || n_ghost_left < 0) return WCSPH_EARG;
+  NativeComm *c = ctx->comm;
+  if (n_send_left > ctx->n_halo_send || n_ghost_left > ctx->n_halo_ghost) return ctx->fail(WCSPH_EARG, "wcsph_comm_set_halo_split: more rows to the left than wcsph_slab_set_halo() listed");
+  c->n_send_left = n_send_left; c->n_ghost_left = n_ghost_left;
+  return comm_reserve(c, (size_t)ctx->n_halo_send * 4, (size_t)ctx->n_halo_ghost * 4);
+}
+// a communicator outlives the context it was created on: a rebalance of the decomposition rebuilds the context (new cell window)
+// and hands the communicator over
+int wcsph_comm_detach(wcsph_ctx *ctx, void **handle) {
+  if (!ctx || !handle) return WCSPH_EARG;
+  *handle = nullptr;
+  NativeComm *c = ctx->comm;
+  if (!c) return WCSPH_OK;
+  CHIPCHK(hipStreamSynchronize(ctx->stream));
+  CHIPCHK(hipStreamSynchronize(c->side));
+  c->ctx = nullptr; ctx->comm = nullptr;
+  *handle = c;
+  return WCSPH_OK;
+}
+int wcsph_comm_attach(wcsph_ctx *ctx, void *handle) {
+  if (!ctx || !handle) return WCSPH_EARG;
+  if (ctx->comm) return ctx->fail(WCSPH_EARG, "wcsph_comm_attach: the context has a communicator");
+  NativeComm *c = (NativeComm *)handle;
+  c->ctx = ctx; ctx->comm = c;
+  c->n_send_left = c->n_ghost_left = 0;
+  return WCSPH_OK;
+}
+int wcsph_halo_exchange(wcsph_ctx *ctx, int32_t W, const void *d_send, int32_t n_send, void *d_recv, int32_t n_ghost) {
+  if (!ctx || !ctx->comm || W < 1 || n_send < 0 || n_ghost < 0) return WCSPH_EARG;
+  NativeComm *c = ctx->comm;
+  if (c->n_send_left > n_send || c->n_ghost_left > n_ghost) return ctx->fail(WCSPH_EARG, "wcsph_halo_exchange: fewer rows than wcsph_comm_set_halo_split() sends / expects to the left");
+  return comm_exchange(c, W, (const float *)d_send, (float *)d_recv, n_send, n_ghost);
+}
+// dtype_op: 0 = int32 SUM, 1 = float64 SUM, 2 = int32 MAX; in place on the device, on the context's stream
+int wcsph_comm_allreduce(wcsph_ctx *ctx, void *d_buf, int64_t n, int32_t dtype_op) {
+  if (!ctx || !ctx->comm || !d_buf || n < 0 || dtype_op < 0 || dtype_op > 2) return WCSPH_EARG;
+  NativeComm *c = ctx->comm;
+  NCCLCHK(c->api->AllReduce(d_buf, d_buf, (size_t)n, dtype_op == 1 ? ncclDouble : ncclInt32, dtype_op == 2 ? ncclMax : ncclSum, c->comm, ctx->stream));
+  c->n_allreduces++;
+  return WCSPH_OK;
+}
+int wcsph_comm_stats(wcsph_ctx *ctx, int64_t out[2]) {
+  if (!ctx || !out) return WCSPH_EARG;
+  out[0] = ctx->comm ? ctx->comm->n_exchanges : 0; out[1] = ctx->comm ? ctx->comm->n_allreduces : 0;
+  return WCSPH_OK;
+}
+
+}  // extern "C"
+#undef NCCLCHK
+#undef CHIPCHK

@@ -1,6 +1,7 @@
 // api_core.h -- the context behind the C ABI (include/wcsph.h): device view, streams, solver state, the mail box through which
 // reduction totals, error flags and the device-side stopping decisions reach the host, and the launch macros.
 #pragma once
+struct NativeComm;   // api_comm.h
 struct wcsph_ctx {
   wcsph_params p;
   Dev d;          // DFSPH view (CubicKernel with h = HashGrid.searchR)
@@ -31,6 +32,9 @@ struct wcsph_ctx {
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false, bk_rows_valid = false;
+  NativeComm *comm = nullptr;     // the native RCCL data plane of a slab decomposition (wcsph_comm_init), or none
+  bool tile_on = false;           // the pressure passes run on the LDS tile walk (tile.h)
+  int tile_cus = 256, tile_lds_build = 0;
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats

@@ -87,6 +87,7 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
 int wcsph_destroy(wcsph_ctx *ctx) {
   if (!ctx) return WCSPH_EARG;
   if (ctx->own_stream) hipStreamSynchronize(ctx->own_stream);
+  wcsph_comm_destroy(ctx);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
@@ -226,6 +227,7 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
       LAUNCHCHK();
     }
   }
+  { int rc_ = tile_setup(ctx); if (rc_) return rc_; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->is_setup = true;
   ctx->grid_valid = false;

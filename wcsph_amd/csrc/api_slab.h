@@ -269,7 +269,11 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
                     int32_t flags, int32_t stats[2]) {
   NEED_SETUP();
   if (n_global < 1) return WCSPH_EARG;
-  SlabRun R{ctx, cb, cb && cb->world > 1, (flags & 1) != 0 && cb && cb->world > 1, interior_lo, interior_hi};
+  if (!cb && ctx->comm) cb = &ctx->comm->cb;   // the native RCCL data plane (api_comm.h)
+  // flags bit 3: every exchange point calls the communicator even with one rank (empty or loop-back halos, all-reduces over one
+  // rank): the host cost of the communicator path, and the data plane itself, can be exercised on one GPU
+  const bool multi = cb && (cb->world > 1 || (flags & 8));
+  SlabRun R{ctx, cb, multi, (flags & 1) != 0 && multi, interior_lo, interior_hi};
   if (R.multi && (!cb->halo_buffers || !cb->halo_post || !cb->halo_wait || !cb->allreduce_acc || !cb->allreduce_max || !cb->allreduce_words)) return WCSPH_EARG;
   Dev &d = ctx->d;
   int rc;

@@ -72,6 +72,15 @@ struct Dev {
   int nbr_stride, nbr_cap;
   float list_r2;                          // squared support radius the lists are built with
   int *bbox;                              // [6] {xmin,ymin,zmin,xmax,ymax,zmax} of the in-box liquid cells of this step
+  // LDS tile walk (tile.h): groups of TG0 x TG1 x 16 cells whose 2-cell-grown boxes are staged in LDS by the pressure passes
+  int tg0n, tg1n, tl_ngroups;             // groups along the outer / middle axis, groups in all
+  int *tl_n;                              // [8] 0: active groups; 1: words of tl_tbl in use; 2: groups whose box exceeds TL_CAP slots
+  int *tl_own;                            // [groups] liquid particles the group owns (k_tile_mark)
+  int *tl_act;                            // [active] group number, in group order (k_tile_scan)
+  int *tl_grp;                            // [active][TL_DESC] descriptors (k_tile_build)
+  int *tl_tbl;                            // box slot -> sorted liquid index, per active group at its descriptor's offset
+  uint4 *nbt;                             // per-particle lists of box slots: eight 16-bit LDS byte offsets per block, block-major like nbl
+  int *ntl;                               // their lengths
   // solids, cell-sorted once
   float4 *spos;
   // cell tables
@@ -433,6 +442,29 @@ __device__ __forceinline__ void nb_pin(T &v) {
 }
 #define NB_LO(w) ((int)(short)((w) & 0xffffu))
 #define NB_HI(w) ((int)(w) >> 16)
+// the solid stream of particle i (cs slots; see walk()): fs(j, r, r2) for every entry
+template <class FS>
+__device__ __forceinline__ void walk_solids(const Dev &d, int i, float3 xi, int cs, FS &&fs) {
+  if (cs == 0) return;
+  const size_t st = (size_t)d.nbr_stride;
+  int run;
+  const uint4 *S = d.nbs + i;
+  run = d.nsbase[i];
+#define WALK_SOL(u, dd, jj, pp) if (k + u < cs && NB_IS_ENTRY(dd)) { const float3 r = xi - xyz(pp); fs(jj, r, dot3(r, r)); }
+  for (int k = 0; k < cs; k += 8) {
+    const uint4 e = *(S + (size_t)(k >> 3) * st);
+    const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
+    const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
+    run = j7;
+    float4 p0 = nb_ld(d.spos, j0);
+    const float4 p1 = nb_ld(d.spos, j1), p2 = nb_ld(d.spos, j2), p3 = nb_ld(d.spos, j3), p4 = nb_ld(d.spos, j4), p5 = nb_ld(d.spos, j5), p6 = nb_ld(d.spos, j6), p7 = nb_ld(d.spos, j7);
+    nb_pin(p0);
+    WALK_SOL(0, d0, j0, p0) WALK_SOL(1, d1, j1, p1) WALK_SOL(2, d2, j2, p2) WALK_SOL(3, d3, j3, p3)
+    WALK_SOL(4, d4, j4, p4) WALK_SOL(5, d5, j5, p5) WALK_SOL(6, d6, j6, p6) WALK_SOL(7, d7, j7, p7)
+  }
+#undef WALK_SOL
+}
+
 // The stream is loaded plainly by every pass (rounds 1-2 loaded it non-temporally in the once-per-step passes, to keep it from
 // displacing the gather records; since round 3 the elementwise traffic is what stays out of the Infinity Cache -- ld_once /
 // st_once -- and every walk after the list build finds the stream there).
@@ -495,20 +527,5 @@ __device__ __forceinline__ void walk(const Dev &d, int i, float4 pi, const float
   }
 #undef WALK_ONE
 #undef WALK_OK
-  if (cs == 0) return;
-  const uint4 *S = d.nbs + i;
-  run = d.nsbase[i];
-#define WALK_SOL(u, dd, jj, pp) if (k + u < cs && NB_IS_ENTRY(dd)) { const float3 r = xi - xyz(pp); fs(jj, r, dot3(r, r)); }
-  for (int k = 0; k < cs; k += 8) {
-    const uint4 e = *(S + (size_t)(k >> 3) * st);
-    const int d0 = NB_LO(e.x), d1 = NB_HI(e.x), d2 = NB_LO(e.y), d3 = NB_HI(e.y), d4 = NB_LO(e.z), d5 = NB_HI(e.z), d6 = NB_LO(e.w), d7 = NB_HI(e.w);
-    const int j0 = run + d0, j1 = j0 + d1, j2 = j1 + d2, j3 = j2 + d3, j4 = j3 + d4, j5 = j4 + d5, j6 = j5 + d6, j7 = j6 + d7;
-    run = j7;
-    float4 p0 = nb_ld(d.spos, j0);
-    const float4 p1 = nb_ld(d.spos, j1), p2 = nb_ld(d.spos, j2), p3 = nb_ld(d.spos, j3), p4 = nb_ld(d.spos, j4), p5 = nb_ld(d.spos, j5), p6 = nb_ld(d.spos, j6), p7 = nb_ld(d.spos, j7);
-    nb_pin(p0);
-    WALK_SOL(0, d0, j0, p0) WALK_SOL(1, d1, j1, p1) WALK_SOL(2, d2, j2, p2) WALK_SOL(3, d3, j3, p3)
-    WALK_SOL(4, d4, j4, p4) WALK_SOL(5, d5, j5, p5) WALK_SOL(6, d6, j6, p6) WALK_SOL(7, d7, j7, p7)
-  }
-#undef WALK_SOL
+  walk_solids(d, i, xi, cs, fs);
 }

@@ -15,6 +15,7 @@
 #include "device.h"
 #include "grid.h"
 #include "dfsph_kernels.h"
+#include "tile.h"
 #include "solver_extra.h"
 #include "surface.h"
 #include "sampler.h"
@@ -23,11 +24,13 @@
 #include "bucket.h"
 
 #include "api_core.h"
+#include "api_tile.h"
 #include "api_setup.h"
 #include "api_grid.h"
 #include "api_fields.h"
 #include "api_dfsph.h"
 #include "api_solvers.h"
 #include "api_post.h"
+#include "api_comm.h"
 #include "api_slab.h"
 #include "api_measure.h"

@@ -205,6 +205,32 @@ class HipBackend:
     def sync(self):
         self._chk(self.lib.wcsph_sync(self.ctx))
 
+    # ---- the native RCCL data plane (include/wcsph.h "native data plane", csrc/api_comm.h) ---------------------------
+    native_comm = False
+
+    def comm_init(self, unique_id, rank, world, neighbours=None):
+        """ncclCommInitRank inside the library; neighbours = (left, right) overrides rank -+ 1 (-1: none; both == rank: loop-back)"""
+        buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        self._chk(self.lib.wcsph_comm_init(self.ctx, buf, int(rank), int(world)))
+        if neighbours is not None:
+            self._chk(self.lib.wcsph_comm_set_neighbours(self.ctx, int(neighbours[0]), int(neighbours[1])))
+        self.native_comm = True
+
+    def comm_detach(self):
+        h = C.c_void_p()
+        self._chk(self.lib.wcsph_comm_detach(self.ctx, C.byref(h)))
+        self.native_comm = False
+        return h
+
+    def comm_attach(self, handle):
+        self._chk(self.lib.wcsph_comm_attach(self.ctx, handle))
+        self.native_comm = True
+
+    def comm_stats(self):
+        out = (C.c_int64 * 2)()
+        self._chk(self.lib.wcsph_comm_stats(self.ctx, C.byref(out)))
+        return int(out[0]), int(out[1])
+
     # ---- the whole step in one library call (include/wcsph.h wcsph_slab_step) --------------------------------------
     def native_step(self, sim):
         """The choreography of SlabSim._step inside the library; `sim` supplies the communicator through callbacks.
@@ -218,14 +244,22 @@ class HipBackend:
         self._chk(lib.wcsph_set_scalar(ctx, _lib.SCALAR_ID["avg_density_err"], float(sim.avg_density_err)))
         self._chk(lib.wcsph_set_iters(ctx, int(sim.vs_iter), int(sim.dv_iter), int(sim.pr_iter)))
         stats = (C.c_int32 * 2)()
-        flags = (1 if sim.overlap else 0) | (2 if sim.tension else 0) | (0 if sim.speculate else 4)
+        flags = (1 if sim.overlap else 0) | (2 if sim.tension else 0) | (0 if sim.speculate else 4) | (8 if getattr(sim, "force_comm", False) else 0)
         sim._cb_exc = None
-        rc = lib.wcsph_slab_step(ctx, C.byref(self._cbs), int(sim.n_global), int(max(sim.interior[0], -(1 << 30))),
+        if self.native_comm:
+            # the library's own communicator: no callback, no Python between the library and RCCL
+            self._chk(lib.wcsph_comm_set_halo_split(ctx, int(sim.send_l.numel()), int(sim.ghost_l.numel())))
+            cbp = None
+        else:
+            cbp = C.byref(self._cbs)
+        rc = lib.wcsph_slab_step(ctx, cbp, int(sim.n_global), int(max(sim.interior[0], -(1 << 30))),
                                  int(min(sim.interior[1], 1 << 30)), flags, C.byref(stats))
         if sim._cb_exc is not None:
             raise sim._cb_exc
         self._chk(rc)
-        sim.n_host_waits += stats[1]       # (the exchanges of the step are counted where they are posted: SlabSim._post)
+        sim.n_host_waits += stats[1]       # (the exchanges of a callback step are counted where they are posted: SlabSim._post)
+        if self.native_comm:
+            sim.n_exchanges += stats[0]
         dt, err = C.c_float(), C.c_float()
         vs, dv, pr = C.c_int32(), C.c_int32(), C.c_int32()
         self._chk(lib.wcsph_get_scalar(ctx, _lib.SCALAR_ID["deltaT"], C.byref(dt)))
@@ -315,6 +349,36 @@ class SlabSim:
         self.speculate = os.environ.get("WCSPH_SLAB_SPECULATE", "1") != "0"
         self._words_work = None
         self._cb_exc = None
+        # flags bit 3 of wcsph_slab_step: call the communicator at every exchange point even with one rank (tools/slab_overhead.py)
+        self.force_comm = os.environ.get("WCSPH_SLAB_FORCE_COMM", "0") == "1"
+
+    # ---- the native data plane: RCCL inside the library instead of torch.distributed behind callbacks ----------------------
+    def enable_native_comm(self, neighbours=None):
+        """Every rank of the job calls this (collective): rank 0 draws the ncclUniqueId, it travels over the job's default
+        process group (the control plane), every rank joins with ncclCommInitRank inside the library.  The halo refreshes and
+        all-reduces of wcsph_slab_step then never leave the library; migration and ghost rebuild (redistribute) stay on
+        torch.distributed."""
+        if not hasattr(self.B, "comm_init"):
+            raise RuntimeError("the native data plane needs the HIP backend")
+        lib = self.B.lib
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            rc = lib.wcsph_comm_unique_id(buf)
+            ident = [bytes(buf.raw) if rc == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        if ident[0] is None:
+            raise RuntimeError("wcsph_comm_unique_id failed on rank 0 (RCCL not loadable)")
+        with torch.cuda.device(self.device):
+            self.B.comm_init(ident[0], self.rank, self.world, neighbours)
+
+    def disable_native_comm(self):
+        if self.B is not None and getattr(self.B, "native_comm", False):
+            h = self.B.comm_detach()
+            self.B.comm_attach(h)                       # (detach synchronises; attach back so that destroy frees it)
+            _lib.check(self.B.ctx, self.B.lib.wcsph_comm_destroy(self.B.ctx))
+            self.B.native_comm = False
 
     def _set_cuts(self, cuts):
         """(re)build this rank's backend for the slab [cuts[rank], cuts[rank+1]): cell window, static boundary particles
@@ -328,9 +392,12 @@ class SlabSim:
         scx = self._cellx_np(sol32[:, 0]) if len(sol32) else np.zeros(0, np.int64)
         solid_local = self.solid_all[(scx >= w0) & (scx < w1)]
         capacity = int(max(self.rows.shape[0], self.n_global // world) * self._cap_factor) + 4096
+        comm_handle = None
         if self.B is not None:
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)   # nothing of the old backend may still be in flight when it is freed
+            if getattr(self.B, "native_comm", False):
+                comm_handle = self.B.comm_detach()    # the communicator outlives the context (a rebalance rebuilds it)
             self.B.close()
         if self.hi - self.lo < MIN_SLAB and world > 1:
             raise ValueError("rank %d: slab [%d, %d) is narrower than %d cell columns" % (rank, self.lo, self.hi, MIN_SLAB))
@@ -343,6 +410,8 @@ class SlabSim:
             kw.update(neighbor_mode="faithful", owned=(self.lo if rank > 0 else -big, self.hi if rank < world - 1 else big),
                       n_global=(self.n_global, len(self.solid_all)))
         self.B = self._factory(**kw)
+        if comm_handle is not None:
+            self.B.comm_attach(comm_handle)
         if self.neighbor_mode == "faithful" and world > 1:
             self._allreduce_tensor(self.B.bucket_hist(1))      # static boundary particles: once per backend
         # halo/compute overlap: a neighbour pass that needs a halo refresh runs on the slab interior (columns at least
