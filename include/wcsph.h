@@ -263,12 +263,6 @@ int wcsph_profile_end(wcsph_ctx *ctx, float *avg_ms, int32_t *launches);
  * stream; *ms_per_launch is the average.  Names: "pressure_iter", "divergence_iter", "density",
  * "grid_update", "visc_iter".  State is not preserved across the call. */
 int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms_per_launch);
-/* Counters of the LDS tile walk of the pressure passes (csrc/tile.h; dfsph.py:518-547 over HashGrid.py:79-106): [0] occupied
- * groups, [1] words of the slot table in use, [2] groups whose box does not fit LDS (their owners keep the gather walk),
- * [3] / [4] owners whose slot list differs from the gather list / entries compared (after wcsph_time_kernel("tile_check")),
- * [5] 1 when the walk is in use for this context. */
-int wcsph_tile_stats(wcsph_ctx *ctx, int32_t out[8]);
-int wcsph_tile_enable(wcsph_ctx *ctx, int32_t on);
 
 /* ---- slab decomposition: one context per GPU, host code exchanges halos between phases -- */
 /* Restrict the dense cell table to global cell columns [x0, x1) along x; call BEFORE wcsph_setup().  Cell

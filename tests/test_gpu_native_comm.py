@@ -1,0 +1,141 @@
+"""GPU: the library's native RCCL data plane (csrc/api_comm.h: wcsph_comm_init / wcsph_halo_exchange) on ONE GPU.
+
+The pool hands out single-GPU boxes and RCCL refuses two ranks on one GPU, so the data plane is exercised LOOP-BACK: a
+communicator of one rank whose left and right neighbour are the rank itself (what is sent to the left arrives from the right,
+as on a ring).  The scene is made periodic by hand: the ghost rows of the slab are copies of its own rows within two cell
+columns of the opposite end, shifted by the slab's width -- physically a ring of one slab; what matters here is that every halo
+refresh of wcsph_slab_step moves real rows and every all-reduce runs, through
+  (a) the caller's communicator behind wcsph_slab_callbacks (torch copies, wcsph_amd/slab.py), and
+  (b) grouped ncclSend / ncclRecv + ncclAllReduce inside the library,
+from the same state: the exchanged buffers bit for bit, the state after three steps to rounding level (new work: the
+reference step, dfsph.py:606-617, is single-device)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+pytestmark = pytest.mark.gpu
+G = 2   # ghost layer: the walk radius in cell columns
+
+
+def _ring_sim(mode, n=12):
+    import slab_util
+    from wcsph_amd.slab import SlabSim, HipBackend, STATE_W
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    liquid, solid, bounds = slab_util.test_scene(n)
+    sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, [0, 10 ** 6], len(liquid), 0, 1, device=dev, neighbor_mode=mode)
+    cx = sim._cellx(sim.rows)
+    blk_lo, blk_hi = int(cx.min().item()), int(cx.max().item()) + 1
+    period = np.float32((blk_hi - blk_lo) * 2 * sim.particleR)
+    # a velocity field of the ring's period with a divergence: the divergence solver, the viscosity PCG and the vorticity sums all
+    # have work, and the rows at the two ends feel their neighbours across the seam
+    sim.rows[:, 3] = 0.5 * torch.sin(2.0 * np.pi * sim.rows[:, 0] / float(period))
+    sim.rows[:, 4] = -0.5
+    sim.loopback, sim.force_comm, sim.overlap = True, True, True
+    sim.interior = (blk_lo + G, blk_hi - G)
+    nl = len(liquid)
+
+    def ring_redistribute():
+        rows = sim.rows
+        cx = sim._cellx(rows)
+        near_l = torch.nonzero(cx < blk_lo + G).flatten()
+        near_r = torch.nonzero(cx >= blk_hi - G).flatten()
+        gl = rows.index_select(0, near_r).clone(); gl[:, 0] -= float(period)      # from the left: the right end, one period down
+        gr = rows.index_select(0, near_l).clone(); gr[:, 0] += float(period)
+        gid = torch.arange(nl, nl + gl.shape[0] + gr.shape[0], dtype=torch.int32, device=rows.device)
+        gl[:, STATE_W - 1] = gid[:gl.shape[0]].view(torch.float32); gr[:, STATE_W - 1] = gid[gl.shape[0]:].view(torch.float32)
+        n = rows.shape[0]
+        i32 = torch.int32
+        sim.send_l, sim.send_r = near_l.to(i32), near_r.to(i32)
+        sim.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=rows.device)
+        sim.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=rows.device)
+        sim.send_all = torch.cat([sim.send_l, sim.send_r]); sim.ghost_all = torch.cat([sim.ghost_l, sim.ghost_r])
+        sim.n_owned = n
+        sim.B.load_state_split(rows, (gl, gr))
+    sim.redistribute = ring_redistribute
+    return sim
+
+
+@pytest.mark.parametrize("mode", ["clean", "faithful"])
+def test_native_rccl_data_plane_loopback_equals_the_callback_path(mode):
+    out = {}
+    for plane in ("callbacks", "native"):
+        sim = _ring_sim(mode)
+        if plane == "native":
+            sim.enable_native_comm(neighbours=(0, 0))
+        log = []
+        for _ in range(3):
+            sim.step()
+            log.append((sim.vs_iter, sim.dv_iter, sim.pr_iter, float(sim.dt)))
+        torch.cuda.synchronize()
+        out[plane] = (sim.rows.cpu().numpy().copy(), log, sim.n_exchanges, sim.B.comm_stats() if plane == "native" else None)
+        assert sim.send_all.numel() > 100 and sim.ghost_all.numel() > 100          # real rows travelled
+        sim.B.close()
+    (ra, la, xa, _), (rb, lb, xb, st) = out["callbacks"], out["native"]
+    assert la == lb, (la, lb)
+    assert xa == xb and xa >= 3 * 10, (xa, xb)                                       # the same number of halo refreshes, >= 10 per step
+    assert st[0] == xb and st[1] >= 3 * 5, st                                       # ... issued by the library itself, and its all-reduces
+    # The state after three steps.  Two runs of the SAME path already differ in the last bits (the PCG's dot products and the
+    # solvers' error sums are double-precision atomics over workgroup partials: their order is the scheduler's), so the two
+    # planes are compared at rounding level on the velocity's scale -- three orders of magnitude below what the ghosts change
+    # (checked last) -- and bit for bit where nothing is summed: the exchange itself (next test).
+    names = ["pos"] * 3 + ["vel"] * 3 + ["omega"] * 3 + ["vel_guess"] * 3 + ["kappa", "kappa_v"]
+    vscale = float(np.abs(ra[:, 3:6]).max())
+    for c, nm in enumerate(names):
+        scale = {"pos": 1.0, "vel": vscale, "vel_guess": vscale}.get(nm, max(float(np.abs(ra[:, c]).max()), 1e-12))
+        d = float(np.abs(ra[:, c] - rb[:, c]).max()) / scale
+        print("native vs callbacks %-9s col %2d: max diff / scale = %.2e" % (nm, c, d))
+        assert d < (5e-7 if nm == "pos" else 5e-6), (nm, c, d)
+    np.testing.assert_array_equal(ra[:, 14].view(np.int32), rb[:, 14].view(np.int32))
+    # and the ghosts mattered: the same rows without any ghost evolve differently
+    sim = _ring_sim(mode)
+    sim.loopback = sim.force_comm = sim.overlap = False
+    from wcsph_amd.slab import SlabSim
+    sim.redistribute = lambda: SlabSim.redistribute(sim)
+    for _ in range(3):
+        sim.step()
+    torch.cuda.synchronize()
+    dv = float(np.abs(sim.rows.cpu().numpy()[:, 3:6] - ra[:, 3:6]).max()) / vscale
+    print("without the ghosts: velocity differs by %.2e of its scale" % dv)
+    assert dv > 2e-2
+    sim.B.close()
+
+
+def test_halo_exchange_and_allreduce_entry_points():
+    """wcsph_halo_exchange / wcsph_comm_allreduce on their own: a loop-back exchange swaps the two halves, an all-reduce over one
+    rank leaves its buffer unchanged (SUM and MAX, int32 and float64)."""
+    import ctypes as C
+    from wcsph_amd import _lib
+    sim = _ring_sim("clean", n=8)
+    sim.enable_native_comm(neighbours=(0, 0))
+    lib, ctx = sim.B.lib, sim.B.ctx
+    W, nl_, nr_ = 3, 40, 25
+    send = torch.arange((nl_ + nr_) * W, dtype=torch.float32, device=sim.device).reshape(-1, W)
+    recv = torch.full(((nl_ + nr_), W), -1.0, dtype=torch.float32, device=sim.device)
+    with torch.cuda.stream(sim.stream):
+        # rows [0, 40) go left and come back from the right (rows [25, 65) of recv); rows [40, 65) go right and come back from the left
+        c = sim.B
+        idx = torch.zeros(nl_ + nr_, dtype=torch.int32, device=sim.device)
+        _lib.check(ctx, lib.wcsph_slab_set_halo(ctx, C.c_void_p(idx.data_ptr()), nl_ + nr_, C.c_void_p(idx.data_ptr()), nl_ + nr_))
+        _lib.check(ctx, lib.wcsph_comm_set_halo_split(ctx, nl_, nr_))
+        _lib.check(ctx, lib.wcsph_halo_exchange(ctx, W, C.c_void_p(send.data_ptr()), nl_ + nr_, C.c_void_p(recv.data_ptr()), nl_ + nr_))
+        words = torch.arange(1000, dtype=torch.int32, device=sim.device)
+        dbl0 = np.linspace(0, 1, 64)
+        dbl = torch.from_numpy(dbl0).to(sim.device)
+        _lib.check(ctx, lib.wcsph_comm_allreduce(ctx, C.c_void_p(words.data_ptr()), 1000, 0))
+        _lib.check(ctx, lib.wcsph_comm_allreduce(ctx, C.c_void_p(dbl.data_ptr()), 64, 1))
+        _lib.check(ctx, lib.wcsph_comm_allreduce(ctx, C.c_void_p(words.data_ptr()), 1, 2))
+        c.sync()
+    torch.cuda.synchronize()
+    r, s = recv.cpu().numpy(), send.cpu().numpy()
+    np.testing.assert_array_equal(r[:nr_], s[nl_:])          # from the left: what went right
+    np.testing.assert_array_equal(r[nr_:], s[:nl_])          # from the right: what went left
+    np.testing.assert_array_equal(words.cpu().numpy(), np.arange(1000, dtype=np.int32))
+    np.testing.assert_array_equal(dbl.cpu().numpy(), dbl0)
+    sim.B.close()

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs tools/variants/lds_tile_walk_experiment.patch applied: profiles/r05_lds_tile_experiment.md)
 # PMC passes for the LDS tile walk's kernels (each pass its own run; --kernel-trace only, per the pool rules).
 # usage: tools/pmc_tile.sh <group: tile_vel|tile_drho|tile_build> <kernel-regex> <out.txt> [lib.so] [steps]
 G=${1:-tile_drho}; RX=${2:-"k_tile_drho"}; OUTTXT=${3:-/root/repo/gpurun_out/pmc_tile.txt}; R=/root/repo

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The pressure passes on the LDS tile walk (csrc/tile.h, WCSPH_TILE=1) against the gather walk, ONE context (the two paths see the
+"""(needs tools/variants/lds_tile_walk_experiment.patch applied: profiles/r05_lds_tile_experiment.md)
+The pressure passes on the LDS tile walk (csrc/tile.h, WCSPH_TILE=1) against the gather walk, ONE context (the two paths see the
 same sort: the order of the particles inside a cell comes from atomics and differs between contexts):
    python tools/tile_bench.py [config=C3] [marks=25,1200] [mode=faithful]
 At every mark: the slot lists checked against the gather lists entry for entry on the device (tile_check); three pressure

@@ -33,8 +33,6 @@ struct wcsph_ctx {
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false, bk_rows_valid = false;
   NativeComm *comm = nullptr;     // the native RCCL data plane of a slab decomposition (wcsph_comm_init), or none
-  bool tile_on = false;           // the pressure passes run on the LDS tile walk (tile.h)
-  int tile_cus = 256, tile_lds_build = 0;
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers
   float *stage = nullptr;  // [max(count*3, nl*9)] floats

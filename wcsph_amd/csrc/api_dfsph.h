@@ -82,14 +82,8 @@ static int pressure_iter_fused(wcsph_ctx *ctx) {
   if (ctx->d.n_owned < ctx->d.nl) return pressure_iter_async(ctx);
   const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
   if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
-  if (tile_usable(ctx)) {
-    int rc_ = tile_vel_launch(ctx, ctx->d.kappa);
-    if (!rc_) rc_ = tile_drho_launch(ctx);
-    if (rc_) return rc_;
-  } else {
-    PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);     // also clears ACC_ERR
-    PASS((k_drho_press<DRHO_ITER, true>), ctx->dt);
-  }
+  PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);     // also clears ACC_ERR
+  PASS((k_drho_press<DRHO_ITER, true>), ctx->dt);
   if (prof) { HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream)); ctx->prof_used += 2; }
   return 0;
 }

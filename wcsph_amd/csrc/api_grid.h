@@ -130,7 +130,6 @@ static int grid_lists(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   if (d.nl > 0) hipLaunchKernelGGL(k_build_lists, dim3(nblk8(d.nl)), dim3(BLOCK), 0, ctx->stream, d, 1);
   LAUNCHCHK();
-  { int rc_ = tile_build_launches(ctx); if (rc_) return rc_; }
   ctx->grid_stage = 3;
   return 0;
 }

@@ -31,25 +31,6 @@ int wcsph_profile_end(wcsph_ctx *ctx, float *avg_ms, int32_t *launches) {
   return WCSPH_OK;
 }
 
-// development: the counters of the LDS tile walk (tile.h Dev::tl_n): occupied groups, slot-table words, groups without a box,
-// [3] owners whose slot list differs from the gather list and [4] entries compared (after wcsph_time_kernel("tile_check")); [5] = 1 when the walk is on
-int wcsph_tile_stats(wcsph_ctx *ctx, int32_t out[8]) {
-  NEED_SETUP();
-  if (!out) return WCSPH_EARG;
-  memset(out, 0, 8 * sizeof(int32_t));
-  if (!ctx->d.tl_n) return WCSPH_OK;
-  HIPCHK(hipMemcpyAsync(out, ctx->d.tl_n, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  out[5] = tile_usable(ctx) ? 1 : 0;
-  return WCSPH_OK;
-}
-// development: switch the pressure passes of a context set up with WCSPH_TILE=1 between the tile walk and the gather walk
-int wcsph_tile_enable(wcsph_ctx *ctx, int32_t on) {
-  NEED_SETUP();
-  if (!ctx->d.tl_n) return ctx->fail(WCSPH_EARG, "the context was set up without WCSPH_TILE=1");
-  ctx->tile_on = on != 0;
-  return WCSPH_OK;
-}
 int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
   NEED_GRID();
   if (!name || reps < 1 || !ms) return WCSPH_EARG;
@@ -71,10 +52,6 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "visc_minv_residual_vort") { RPASS(k_visc_minv_residual_vort, ctx->dt); return 0; }
     if (nm == "vorticity") { RPASS(k_vorticity, ctx->dt); return 0; }
     if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; RPASS(k_visc_minv_residual, ctx->dt); return 0; }
-    if (nm == "tile_build") return tile_build_launches(ctx);
-    if (nm == "tile_check") { if (!tile_usable(ctx)) return ctx->fail(WCSPH_EARG, "tile walk off"); hipLaunchKernelGGL(k_tile_check, dim3(ctx->tile_cus * 4), dim3(BLOCK), 0, ctx->stream, ctx->d); LAUNCHCHK(); return 0; }
-    if (nm == "tile_vel") return tile_usable(ctx) ? tile_vel_launch(ctx, nullptr) : ctx->fail(WCSPH_EARG, "tile walk off");
-    if (nm == "tile_drho") return tile_usable(ctx) ? tile_drho_launch(ctx) : ctx->fail(WCSPH_EARG, "tile walk off");
     if (nm == "build_lists") { PASS(k_build_lists, 1); return 0; }
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; RPASS(k_visc_Ad, ctx->dt); return 0; }
     return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");

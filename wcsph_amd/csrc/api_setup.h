@@ -227,7 +227,6 @@ int wcsph_setup(wcsph_ctx *ctx, const float *pos_xyz, const float *maxb, const f
       LAUNCHCHK();
     }
   }
-  { int rc_ = tile_setup(ctx); if (rc_) return rc_; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->is_setup = true;
   ctx->grid_valid = false;

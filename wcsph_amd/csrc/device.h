@@ -72,15 +72,6 @@ struct Dev {
   int nbr_stride, nbr_cap;
   float list_r2;                          // squared support radius the lists are built with
   int *bbox;                              // [6] {xmin,ymin,zmin,xmax,ymax,zmax} of the in-box liquid cells of this step
-  // LDS tile walk (tile.h): groups of TG0 x TG1 x 16 cells whose 2-cell-grown boxes are staged in LDS by the pressure passes
-  int tg0n, tg1n, tl_ngroups;             // groups along the outer / middle axis, groups in all
-  int *tl_n;                              // [8] 0: active groups; 1: words of tl_tbl in use; 2: groups whose box exceeds TL_CAP slots
-  int *tl_own;                            // [groups] liquid particles the group owns (k_tile_mark)
-  int *tl_act;                            // [active] group number, in group order (k_tile_scan)
-  int *tl_grp;                            // [active][TL_DESC] descriptors (k_tile_build)
-  int *tl_tbl;                            // box slot -> sorted liquid index, per active group at its descriptor's offset
-  uint4 *nbt;                             // per-particle lists of box slots: eight 16-bit LDS byte offsets per block, block-major like nbl
-  int *ntl;                               // their lengths
   // solids, cell-sorted once
   float4 *spos;
   // cell tables

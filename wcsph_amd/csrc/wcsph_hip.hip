@@ -15,7 +15,6 @@
 #include "device.h"
 #include "grid.h"
 #include "dfsph_kernels.h"
-#include "tile.h"
 #include "solver_extra.h"
 #include "surface.h"
 #include "sampler.h"
@@ -24,7 +23,6 @@
 #include "bucket.h"
 
 #include "api_core.h"
-#include "api_tile.h"
 #include "api_setup.h"
 #include "api_grid.h"
 #include "api_fields.h"

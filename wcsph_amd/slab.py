@@ -445,6 +445,8 @@ class SlabSim:
 
     def _allreduce_tensor(self, t, op=None):
         op = op if op is not None else dist.ReduceOp.SUM
+        if self.world == 1:                        # (the communicator path forced on one rank: wcsph_slab_step flags bit 3)
+            return
         if self.comm_device != self.device:        # gloo dry run: stage through the host
             h = t.to(self.comm_device)
             dist.all_reduce(h, op=op, group=self.group)
@@ -483,6 +485,12 @@ class SlabSim:
         transfers run on the process group's own stream: work queued on the current stream after this call overlaps with
         them until _complete makes the stream wait."""
         left, right = self._neighbours()
+        if getattr(self, "loopback", False):
+            # one rank whose left and right neighbour are itself (the one-GPU test of the data plane, tests/test_gpu_native_comm.py):
+            # what goes out to the left comes in from the right
+            from_right.copy_(to_left); from_left.copy_(to_right)
+            self.n_exchanges += 1
+            return [], None, (from_left, from_right), (to_left, to_right)
         staged = self.comm_device != self.device
         dst = None
         if staged:
@@ -644,6 +652,9 @@ class SlabSim:
             # the bucket histogram's all-reduce, started here and awaited in words_wait: with RCCL it runs on the process
             # group's own stream, ordered behind what the context's stream holds NOW (the packed histogram), while the
             # library queues the scan, the sort and the list build.  Host-staged (gloo) runs have nothing to overlap with.
+            if self.world == 1:
+                self._words_work = None
+                return
             t = torch.as_tensor(_DevArray(ptr, n), device=self.device)
             if self.comm_device != self.device:
                 self._allreduce_tensor(t)
