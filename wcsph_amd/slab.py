@@ -226,6 +226,36 @@ class HipBackend:
         self._chk(self.lib.wcsph_comm_attach(self.ctx, handle))
         self.native_comm = True
 
+    def comm_probe(self, rank, world):
+        """one small grouped exchange with the slab neighbours and one all-reduce of each kind through the library's own
+        communicator, verified; raises on a mismatch (bench: before the data plane is trusted with the run)"""
+        lib, ctx, dev = self.lib, self.ctx, self.device
+        has_l, has_r, n = rank > 0, rank < world - 1, 128
+        ns = n * (int(has_l) + int(has_r))
+        with torch.cuda.stream(self.stream):
+            idx = torch.zeros(max(ns, 1), dtype=torch.int32, device=dev)
+            send = torch.full((max(ns, 1), 3), float(rank), dtype=torch.float32, device=dev)
+            recv = torch.full((max(ns, 1), 3), -1.0, dtype=torch.float32, device=dev)
+            self._chk(lib.wcsph_slab_set_halo(ctx, C.c_void_p(idx.data_ptr()), ns, C.c_void_p(idx.data_ptr()), ns))
+            self._chk(lib.wcsph_comm_set_halo_split(ctx, n * int(has_l), n * int(has_l)))
+            self._chk(lib.wcsph_halo_exchange(ctx, 3, C.c_void_p(send.data_ptr()), ns, C.c_void_p(recv.data_ptr()), ns))
+            w = torch.tensor([rank, 7], dtype=torch.int32, device=dev)
+            dbl = torch.full((64,), float(rank + 1), dtype=torch.float64, device=dev)
+            mx = torch.tensor([rank], dtype=torch.int32, device=dev)
+            self._chk(lib.wcsph_comm_allreduce(ctx, C.c_void_p(w.data_ptr()), 2, 0))
+            self._chk(lib.wcsph_comm_allreduce(ctx, C.c_void_p(dbl.data_ptr()), 64, 1))
+            self._chk(lib.wcsph_comm_allreduce(ctx, C.c_void_p(mx.data_ptr()), 1, 2))
+            self.sync()
+        torch.cuda.synchronize(dev)
+        exp = ([float(rank - 1)] * n if has_l else []) + ([float(rank + 1)] * n if has_r else [])
+        got = recv[:ns, 0].tolist()
+        if got != exp or (ns and recv[:ns].min().item() != min(exp)):
+            raise RuntimeError("native halo exchange returned wrong rows")
+        if w.tolist() != [world * (world - 1) // 2, 7 * world] or float(dbl[0].item()) != world * (world + 1) / 2.0 or int(mx.item()) != world - 1:
+            raise RuntimeError("native all-reduce returned %r / %r / %r" % (w.tolist(), float(dbl[0].item()), int(mx.item())))
+        self._chk(lib.wcsph_slab_set_halo(ctx, None, 0, None, 0))
+        self._chk(lib.wcsph_comm_set_halo_split(ctx, 0, 0))
+
     def comm_stats(self):
         out = (C.c_int64 * 2)()
         self._chk(self.lib.wcsph_comm_stats(self.ctx, C.byref(out)))
@@ -1066,6 +1096,28 @@ def bench_main(args):
     sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, cuts, n_global, rank, world, device=dev,
                   comm_device=torch.device("cpu") if staged else dev, neighbor_mode=args.mode, gid_local=gid, group=grp,
                   rebalance_every=int(os.environ.get("WCSPH_REBALANCE_EVERY", "200")))
+    # Data plane of the step's halo refreshes and all-reduces: the library's own RCCL calls (csrc/api_comm.h: no Python between
+    # wcsph_slab_step and the wire) when every rank can join and a probe of the real neighbour pattern comes back right;
+    # otherwise this rank's torch.distributed group behind wcsph_slab_callbacks, as before.  WCSPH_BENCH_NATIVE=0 keeps the callbacks.
+    plane = "torch.distributed (%s) behind wcsph_slab_callbacks" % ("RCCL" if not staged else "gloo, host-staged")
+    if not staged and sim.native and os.environ.get("WCSPH_BENCH_NATIVE", "1") != "0":
+        ok, why = 1, ""
+        try:
+            sim.enable_native_comm()
+            sim.B.comm_probe(rank, world)
+        except Exception as e:      # noqa: BLE001 -- the decision must be collective
+            ok, why = 0, "%s: %s" % (type(e).__name__, (str(e).strip().splitlines() or [""])[0][:200])
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            plane = "native RCCL inside the library (wcsph_comm_init / wcsph_halo_exchange: grouped ncclSend/ncclRecv + ncclAllReduce on the context's stream); migration + ghost rebuild over torch.distributed (RCCL)"
+        else:
+            if why:
+                print("[bench rank %d] native data plane not used (%s): torch.distributed callbacks" % (rank, why), file=sys.stderr, flush=True)
+            try:
+                sim.disable_native_comm()
+            except Exception:       # noqa: BLE001
+                sim.B.native_comm = False
     iters = []
     for _ in range(args.warmup):
         sim.step()
@@ -1111,8 +1163,9 @@ def bench_main(args):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DFSPH 3D dam-break %d^3 = %d liquid particles over %d x-slabs (C3 load per GPU; C4 at 8 "
                                    "GPUs), ghost halos over %s, viscosity PCG + vorticity on" % (n, n_global, world, "RCCL send/recv" if not staged else "gloo (host-staged)"),
-                       "neighbor_mode": args.mode, "n_liquid": n_global, "cuts": sim.cuts, "comm": comm,
-                       "step_driver": "wcsph_slab_step (library, communicator behind callbacks)" if sim.native else "python phase driver",
+                       "neighbor_mode": args.mode, "n_liquid": n_global, "cuts": sim.cuts, "comm": comm, "data_plane": plane,
+                       "step_driver": ("wcsph_slab_step (library, its own RCCL communicator)" if getattr(sim.B, "native_comm", False) else
+                                       "wcsph_slab_step (library, communicator behind callbacks)") if sim.native else "python phase driver",
                        "host_waits_per_step": round(sim.n_host_waits / float(args.steps + args.warmup), 1),
                        "rebalance_every": sim.rebalance_every, "rebalanced": sim.n_rebalanced,
                        "owned_per_rank": [int(c.item()) for c in allc],
