@@ -12,5 +12,12 @@ dfsph.reset_param()
 for _ in range(steps):
     dfsph.step()
 pd.sync()
-print("iters", dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter)
+import numpy as np, time
+nc = pd.hash_grid.neighborCount.to_numpy()
+t0 = time.perf_counter()
+for _ in range(10):
+    dfsph.step()
+pd.sync()
+print("iters", dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter, "| liquid %d solid %d | raw list entries per particle (HashGrid.neighborCount): mean %.1f max %d | %.3f ms/step"
+      % (pd.liquid_count, pd.solid_count, nc.mean(), nc.max(), (time.perf_counter() - t0) / 10 * 1e3))
 pd.close()
