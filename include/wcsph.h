@@ -97,6 +97,7 @@ enum wcsph_scalar {
   WCSPH_S_VISCOSITY, WCSPH_S_VISCOSITY_B, WCSPH_S_TENSION, WCSPH_S_TENSION_B, WCSPH_S_VEL_MAX0,
   WCSPH_S_RHO_ERR,     /* pcisph.py:58 rho_err */
   WCSPH_S_TABLE_UPDATES_IN_PLACE,   /* read only, diagnostics: grid updates of this context that updated the reference bucket table in place instead of rebuilding it (api_grid.h grid_assign) */
+  WCSPH_S_DT_RULE_MISMATCHES,       /* read only, diagnostics: speculative steps whose device-formed deltaT (k_cfl_store, DtRule) differed from the host rule of dfsph.py:113-129 evaluated on the same inputs; stays 0 (the device value is the one the step ran with, and is adopted) */
   WCSPH_S__COUNT
 };
 

@@ -43,7 +43,7 @@ FIELDS = ["pos", "vel", "vel_guess", "d_vel", "omega", "d_omega", "normal", "cg_
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 # enum wcsph_scalar
 SCALARS = ["deltaT", "avg_density_err", "cg_delta", "cg_delta_old", "cg_delta_zero", "viscosity", "viscosity_b",
-           "tension_coff", "tension_coff_b", "vel_max0", "rho_err", "table_updates_in_place"]
+           "tension_coff", "tension_coff_b", "vel_max0", "rho_err", "table_updates_in_place", "dt_rule_mismatches"]
 SCALAR_ID = {n: i for i, n in enumerate(SCALARS)}
 
 # every entry point include/wcsph.h declares that takes only the context

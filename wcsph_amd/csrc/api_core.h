@@ -25,6 +25,7 @@ struct wcsph_ctx {
   int grid_stage = 0;             // split grid update (api_grid.h): 1 cells assigned, 2 sorted, 3 lists built; 0 none in progress
   bool hist_valid = false;       // bcount8 == static + liquid histogram of the cells in pos.w (left by a complete update of one context): the next one may update it in place
   bool hist_inc = false;         // the update in progress does so
+  int n_dt_mismatch = 0;         // speculative steps whose device-formed deltaT differed from the host rule (WCSPH_S_DT_RULE_MISMATCHES)
   int n_hist_inc = 0;            // how many updates did (WCSPH_S_TABLE_UPDATES_IN_PLACE)
   bool bcount_int_valid = false; // the int table (gridCount) matches the byte table (k_bucket_sum wrote both; k_bucket_expand on demand)
   int warm_gen = 0;              // generation number of flags[FLAG_WARM] (api_dfsph.h update_vel_warm_start)

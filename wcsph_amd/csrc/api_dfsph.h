@@ -326,9 +326,15 @@ int wcsph_dfsph_optimize_time_step(wcsph_ctx *ctx) {  // ref: dfsph.py:107-129
     //  -- the state has already advanced with it.  Development builds check that both rules agree bit for bit.
     ctx->spec_dt = false;
     float ddt; memcpy(&ddt, &ctx->h_flags[FLAG_DT], 4);
+    // always on: the two rules are compared on every speculative step and a difference is COUNTED
+    // (WCSPH_S_DT_RULE_MISMATCHES; the reference-text fixture tests assert 0) -- a development build refuses it
+    if (memcmp(&ddt, &ctx->dt, 4) != 0) {
+      ctx->n_dt_mismatch++;
 #ifdef WCSPH_DEV
-    if (memcmp(&ddt, &ctx->dt, 4) != 0) { ctx->spec_press_seq = 0; return ctx->fail(WCSPH_EHIP, "deltaT formed on the device differs from the host rule (dfsph.py:113-129)"); }
+      ctx->spec_press_seq = 0;
+      return ctx->fail(WCSPH_EHIP, "deltaT formed on the device differs from the host rule (dfsph.py:113-129)");
 #endif
+    }
     ctx->dt = ddt;
   }
   return WCSPH_OK;

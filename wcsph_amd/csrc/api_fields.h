@@ -207,6 +207,7 @@ int wcsph_get_scalar(wcsph_ctx *ctx, int id, float *v) {
     case WCSPH_S_VEL_MAX0: *v = ctx->vel_max0; break;
     case WCSPH_S_RHO_ERR: *v = ctx->rho_err; break;
     case WCSPH_S_TABLE_UPDATES_IN_PLACE: *v = (float)ctx->n_hist_inc; break;
+    case WCSPH_S_DT_RULE_MISMATCHES: *v = (float)ctx->n_dt_mismatch; break;
     default: return ctx->fail(WCSPH_EARG, "unknown scalar id");
   }
   return WCSPH_OK;

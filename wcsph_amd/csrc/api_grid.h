@@ -73,6 +73,8 @@ static int grid_assign(wcsph_ctx *ctx, bool single = false) {   // single: wcsph
   return 0;
 }
 // the counting sort: occupied box, exclusive scan of the cell counters, every persistent field to its cell-sorted place
+// (grid_sort and grid_lists must not touch ctx->bcount: on a slab the packed bucket histogram is being all-reduced in it while they
+// are queued -- wcsph_slab_step, allreduce_words_post / _wait)
 static int grid_sort(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;

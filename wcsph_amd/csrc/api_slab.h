@@ -296,8 +296,11 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
     const bool split = cb->allreduce_words_post && cb->allreduce_words_wait;
     if (split) { if ((rc = cb->allreduce_words_post(cb->user, words, nw))) return ctx->fail(rc, "slab callback allreduce_words_post failed"); }
     else if ((rc = cb->allreduce_words(cb->user, words, nw))) return ctx->fail(rc, "slab callback allreduce_words failed");
-    SRC(wcsph_grid_update_mid(ctx));
-    if (split && (rc = cb->allreduce_words_wait(cb->user))) return ctx->fail(rc, "slab callback allreduce_words_wait failed");
+    // (the posted all-reduce sums ctx->bcount in place while grid_sort / grid_lists are queued: neither touches bcount -- api_grid.h --
+    // and a failure in between still awaits it, so that the next step's pack never overwrites a buffer under a pending all-reduce)
+    rc = wcsph_grid_update_mid(ctx);
+    if (split) { const int rc2 = cb->allreduce_words_wait(cb->user); if (!rc && rc2) rc = ctx->fail(rc2, "slab callback allreduce_words_wait failed"); }
+    SRC(rc);
     SRC(wcsph_bucket_hist_unpack(ctx));
     SRC(wcsph_grid_update_end(ctx));
   } else SRC(wcsph_grid_update(ctx));
@@ -459,6 +462,10 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
       if (ctx->h_pred) {
         SRC(collect_mail(ctx, true, seqC));
         memcpy(&ctx->vel_max0, &ctx->h_flags[FLAG_VMAX], 4);
+        { float host_dt_before = ctx->dt; host_dt_rule((double)ctx->vel_max0);   // the host rule on the same inputs: compared, counted
+          float ddt; memcpy(&ddt, &ctx->h_flags[FLAG_DT], 4);
+          if (memcmp(&ddt, &ctx->dt, 4) != 0) ctx->n_dt_mismatch++;
+          ctx->dt = host_dt_before; }
         memcpy(&ctx->dt, &ctx->h_flags[FLAG_DT], 4);       // the device's deltaT is the one the queued kernels ran with: adopted
         dtn = ctx->dt;
         SRC(collect_mail(ctx, true, seqD));
