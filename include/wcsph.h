@@ -417,6 +417,23 @@ int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_sen
 int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_global, int32_t interior_lo, int32_t interior_hi,
                     int32_t flags, int32_t stats[2]);
 
+/* ---- slab state resident in the library (round 5) -------------------------------------------------------------------
+ * Instead of storing every row after a step and loading every row before the next (wcsph_store_state / wcsph_load_state*:
+ * 2 x 120 MB per step at C3), the driver leaves the state where it is and only handles the rows that travel:
+ *   wcsph_state_classify(ctx, lo, hi, ghost, has_left, has_right, d_idx, cap, d_counts): wcsph_slab_classify over the context's
+ *        OWN owned rows (original indices), by their current positions
+ *   wcsph_state_gather_rows(ctx, d_idx, n, d_rows): the STATE_W-float rows of the listed original indices
+ *   wcsph_state_apply(ctx, n_owned_new, d_fold_dst, d_fold_src, n_fold, d_write_idx, d_write_rows, n_write, d_ghost_rows, n_ghost):
+ *        original row fold_src[k] is relabelled fold_dst[k] (a staying row of the shrinking table's tail takes the index of a row
+ *        that left; no data moves); then d_write_rows[k] becomes original row write_idx[k] (arrivals: into the slots of rows that
+ *        left, or appended); then the n_ghost ghost rows become original rows n_owned_new ... (replacing the old ghosts).  The
+ *        arrays then have holes; the next grid update (wcsph_slab_step) drops them -- nothing else may run in between.
+ * (all index arrays int64 on the device, as wcsph_slab_classify returns them) */
+int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts);
+int wcsph_state_gather_rows(wcsph_ctx *ctx, const int64_t *d_idx, int32_t n, float *d_rows);
+int wcsph_state_apply(wcsph_ctx *ctx, int32_t n_owned_new, const int64_t *d_fold_dst, const int64_t *d_fold_src, int32_t n_fold,
+                      const int64_t *d_write_idx, const float *d_write_rows, int32_t n_write, const float *d_ghost_rows, int32_t n_ghost);
+
 /* ---- native data plane (wcsph_comm_init / wcsph_halo_exchange) -----------------------------------------
  * The library's own implementation of the communicator above on RCCL: grouped ncclSend / ncclRecv with the slab neighbours
  * and ncclAllReduce, all on the context's stream, no host code per exchange.  New work -- the reference step is single-device

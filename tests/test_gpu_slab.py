@@ -40,7 +40,7 @@ def _hip_run(rank, world, port, outdir, n):
     torch.cuda.synchronize()
     np.save(os.path.join(outdir, "hrows_w%d_r%d.npy" % (world, rank)), sim.rows.cpu().numpy())
     np.save(os.path.join(outdir, "hlog_w%d_r%d.npy" % (world, rank)), np.array(log))
-    np.save(os.path.join(outdir, "hwaits_w%d_r%d.npy" % (world, rank)), np.array([sim.n_host_waits, sim.n_exchanges, STEPS]))
+    np.save(os.path.join(outdir, "hwaits_w%d_r%d.npy" % (world, rank)), np.array([sim.n_host_waits, sim.n_exchanges, STEPS, getattr(sim, "n_resident", 0)]))
     sim.B.close()
     if world > 1:
         dist.barrier()
@@ -254,3 +254,32 @@ def test_native_classifier_equals_the_torch_classification():
             assert torch.equal(torch.nonzero(want).flatten(), torch.sort(have)[0])
         assert cnt == [int(near_l.sum()), int(near_r.sum()), int(go_l.sum()), int(go_r.sum()), int(lost.sum())]
     B.close()
+
+
+def test_resident_slab_state_equals_the_row_table_round_trip(tmp_path):
+    """Round 5: between two steps the state stays in the library -- the driver classifies the context's own rows, takes out the
+    ~6 % that travel and applies what arrives (wcsph_state_classify / _gather_rows / _apply; dead slots vanish in the next sort)
+    -- instead of storing and reloading every row (WCSPH_SLAB_RESIDENT=0: rounds 2-4).  Three ranks, rows crossing both cuts of the
+    interior rank, a forced rebalance on the way: the two forms agree to rounding level, and the resident form really ran."""
+    import slab_util
+    from test_slab_gloo import _free_port
+    n, world = 12, 3
+    res = {}
+    for flag in ("1", "0"):
+        out = os.path.join(str(tmp_path), "resident" + flag)
+        os.makedirs(out)
+        os.environ.update(WCSPH_SLAB_RESIDENT=flag, SLAB_TEST_REBALANCE_AT="3")
+        try:
+            mp.spawn(_hip_run, args=(world, _free_port(), out, n), nprocs=world, join=True)
+        finally:
+            os.environ.pop("WCSPH_SLAB_RESIDENT", None); os.environ.pop("SLAB_TEST_REBALANCE_AT", None)
+        rows = np.concatenate([np.load(os.path.join(out, "hrows_w%d_r%d.npy" % (world, r))) for r in range(world)])
+        logs = [np.load(os.path.join(out, "hlog_w%d_r%d.npy" % (world, r))) for r in range(world)]
+        used = [int(np.load(os.path.join(out, "hwaits_w%d_r%d.npy" % (world, r)))[3]) for r in range(world)]
+        res[flag] = (rows, logs, used)
+    assert min(res["1"][2]) >= STEPS - 2 and max(res["0"][2]) == 0          # every step but the first and the one after the rebalance
+    dpos, dvel, _ = slab_util.match_rows(res["1"][0], res["0"][0])
+    assert dpos < 1e-6 and dvel < 1e-4
+    for la, lb in zip(res["1"][1], res["0"][1]):
+        np.testing.assert_array_equal(la[:, :3], lb[:, :3])                   # iteration counts
+        np.testing.assert_array_equal(la[:, 4], lb[:, 4])                     # owned rows per step: the same migrations

@@ -225,6 +225,13 @@ def test_hip_fused_step_reproduces_the_reference_text(fixture):
         _close("pos", pd.pos.to_numpy(), f["s%d_end_pos" % s], 1e-6)
         _close("vel", pd.vel.to_numpy(), f["s%d_pressure_vel" % s], 2e-5)
         _close("kappa", dfsph.kappa.to_numpy(), f["s%d_pressure_kappa" % s], 5e-5)
+    # the deltaT the device formed on the speculative path (k_cfl_store, DtRule) is compared with the host rule of dfsph.py:113-129 on
+    # every such step and a difference is counted: none
+    import ctypes as C
+    from wcsph_amd import _lib
+    v, ctx = C.c_float(), pd._need_ctx()
+    _lib.check(ctx, _lib.load().wcsph_get_scalar(ctx, _lib.SCALAR_ID["dt_rule_mismatches"], C.byref(v)))
+    assert v.value == 0.0
     pd.close()
 
 

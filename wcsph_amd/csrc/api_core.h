@@ -22,6 +22,7 @@ struct wcsph_ctx {
   int n_alias = 0, scan_blocks = 0, n_regions = 0;
   unsigned char *bcount8 = nullptr;
   int *region_occ = nullptr;      // neighborCount regions that hold particles: flagged by k_cell_assign, cleared by k_ncount_box
+  int nl_phys = 0;                // > 0: the liquid arrays hold this many rows, some of them dead (a resident slab state between wcsph_state_apply and the sort that drops them)
   int grid_stage = 0;             // split grid update (api_grid.h): 1 cells assigned, 2 sorted, 3 lists built; 0 none in progress
   bool hist_valid = false;       // bcount8 == static + liquid histogram of the cells in pos.w (left by a complete update of one context): the next one may update it in place
   bool hist_inc = false;         // the update in progress does so

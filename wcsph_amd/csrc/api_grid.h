@@ -8,15 +8,17 @@ extern "C" {
 // binned per workgroup and counted in LDS (grid.h k_hash_bin / k_bin_hist), atomics when the table is too large for that
 static int bucket_hist_launches(wcsph_ctx *ctx, hipStream_t s2) {
   Dev &d = ctx->d;
-  const int nh = d.nl < d.n_owned ? d.nl : d.n_owned;
+  // (a resident slab state: owned rows are not a prefix of the arrays -- every row is looked at, ownership by its original index)
+  const int *live = ctx->nl_phys > 0 ? (const int *)d.oid : (const int *)nullptr;
+  const int nh = live ? ctx->nl_phys : (d.nl < d.n_owned ? d.nl : d.n_owned);
   if (nh > 0 && ctx->hb_bins) {
     if (ctx->hb_gen == 0x7fffffff) { HIPCHK(hipMemsetAsync(ctx->hb_bins + HB_FLAG, 0, sizeof(int), s2)); ctx->hb_gen = 0; }   // (wrap-around)
     const int gen = ++ctx->hb_gen;
     hipLaunchKernelGGL(k_hash_bin, dim3((nh + BLOCK * HB_ROWS - 1) / (BLOCK * HB_ROWS)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh,
-                       ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf, gen);
+                       ctx->hb_nbins, ctx->hb_cap, ctx->hb_bins, ctx->hb_buf, gen, live);
     hipLaunchKernelGGL(k_bin_hist, dim3(ctx->hb_nbins), dim3(1024), 0, s2, d, ctx->hb_cap, ctx->hb_bins, (const int *)ctx->hb_buf, ctx->bcount_l, gen);
-    hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh) < 512 ? nblk(nh) : 512), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins, gen);
-  } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l);
+    hipLaunchKernelGGL(k_bucket_hist_gated, dim3(nblk(nh) < 512 ? nblk(nh) : 512), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, ctx->hb_nbins, ctx->hb_bins, gen, live);
+  } else if (nh > 0) hipLaunchKernelGGL(k_bucket_hist, dim3(nblk(nh)), dim3(BLOCK), 0, s2, d, (const int *)ctx->pw, nh, ctx->bcount_l, live);
   return 0;
 }
 // The bucket histogram is not taken inside k_cell_assign (its 2 M random device-scope atomics were 71 of that kernel's 88 us at
@@ -63,10 +65,12 @@ static int grid_assign(wcsph_ctx *ctx, bool single = false) {   // single: wcsph
                   d.own_lo <= 0 && d.own_hi >= ctx->bs[0];
   ctx->hist_valid = false;
   if (ctx->hist_inc) { ctx->bcount_int_valid = false; ctx->n_hist_inc++; }
-  if (d.nl > 0)
-    hipLaunchKernelGGL(k_cell_assign, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, d.nl, ctx->cnt, ctx->pw, ctx->slot,
+  const int n_rows = ctx->nl_phys > 0 ? ctx->nl_phys : d.nl;   // (a resident slab state has holes: api_slab.h wcsph_state_apply)
+  if (n_rows > 0)
+    hipLaunchKernelGGL(k_cell_assign, dim3(nblk(n_rows)), dim3(BLOCK), 0, s, d, (const float4 *)d.pos, n_rows, ctx->cnt, ctx->pw, ctx->slot,
                        (int *)nullptr, ctx->bbox_part, d.n_owned,
-                       ctx->region_occ, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr);
+                       ctx->region_occ, ctx->hist_inc ? reinterpret_cast<unsigned *>(ctx->bcount8) : (unsigned *)nullptr,
+                       ctx->nl_phys > 0 ? (const int *)d.oid : (const int *)nullptr);
   if (d.faithful && !ctx->hist_inc) { int rc_ = bucket_hist_launches(ctx, s); if (rc_) return rc_; }   // (a slab: before the all-reduce)
   LAUNCHCHK();
   ctx->grid_stage = 1;
@@ -79,19 +83,21 @@ static int grid_sort(wcsph_ctx *ctx) {
   Dev &d = ctx->d;
   const int nscan = d.ncell_p + 2;
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, d.nl > 0 ? nblk(d.nl) : 0, d.bbox);
+  const int n_rows = ctx->nl_phys > 0 ? ctx->nl_phys : d.nl;
+  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, s, (const int *)ctx->bbox_part, n_rows > 0 ? nblk(n_rows) : 0, d.bbox);
   int rc = run_scan(ctx, ctx->cnt, nscan, d.cs_l, d.bbox, 1);
   if (rc) return rc;
   if (d.nl > 0) {
     SortBuffers b = {d.pos, d.vel, d.vel_guess, d.omega, d.kappa, d.kappa_v, d.pressure, d.oid,
                      ctx->pos_b, ctx->vel_b, ctx->vel_guess_b, ctx->omega_b, ctx->kappa_b, ctx->kappa_v_b, ctx->pressure_b, ctx->oid_b, d.where};
-    hipLaunchKernelGGL(k_scatter_liquid, dim3(nblk(d.nl)), dim3(BLOCK), 0, s, d, b, (const int *)d.cs_l, (const int *)ctx->pw,
-                       (const int *)ctx->slot);
+    hipLaunchKernelGGL(k_scatter_liquid, dim3(nblk(n_rows)), dim3(BLOCK), 0, s, d, b, (const int *)d.cs_l, (const int *)ctx->pw,
+                       (const int *)ctx->slot, n_rows);
     std::swap(d.pos, ctx->pos_b); std::swap(d.vel, ctx->vel_b); std::swap(d.vel_guess, ctx->vel_guess_b);
     std::swap(d.omega, ctx->omega_b); std::swap(d.kappa, ctx->kappa_b); std::swap(d.kappa_v, ctx->kappa_v_b);
     std::swap(d.oid, ctx->oid_b); std::swap(d.pressure, ctx->pressure_b);
   }
   LAUNCHCHK();
+  ctx->nl_phys = 0;   // the sorted arrays are compact
   ctx->grid_stage = 2;
   return 0;
 }

@@ -45,6 +45,47 @@ int wcsph_slab_classify(wcsph_ctx *ctx, const void *d_rows, int64_t n, int32_t l
   return WCSPH_OK;
 }
 
+// ---- slab state resident in the library between steps (round 5): the driver no longer stores and reloads every row per step
+// (2 x 120 MB at C3, 0.1 ms) -- it classifies the context's own rows, takes out the few that travel and applies what arrives.
+int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts) {
+  NEED_SETUP();
+  if (cap < 0 || !d_idx || !d_counts) return WCSPH_EARG;
+  if (ctx->nl_phys > 0) return ctx->fail(WCSPH_EARG, "wcsph_state_classify: the state has pending changes (wcsph_state_apply) that no grid update has sorted in yet");
+  HIPCHK(hipMemsetAsync(d_counts, 0, 5 * sizeof(int32_t), ctx->stream));
+  const long long n = ctx->d.n_owned;
+  if (n > 0)
+    hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)ctx->d.pos, n, 4,
+                       ctx->d.minx, ctx->d.inv_grid, lo, hi, ghost, has_left, has_right, (long long *)d_idx, cap, d_counts, (const int *)ctx->d.where);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_state_gather_rows(wcsph_ctx *ctx, const int64_t *d_idx, int32_t n, float *d_rows) {
+  NEED_SETUP();
+  if (n < 0 || (n > 0 && (!d_idx || !d_rows))) return WCSPH_EARG;
+  if (ctx->nl_phys > 0) return ctx->fail(WCSPH_EARG, "wcsph_state_gather_rows: the state has pending changes (wcsph_state_apply)");
+  if (n > 0) hipLaunchKernelGGL(k_state_gather_rows, dim3(nblk(n)), dim3(BLOCK), 0, ctx->stream, ctx->d, (const long long *)d_idx, n, d_rows);
+  LAUNCHCHK();
+  return WCSPH_OK;
+}
+int wcsph_state_apply(wcsph_ctx *ctx, int32_t n_owned_new, const int64_t *d_fold_dst, const int64_t *d_fold_src, int32_t n_fold,
+                      const int64_t *d_write_idx, const float *d_write_rows, int32_t n_write, const float *d_ghost_rows, int32_t n_ghost) {
+  NEED_SETUP();
+  if (n_owned_new < 0 || n_fold < 0 || n_write < 0 || n_ghost < 0 || (long)n_owned_new + n_ghost > ctx->capacity) return ctx->fail(WCSPH_EARG, "wcsph_state_apply: counts exceed the context capacity");
+  if ((n_fold > 0 && (!d_fold_dst || !d_fold_src)) || (n_write > 0 && (!d_write_idx || !d_write_rows)) || (n_ghost > 0 && !d_ghost_rows)) return WCSPH_EARG;
+  if (ctx->nl_phys > 0) return ctx->fail(WCSPH_EARG, "wcsph_state_apply: called twice without a grid update in between");
+  Dev &d = ctx->d;
+  const int nl_old = d.nl;
+  hipStream_t s = ctx->stream;
+  if (n_fold > 0) hipLaunchKernelGGL(k_state_relabel, dim3(nblk(n_fold)), dim3(BLOCK), 0, s, d, (const long long *)d_fold_dst, (const long long *)d_fold_src, n_fold);
+  if (n_write > 0) hipLaunchKernelGGL(k_state_write_rows, dim3(nblk(n_write)), dim3(BLOCK), 0, s, d, (const long long *)d_write_idx, 0, d_write_rows, n_write, nl_old);
+  if (n_ghost > 0) hipLaunchKernelGGL(k_state_write_rows, dim3(nblk(n_ghost)), dim3(BLOCK), 0, s, d, (const long long *)nullptr, n_owned_new, d_ghost_rows, n_ghost, nl_old);
+  LAUNCHCHK();
+  d.n_owned = n_owned_new; d.nl = n_owned_new + n_ghost;
+  ctx->nl_phys = nl_old > d.nl ? nl_old : d.nl;   // rows [d.nl, nl_old) by original index are dead until the sort drops them
+  ctx->grid_valid = ctx->hist_valid = false;
+  ctx->pr_valid = false;
+  return WCSPH_OK;
+}
 int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, void *d_out) {
   NEED_SETUP();
   HaloFields h;
@@ -70,7 +111,7 @@ int wcsph_halo_unpack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, c
 int wcsph_load_state(wcsph_ctx *ctx, int32_t n_owned, int32_t n_total, const float *d_rows) {
   NEED_SETUP();
   if (n_owned < 0 || n_total < n_owned || n_total > ctx->capacity) return ctx->fail(WCSPH_EARG, "load_state: counts exceed the context capacity");
-  ctx->d.nl = n_total; ctx->d.n_owned = n_owned;
+  ctx->d.nl = n_total; ctx->d.n_owned = n_owned; ctx->nl_phys = 0;
   if (n_total > 0) {
     if (!d_rows) return WCSPH_EARG;
     hipLaunchKernelGGL(k_load_state, dim3(nblk(n_total)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows, n_total, 0);
@@ -83,7 +124,7 @@ int wcsph_load_state_split(wcsph_ctx *ctx, int32_t n_owned, const float *d_owned
   NEED_SETUP();
   if (n_owned < 0 || n_ghost < 0 || (long)n_owned + n_ghost > ctx->capacity) return ctx->fail(WCSPH_EARG, "load_state: counts exceed the context capacity");
   if ((n_owned > 0 && !d_owned_rows) || (n_ghost > 0 && !d_ghost_rows)) return WCSPH_EARG;
-  ctx->d.nl = n_owned + n_ghost; ctx->d.n_owned = n_owned;
+  ctx->d.nl = n_owned + n_ghost; ctx->d.n_owned = n_owned; ctx->nl_phys = 0;
   if (n_owned > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_owned)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_owned_rows, n_owned, 0);
   if (n_ghost > 0) hipLaunchKernelGGL(k_load_state, dim3(nblk(n_ghost)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_ghost_rows, n_ghost, n_owned);
   LAUNCHCHK();
@@ -92,6 +133,7 @@ int wcsph_load_state_split(wcsph_ctx *ctx, int32_t n_owned, const float *d_owned
 }
 int wcsph_store_state(wcsph_ctx *ctx, float *d_rows) {
   NEED_SETUP();
+  if (ctx->nl_phys > 0) return ctx->fail(WCSPH_EARG, "wcsph_store_state: the state has pending changes (wcsph_state_apply) that no grid update has sorted in yet");
   if (ctx->d.nl > 0) {
     if (!d_rows) return WCSPH_EARG;
     if (ctx->d.n_owned > 0) hipLaunchKernelGGL(k_store_state, dim3(nblk(ctx->d.n_owned)), dim3(BLOCK), 0, ctx->stream, ctx->d, d_rows);

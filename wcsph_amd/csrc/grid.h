@@ -50,12 +50,19 @@ __device__ __forceinline__ int region_of_cell(const Dev &d, int w) {   // w: pac
 // in its old bucket, one more in the new one (32-bit atomics on the containing word, no value returned).  The cap is checked by
 // k_cellval_occ, which reads the count of every cell that holds a particle AFTER all of the update's atomics (a bucket that one
 // particle leaves and another enters in the same update may pass the cap for a moment, whichever atomic lands first).
+// live != nullptr (a slab whose state stays in the library between steps, api_slab.h wcsph_state_apply): the rows are in LAST
+// step's sorted order with holes -- row i is original row live[i]; it is DEAD (a row that left, or an old ghost slot nobody
+// took) when live[i] >= d.nl, and owned when live[i] < count_limit.  Dead rows get cell word CELL_DEAD and vanish in the sort.
+#define CELL_DEAD (-2)
 __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos, int n, int *cnt, int *pw, int *slot, int *bcount, int *bbox, int count_limit, int *occ = nullptr,
-                                                      unsigned *inc8 = nullptr) {
+                                                      unsigned *inc8 = nullptr, const int *live = nullptr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-  if (i < n) {
+  bool dead = false;
+  if (i < n && live) { dead = live[i] >= d.nl; if (dead) st_once(pw + i, CELL_DEAD); }
+  if (i < n && !dead) {
     float4 p = ld_once(pos + i);
+    const bool mine = live ? live[i] < count_limit : i < count_limit;
     int lin;
     bool finite;
     int w = cell_packed(d, xyz(p), &lin, &finite);
@@ -63,7 +70,7 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
     if (!finite) atomicOr(&d.flags[FLAG_ERR], ERRBIT_NONFINITE);
     st_once(pw + i, w);
     st_once(slot + i, atomicAdd(&cnt[lin], 1));
-    if (inc8 && i < count_limit) {
+    if (inc8 && mine) {
       const int wo = __float_as_int(p.w);
       if (wo != w) {
         if (wo >= 0) {
@@ -85,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
       // particles by their owner (ghost rows sit behind the owned ones before the sort), boundary particles by the rank
       // whose owned columns hold them (own_lo <= global cell x < own_hi)
       const int gx = (w & 1023) + d.x0;
-      if (bcount && i < count_limit && gx >= d.own_lo && gx < d.own_hi)
+      if (bcount && mine && gx >= d.own_lo && gx < d.own_hi)
         atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
       lo[0] = hi[0] = w & 1023; lo[1] = hi[1] = (w >> 10) & 1023; lo[2] = hi[2] = w >> 20;
       if (occ) occ[region_of_cell(d, w)] = 1;
@@ -111,11 +118,12 @@ __global__ void __launch_bounds__(BLOCK) k_cell_assign(Dev d, const float4 *pos,
 }
 // the reference bucket histogram on its own (wcsph_grid_update of one faithful context: beside the sort, on the side stream):
 // rows [0, n) = the owned liquid rows, cells from k_cell_assign's packed words, the same ownership rule
-__global__ void __launch_bounds__(BLOCK) k_bucket_hist(Dev d, const int *pw, int n, int *bcount) {
+// live != nullptr (resident slab state, see k_cell_assign): the owned rows are those with live[i] < n_owned, among all n rows
+__global__ void __launch_bounds__(BLOCK) k_bucket_hist(Dev d, const int *pw, int n, int *bcount, const int *live = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int w = pw[i];
-  if (w < 0) return;
+  if (w < 0 || (live && live[i] >= d.n_owned)) return;
   const int gx = (w & 1023) + d.x0;
   if (gx >= d.own_lo && gx < d.own_hi) atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
 }
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist(Dev d, const int *pw, int
 #define HB_MAXBINS 1024   /* tables up to 33.5 M buckets (a 16 M + 4 M particle decomposition has 20 M) */
 #define HB_FLAG HB_MAXBINS
 #define HB_ROWS 16
-__global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n, int nbins, int cap, int *bins, int *binbuf, int gen) {
+__global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n, int nbins, int cap, int *bins, int *binbuf, int gen, const int *live = nullptr) {
   __shared__ int cnt[HB_MAXBINS], base[HB_MAXBINS];
   for (int b = threadIdx.x; b < nbins; b += BLOCK) cnt[b] = 0;
   __syncthreads();
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(BLOCK) k_hash_bin(Dev d, const int *pw, int n,
     h[r] = -1; at[r] = 0;
     if (i < n) {
       const int w = pw[i];
-      if (w >= 0) {
+      if (w >= 0 && !(live && live[i] >= d.n_owned)) {
         const int gx = (w & 1023) + d.x0;
         if (gx >= d.own_lo && gx < d.own_hi) h[r] = ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size);
       }
@@ -177,13 +185,13 @@ __global__ void __launch_bounds__(1024) k_bin_hist(Dev d, int cap, int *bins, co
 }
 // the atomics path, only when a range list overflowed (also leaves the lists empty for the next update)
 // (grid-stride over a SMALL grid: in the usual case every block of this launch only reads the flag and leaves)
-__global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *pw, int n, int *bcount, int nbins, int *bins, int gen) {
+__global__ void __launch_bounds__(BLOCK) k_bucket_hist_gated(Dev d, const int *pw, int n, int *bcount, int nbins, int *bins, int gen, const int *live = nullptr) {
   if (bins[HB_FLAG] != gen) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < max(n, nbins); i += gridDim.x * blockDim.x) {
     if (i < nbins) bins[i] = 0;
     if (i >= n) continue;
     const int w = pw[i];
-    if (w < 0) continue;
+    if (w < 0 || (live && live[i] >= d.n_owned)) continue;
     const int gx = (w & 1023) + d.x0;
     if (gx >= d.own_lo && gx < d.own_hi) atomicAdd(&bcount[ref_hash(gx, (w >> 10) & 1023, w >> 20, d.table_size)], 1);
   }
@@ -226,10 +234,12 @@ struct SortBuffers {
   float *kappa_o, *kappa_v_o, *pressure_o;
   int *oid_o, *where;
 };
-__global__ void k_scatter_liquid(Dev d, SortBuffers b, const int *cs, const int *pw, const int *slot) {
+// n: rows to scatter (d.nl; more when the state has holes: rows with cell word CELL_DEAD are dropped, see k_cell_assign)
+__global__ void k_scatter_liquid(Dev d, SortBuffers b, const int *cs, const int *pw, const int *slot, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.nl) return;
+  if (i >= n) return;
   int w = ld_once(pw + i);
+  if (w == CELL_DEAD) return;
   int dst = cs[lin_of(d, w)] + ld_once(slot + i);
   float4 p = ld_once(b.pos + i);
   p.w = __int_as_float(w);
@@ -743,6 +753,47 @@ __global__ void __launch_bounds__(BLOCK) k_store_state(Dev d, float *rows) {   /
   for (int k = threadIdx.x; k < cnt * STATE_W; k += BLOCK) dst[k] = sh[k];
 }
 
+// ---- slab state resident in the library (api_slab.h wcsph_state_*): only the rows that travel leave it --------------------
+// rows (STATE_W floats) of the listed ORIGINAL indices
+__global__ void __launch_bounds__(BLOCK) k_state_gather_rows(Dev d, const long long *idx, int n, float *out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int o = (int)idx[k], i = d.where[o];
+  const float4 p = d.pos[i], v = d.vel[i], w = d.omega[i], g = d.vel_guess[i];
+  float *r = out + (size_t)k * STATE_W;
+  r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = v.x; r[4] = v.y; r[5] = v.z; r[6] = w.x; r[7] = w.y; r[8] = w.z;
+  r[9] = g.x; r[10] = g.y; r[11] = g.z; r[12] = d.kappa[i]; r[13] = d.kappa_v[i];
+  r[14] = __int_as_float(d.gid ? d.gid[o] : o);
+}
+// original row src[k] becomes original row dst[k] (a staying row of the shrinking table's tail takes the index of a row that left):
+// the two rows swap labels, no data moves.  The sources and the destinations are disjoint sets.
+__global__ void __launch_bounds__(BLOCK) k_state_relabel(Dev d, const long long *dst, const long long *src, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int t = (int)src[k], h = (int)dst[k];
+  const int st = d.where[t], sh = d.where[h];
+  d.where[h] = st; d.oid[st] = h;
+  d.where[t] = sh; d.oid[sh] = t;
+  if (d.gid) d.gid[h] = d.gid[t];
+}
+// rows[k] -> original row (idx ? idx[k] : first + k): into the slot that original index has (a row that left, an old ghost) or,
+// beyond the nl_old rows the table had, into a new slot of its own
+__global__ void __launch_bounds__(BLOCK) k_state_write_rows(Dev d, const long long *idx, int first, const float *rows, int n, int nl_old) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int o = idx ? (int)idx[k] : first + k;
+  int i = o;
+  if (o < nl_old) i = d.where[o]; else { d.where[o] = o; d.oid[o] = o; }
+  const float *r = rows + (size_t)k * STATE_W;
+  d.pos[i] = make_float4(r[0], r[1], r[2], __int_as_float(-1));
+  d.vel[i] = make_float4(r[3], r[4], r[5], 0);
+  d.omega[i] = make_float4(r[6], r[7], r[8], 0);
+  d.vel_guess[i] = make_float4(r[9], r[10], r[11], 0);
+  d.kappa[i] = r[12];
+  d.kappa_v[i] = r[13];
+  if (d.gid) d.gid[o] = __float_as_int(r[14]);
+}
+
 // ---- original-order <-> sorted-order field transfer ---------------------------------------
 __global__ void k_unpermute3(const float4 *f, const int *oid, int n, float *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,8 +827,9 @@ __global__ void k_permute1(float *f, const int *where, int n, const float *in) {
 // reserves its share of each list with ONE device atomic per class (one per wave was 125 k atomics on five addresses at
 // 2 M rows: 1 ms); order inside a list is arbitrary.  Cell column exactly as the grid update forms it (ref: HashGrid.py:68).
 constexpr int CLS_ROWS = 16;
+// where != nullptr: the rows are the context's own (x of original row i = rows[where[i] * W])
 __global__ void __launch_bounds__(BLOCK) k_slab_classify(const float *rows, long long n, int W, float minx, float inv_grid, int lo, int hi, int ghost,
-                                                         int has_l, int has_r, long long *idx, int cap, int *counts) {
+                                                         int has_l, int has_r, long long *idx, int cap, int *counts, const int *where = nullptr) {
   __shared__ int cnt[5], base[5];
   if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -789,7 +841,7 @@ __global__ void __launch_bounds__(BLOCK) k_slab_classify(const float *rows, long
     const long long i = first + (long long)r * BLOCK;
     int cls = -1;
     if (i < n) {
-      const int cx = (int)__fmul_rn(__fsub_rn(rows[i * W], minx), inv_grid);
+      const int cx = (int)__fmul_rn(__fsub_rn(rows[(where ? (long long)where[i] : i) * W], minx), inv_grid);
       if (has_l) { if (cx < lo + ghost) cls = 0; if (cx < lo) cls = 2; if (cx < lo - ghost) cls = 4; }
       if (has_r) { if (cx >= hi - ghost) cls = 1; if (cx >= hi) cls = 3; if (cx >= hi + ghost) cls = 4; }
     }

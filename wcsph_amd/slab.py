@@ -122,6 +122,42 @@ class HipBackend:
             return None
         return c, [self._cls_idx[k, :c[k]] for k in range(4)]
 
+    # ---- state resident in the library between steps (include/wcsph.h "slab state resident in the library") -------------
+    def classify_state(self, lo, hi, ghost, has_l, has_r):
+        """classify_rows over the context's OWN owned rows (no row table in the driver): counts + four int64 lists of
+        original indices, one launch and one host wait; None when a list did not fit its buffer"""
+        n = int(self.n_owned)
+        cap = max(65536, n // 8)
+        if getattr(self, "_cls_idx", None) is None or self._cls_idx.shape[1] < cap:
+            self._cls_idx = torch.empty((4, cap), dtype=torch.int64, device=self.device)
+            self._cls_cnt = torch.empty(5, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.wcsph_state_classify(self.ctx, int(lo), int(hi), int(ghost), int(has_l), int(has_r),
+                                                C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.c_void_p(self._cls_cnt.data_ptr())))
+        c = self._cls_cnt.tolist()
+        if max(c[:4]) > self._cls_idx.shape[1]:
+            return None
+        return c, [self._cls_idx[k, :c[k]] for k in range(4)]
+
+    def gather_state_rows(self, idx):
+        """the STATE_W-float rows of the listed original indices (int64, device)"""
+        idx = idx.contiguous()
+        out = torch.empty((int(idx.numel()), STATE_W), dtype=torch.float32, device=self.device)
+        if idx.numel():
+            self._chk(self.lib.wcsph_state_gather_rows(self.ctx, C.c_void_p(idx.data_ptr()), int(idx.numel()), C.c_void_p(out.data_ptr())))
+        return out
+
+    def apply_state(self, n_owned_new, fold_dst, fold_src, write_idx, write_rows, ghosts):
+        """ownership changes applied to the resident state (wcsph_state_apply): relabels, arrivals, the new ghost rows"""
+        fold_dst, fold_src, write_idx = fold_dst.contiguous(), fold_src.contiguous(), write_idx.contiguous()
+        write_rows, ghosts = write_rows.contiguous(), ghosts.contiguous()
+        if n_owned_new + ghosts.shape[0] > self.capacity:
+            raise RuntimeError("slab capacity %d exceeded (%d rows)" % (self.capacity, n_owned_new + ghosts.shape[0]))
+        self._chk(self.lib.wcsph_state_apply(self.ctx, int(n_owned_new), C.c_void_p(fold_dst.data_ptr()), C.c_void_p(fold_src.data_ptr()), int(fold_dst.numel()),
+                                             C.c_void_p(write_idx.data_ptr()), C.c_void_p(write_rows.data_ptr()), int(write_idx.numel()),
+                                             C.c_void_p(ghosts.data_ptr()), int(ghosts.shape[0])))
+        self.n_owned = int(n_owned_new)
+        self._keep = (fold_dst, fold_src, write_idx, write_rows, ghosts)   # alive until the stream has consumed them
+
     def store_state(self):
         # a view of a slightly larger buffer: rows that arrive next step are appended in place (SlabSim._swap_rows)
         slack = max(4096, self.n_owned // 64)
@@ -355,6 +391,7 @@ class SlabSim:
                 counts = [int(c.item()) for c in allc]
             gid_local = sum(counts[:rank]) + np.arange(n_local, dtype=np.int64)
         rows[:, 14] = np.asarray(gid_local, np.int32).view(np.float32)
+        self._rows = None
         self.rows = torch.from_numpy(rows).to(self.device)
         self.B = None
         # ONE stream for the life of the simulation, handed to every backend (a rebalance rebuilds the backend)
@@ -374,6 +411,7 @@ class SlabSim:
         # WCSPH_SLAB_NATIVE=0: drive the step phase by phase from Python (the form the checker backend of the CPU tests
         # runs, kept in step with wcsph_slab_step by tests/test_gpu_slab.py)
         self.native = os.environ.get("WCSPH_SLAB_NATIVE", "1") != "0"
+        self.resident = os.environ.get("WCSPH_SLAB_RESIDENT", "1") != "0"
         # the native step queues the common-case continuation behind every solver decision (wcsph_slab_step); False: one host
         # wait per decision (tests compare the two)
         self.speculate = os.environ.get("WCSPH_SLAB_SPECULATE", "1") != "0"
@@ -381,6 +419,25 @@ class SlabSim:
         self._cb_exc = None
         # flags bit 3 of wcsph_slab_step: call the communicator at every exchange point even with one rank (tools/slab_overhead.py)
         self.force_comm = os.environ.get("WCSPH_SLAB_FORCE_COMM", "0") == "1"
+
+    # ---- the owned rows (STATE_W floats each) ------------------------------------------------------------------------------
+    # With the HIP backend and the native step the state LIVES IN THE LIBRARY between steps (WCSPH_SLAB_RESIDENT=0 switches it
+    # off): `rows` is then materialised on demand (wcsph_store_state) -- by a test, a tool, the rebalance -- and a
+    # materialised table is the truth again: the next redistribute() loads it in full, as rounds 2-4 did every step
+    # (0.052 + 0.047 ms of the driver's 0.115 ms per step at C3, profiles/r05_slab_overhead.txt).
+    @property
+    def rows(self):
+        if self._rows is None:
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    self._rows = self.B.store_state()
+            else:
+                self._rows = self.B.store_state()
+        return self._rows
+
+    @rows.setter
+    def rows(self, value):
+        self._rows = value
 
     # ---- the native data plane: RCCL inside the library instead of torch.distributed behind callbacks ----------------------
     def enable_native_comm(self, neighbours=None):
@@ -719,6 +776,8 @@ class SlabSim:
         refreshes follow from the same bookkeeping on both sides:
             my send list to L  = my near-cut rows (in sent order) ++ the rows L just handed to me (in received order)
             L's ghost rows of me = what it received as ghosts       ++ what it handed to me."""
+        if self._rows is None:
+            return self._redistribute_resident()
         rows = self.rows
         i32 = torch.int32
         if self.world == 1:
@@ -783,6 +842,75 @@ class SlabSim:
             self.B.load_state_split(rows, (gl, gr))
         else:
             self.B.load_state(n, torch.cat([rows, gl, gr], 0))
+
+    def _redistribute_resident(self):
+        """redistribute() on the state that stayed in the library (the previous step ran through wcsph_slab_step and nobody
+        has asked for `rows` since): the same bookkeeping, but only the rows that travel -- ~6 % of a slab -- leave the
+        library, and what arrives is written into the slots of what left (wcsph_state_apply); no row table in the driver."""
+        B = self.B
+        i32 = torch.int32
+        self.n_resident = getattr(self, "n_resident", 0) + 1
+        if self.world == 1 and not getattr(self, "loopback", False):
+            return                                           # nothing moves, nothing to reload: the state is where the step left it
+        G = GHOST_CELLS
+        n = int(self.n_owned)
+        has_l, has_r = self.rank > 0, self.rank < self.world - 1
+        native = B.classify_state(self.lo, self.hi, G, has_l, has_r)
+        self.n_host_waits += 1
+        if native is None:                                   # a list overflowed its buffer: the classic path on a materialised table
+            _ = self.rows
+            return self.redistribute()
+        (n_nl, n_nr, n_ml, n_mr, n_lost), (idx_nl, idx_nr, idx_gl, idx_gr) = native
+        if n_lost:
+            raise RuntimeError("rank %d: %d particles moved more than %d cell columns past a cut in one step (CFL violated); "
+                               "they would land outside the neighbour's cell window" % (self.rank, n_lost, G))
+        out = B.gather_state_rows(torch.cat([idx_gl, idx_nl, idx_gr, idx_nr]))
+        to_l, to_r = out[:n_ml + n_nl], out[n_ml + n_nl:]
+        mig_l, mig_r = to_l[:n_ml], to_r[:n_mr]
+        in_l, in_r, hl, hr = self._exchange_var(to_l, to_r, (n_ml,), (n_mr,))
+        a_l, a_r = int(hl[0]), int(hr[0])
+        arrivals = torch.cat([in_l[:a_l], in_r[:a_r]], 0) if (a_l or a_r) else out[:0]
+        n_new, pos_arr, idx_nl, idx_nr, fold_dst, fold_src = self._swap_plan(n, torch.cat([idx_gl, idx_gr]), int(arrivals.shape[0]), idx_nl, idx_nr)
+        gl = torch.cat([in_l[a_l:], mig_l], 0)
+        gr = torch.cat([in_r[a_r:], mig_r], 0)
+        B.apply_state(n_new, fold_dst, fold_src, pos_arr, arrivals, torch.cat([gl, gr], 0))
+        n = n_new
+        self.send_l = torch.cat([idx_nl, pos_arr[:a_l]]).to(i32)
+        self.send_r = torch.cat([idx_nr, pos_arr[a_l:]]).to(i32)
+        self.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=self.device)
+        self.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=self.device)
+        self.send_all = torch.cat([self.send_l, self.send_r])
+        self.ghost_all = torch.cat([self.ghost_l, self.ghost_r])
+        self.n_owned = n
+
+    def _swap_plan(self, n, holes, a, *index_lists):
+        """_swap_rows as a PLAN on indices (the rows themselves live in the library): a table of n rows loses the rows `holes`
+        (k indices) and gains `a` arrivals.  Returns (n', positions of the arrivals, the index lists translated, fold_dst,
+        fold_src): a >= k: the first k arrivals take the holes, the rest is appended at n ..; a < k: the arrivals take the first
+        a holes, the table shrinks by L = k - a, and the rows of its last L slots that stay are relabelled (fold_src -> fold_dst)
+        into the remaining holes below the new end -- an arrival that took a hole in the tail is folded like any other row."""
+        k = int(holes.shape[0])
+        dev = holes.device
+        none = torch.zeros(0, dtype=torch.int64, device=dev)
+        if a >= k:
+            pos = torch.cat([holes, torch.arange(n, n + a - k, dtype=torch.int64, device=dev)])
+            return (n + a - k, pos) + index_lists + (none, none)
+        rest, L = holes[a:], k - a
+        n_new = n - L
+        in_tail = rest >= n_new
+        hole_tail = torch.zeros(L + 1, dtype=torch.bool, device=dev)
+        hole_tail[torch.where(in_tail, rest - n_new, L)] = True          # slot L: dummy for the holes below the new end
+        keep = ~hole_tail[:L]
+        below = ~in_tail
+        target = torch.full((L + 1,), n, dtype=torch.int64, device=dev)
+        target[torch.where(below, torch.cumsum(below, 0) - 1, L)] = rest
+        tail = n_new + torch.arange(L, device=dev)
+        dest = torch.where(keep, target[:L][(torch.cumsum(keep, 0) - 1).clamp_(min=0)], tail)
+        out = []
+        for lst in (holes[:a],) + index_lists:
+            moved = lst >= n_new
+            out.append(torch.where(moved, dest[(lst - n_new).clamp_(min=0)], lst))
+        return (n_new,) + tuple(out) + (dest[keep], tail[keep])
 
     def _swap_rows(self, rows, holes, arrivals, *index_lists):
         """rows (n, W) loses the rows `holes` (k indices) and gains `arrivals` (a rows), in place where it can.
@@ -900,7 +1028,8 @@ class SlabSim:
             # the rest of the step -- every phase, halo refresh, solver loop and the dt rule below -- runs inside the
             # library (wcsph_slab_step); this rank's communicator is reached through callbacks
             self.dt, self.vs_iter, self.dv_iter, self.pr_iter, self.avg_density_err = B.native_step(self)
-            self.rows = B.store_state()
+            # the state stays in the library (`rows` materialises on demand); otherwise one copy out per step
+            self.rows = None if (self.resident and hasattr(B, "apply_state")) else B.store_state()
             return float(self.dt)
         B.set_scalar("deltaT", self.dt)
         if self.neighbor_mode == "faithful" and self.world > 1:
