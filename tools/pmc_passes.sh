@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes for one kernel group (each pass its own run; --kernel-trace only, per the pool rules).
 # Summaries are extracted on the box (the rocpd databases are too big to ship back).
-# usage: tools/pmc_passes.sh <group> <kernel-regex> <out.txt>
+# usage: tools/pmc_passes.sh <group> <kernel-regex> <out.txt> [mode] [steps before the measurement: 5 = at rest, 1200 = developed]
 G=${1:-pressure_iter}; RX=${2:-"k_vel_from_k|k_drho_press"}; OUTTXT=${3:-/root/repo/gpurun_out/pmc_summary.txt}; R=/root/repo
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcw; mkdir -p /tmp/pmcw
@@ -14,7 +14,7 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
          "TCC_HIT TCC_MISS TCC_REQ" \
          "TA_BUSY TA_TOTAL_WAVEFRONTS"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$RX" -d /tmp/pmcw/p$i -o pmc -- python $R/tools/run_kernel_group.py $G 3 126 ${4:-faithful} > /tmp/pmcw/p$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$RX" -d /tmp/pmcw/p$i -o pmc -- python $R/tools/run_kernel_group.py $G 3 126 ${4:-faithful} ${5:-5} > /tmp/pmcw/p$i.log 2>&1
   echo "## pass $i: $C (rc=$?)" >> $OUTTXT
   for K in $(echo $RX | tr '|' ' '); do
     echo "# $K" >> $OUTTXT
