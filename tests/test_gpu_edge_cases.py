@@ -131,3 +131,30 @@ def test_results_are_reproducible_to_rounding():
     assert out[0][2] == out[1][2]
     assert np.abs(out[0][0] - out[1][0]).max() < 1e-6
     assert rel_err(out[0][1], out[1][1]) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["faithful", "clean"])
+def test_large_sparse_grid_takes_the_prefixed_scan(mode):
+    """beyond ~16 M cells the cell-counter scan prefix-sums its block totals once (grid.h k_scan_bsums, SCAN_BPRE_MIN)
+    instead of having every block re-read them.  Two small liquid blocks in opposite corners of a 300^3-cell box (27 M cells, 13 k
+    scan blocks, the occupied bounding box spans the domain so that every block is active): raw list lengths, bucket occupancy and one
+    DFSPH step against the oracle (ref: HashGrid.py:56-106)."""
+    from oracle import Oracle
+    R, L = 0.025, 14.9
+    big = np.array([[0.0, 0.0, 0.0], [L, L, L]])
+    k = np.arange(6 ** 3)
+    blk = np.stack([k // 36, (k // 6) % 6, k % 6], 1) * (2 * R) + 0.31
+    rng = np.random.default_rng(5)
+    liquid = np.concatenate([blk, L - 0.3 - blk]) + rng.uniform(-0.2, 0.2, (2 * len(blk), 3)) * R
+    g = GpuSim(liquid, big, mode=mode)
+    assert int(np.prod(g.pd.hash_grid.blockSize.to_numpy()[0].astype(np.int64))) > 8192 * 2048           # more scan blocks than SCAN_BPRE_MIN
+    o = Oracle(g.pd.pos.to_numpy(), len(liquid), R, mode=mode)
+    g.pd.hash_grid.update_grid(); o.update_grid()
+    np.testing.assert_array_equal(g.pd.hash_grid.neighborCount.to_numpy(), o.neighborCount)
+    if mode == "faithful":
+        np.testing.assert_array_equal(g.pd.hash_grid.gridCount, o.gridCount)
+    g.call("dfsph_reset_param"); o.reset_param()
+    g.call("dfsph_step"); o.dfsph_step()
+    assert rel_err(g.pd.rho.to_numpy(), o.rho) < 1e-5
+    assert np.abs(g.pd.pos.to_numpy()[:len(liquid)] - o.pos[:len(liquid)]).max() < 2e-6
+    g.close(); o.close()
