@@ -139,3 +139,31 @@ def test_halo_exchange_and_allreduce_entry_points():
     np.testing.assert_array_equal(words.cpu().numpy(), np.arange(1000, dtype=np.int32))
     np.testing.assert_array_equal(dbl.cpu().numpy(), dbl0)
     sim.B.close()
+
+
+def test_native_communicator_survives_a_rebuilt_context():
+    """A rebalance of the decomposition closes the rank's context and builds a new one (new cell window): the communicator is
+    detached from the old context and attached to the new one (wcsph_comm_detach / _attach, SlabSim._set_cuts).  Ring of one slab:
+    two steps, context rebuilt, one more step -- against the same three steps without the rebuild."""
+    out = {}
+    for rebuild in (False, True):
+        sim = _ring_sim("clean")
+        sim.enable_native_comm(neighbours=(0, 0))
+        for k in range(3):
+            if rebuild and k == 2:
+                keep = sim.rows.clone()                      # materialised from the library: the truth for the new context
+                old_ctx = sim.B.ctx
+                sim._set_cuts(list(sim.cuts))                # closes the backend, builds a new one, hands the communicator over
+                sim.rows = keep
+                assert sim.B.native_comm and sim.B.ctx != old_ctx
+                sim.loopback, sim.force_comm, sim.overlap = True, True, True
+                cx = sim._cellx(sim.rows)
+                sim.interior = (int(cx.min().item()) + G, int(cx.max().item()) + 1 - G)
+            sim.step()
+        torch.cuda.synchronize()
+        out[rebuild] = (sim.rows.cpu().numpy().copy(), sim.B.comm_stats())
+        sim.B.close()
+    (ra, sa), (rb, sb) = out[False], out[True]
+    assert sa == sb and sa[0] >= 30                                  # the same exchanges went through the one communicator
+    vscale = float(np.abs(ra[:, 3:6]).max())
+    assert np.abs(ra[:, :3] - rb[:, :3]).max() < 5e-7 and np.abs(ra[:, 3:6] - rb[:, 3:6]).max() < 5e-6 * vscale
