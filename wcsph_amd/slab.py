@@ -1234,6 +1234,8 @@ def bench_main(args):
         try:
             sim.enable_native_comm()
             sim.B.comm_probe(rank, world)
+            if os.environ.get("WCSPH_BENCH_FAIL_NATIVE_PROBE"):        # test hook: the fall-back to the callbacks on a healthy box
+                raise RuntimeError("WCSPH_BENCH_FAIL_NATIVE_PROBE is set")
         except Exception as e:      # noqa: BLE001 -- the decision must be collective
             ok, why = 0, "%s: %s" % (type(e).__name__, (str(e).strip().splitlines() or [""])[0][:200])
         flag = torch.tensor([ok], dtype=torch.int32)
