@@ -291,10 +291,16 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
   const float ux = (pi.x - d.minx) * d.inv_grid - (float)(cx + d.x0), uy = (pi.y - d.miny) * d.inv_grid - (float)cy;
   const float fz = (pi.z - d.minz) * d.inv_grid;
   const float rm = __builtin_amdgcn_sqrtf(d.list_r2) * d.inv_grid * 1.0001f + 1e-3f, rm2 = rm * rm;
-  auto zrange = [&](int dx, int dy, int &za, int &zb) -> bool {
-    const float ex = dx > 0 ? (float)dx - ux : (dx < 0 ? (float)(-dx - 1) + ux : 0.0f);
-    const float ey = dy > 0 ? (float)dy - uy : (dy < 0 ? (float)(-dy - 1) + uy : 0.0f);
-    const float q = rm2 - ex * ex - ey * ey;
+  // (squared distance to the column's face along one axis, offset e cells: the five middle-axis values are formed once per
+  // particle, the outer-axis one once per plane -- a row costs two subtractions instead of two compare / select chains)
+  auto face2 = [](int e, float u) -> float {
+    const float v = e > 0 ? (float)e - u : (e < 0 ? (float)(-e - 1) + u : 0.0f);
+    return v * v;
+  };
+  const float u0 = d.perm ? uy : ux, u1 = d.perm ? ux : uy;
+  const float m2[5] = {face2(-2, u1), face2(-1, u1), 0.0f, face2(1, u1), face2(2, u1)};
+  auto zrange = [&](float o2, float mm2, int &za, int &zb) -> bool {
+    const float q = rm2 - o2 - mm2;
     if (q < 0.0f) return false;
     const float zr = __builtin_amdgcn_sqrtf(q);
     za = max(max((int)floorf(fz - zr), cz - 2), 0);
@@ -309,12 +315,13 @@ __device__ __forceinline__ void walk_cells(const Dev &d, int i, float4 pi, bool 
   _Pragma("unroll 1") for (int e0 = -2; e0 <= 2; e0++) {                                          \
     const int a0 = c0 + e0;                                                                       \
     if ((unsigned)a0 >= (unsigned)n0) continue;                                                   \
+    const float o2 = face2(e0, u0);                                                               \
     RowPieces rp[5];                                                                              \
     _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
       const int a1 = c1 + t - 2;                                                                  \
       int z0, z1;                                                                                 \
       rp[t].lo0 = rp[t].hi0 = rp[t].lo1 = rp[t].hi1 = 0;                                          \
-      if ((unsigned)a1 < (unsigned)n1 && zrange(d.perm ? t - 2 : e0, d.perm ? e0 : t - 2, z0, z1)) \
+      if ((unsigned)a1 < (unsigned)n1 && zrange(o2, m2[t], z0, z1))                               \
         rp[t] = row_pieces(d, CS, d.perm ? a1 : a0, d.perm ? a0 : a1, z0, z1);                    \
     }                                                                                             \
     _Pragma("unroll") for (int t = 0; t < 5; t++) {                                               \
