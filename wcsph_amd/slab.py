@@ -462,9 +462,7 @@ class SlabSim:
 
     def disable_native_comm(self):
         if self.B is not None and getattr(self.B, "native_comm", False):
-            h = self.B.comm_detach()
-            self.B.comm_attach(h)                       # (detach synchronises; attach back so that destroy frees it)
-            _lib.check(self.B.ctx, self.B.lib.wcsph_comm_destroy(self.B.ctx))
+            _lib.check(self.B.ctx, self.B.lib.wcsph_comm_destroy(self.B.ctx))     # (drains the context's stream first)
             self.B.native_comm = False
 
     def _set_cuts(self, cuts):
