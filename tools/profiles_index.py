@@ -46,10 +46,10 @@ says otherwise.  (Regenerate with `python tools/profiles_index.py`.)
 | file | what it shows |
 |---|---|
 | `r05_lds_tile_experiment.md` (+ `r05_tile_*`, `r05_pmc_build_lists.txt`, `r05_ab_flat_list_build.txt`) | (1) the LDS design VERDICT r04 asked for -- compact tiles, LDS-DMA staging, 16-bit LDS-slot lists -- built bit-exact and measured with counters: 191 vs 135 us at rest, 417 vs 326 us developed; where it loses.  (2) the list build in the developed flow: divergence-bound (34 of 64 lanes active), a flattened candidate loop built and 26-32 % slower |
-| `r05z_bench_20_5.json`, `r05z_bench_default.json`, `r05z_rest_kernel_stats.md`, `r05z_dev_kernel_stats.md`, `r05z_bench_rocprof_stats.md`, `r05z_pmc_*` | the campaign on the final source (`tools/campaign_r05.sh`): 1237 M particle-steps/s (1.617 ms/step), 1021 M over the default window, 610 M developed; DESIGN 4's table is generated from the ONE kernel trace here |
-| `r05_slab_overhead.txt`, `r05z_slab_overhead.txt`, `r05z_slab_nccl_world1.json` | slab driver on one GPU: +0.115 ms over the fused step (state store 0.052 + load 0.047) -> **+0.013 ... 0.018 ms** with the state resident in the library; the communicator called at every exchange point (Python callbacks or the native RCCL plane) adds 0.00-0.04 ms; the bench path on the real RCCL backend with one rank and the native data plane: 1184 M |
+| `r05z_bench_20_5.json`, `r05z_bench_default.json`, `r05z_rest_kernel_stats.md`, `r05z_dev_kernel_stats.md`, `r05z_bench_rocprof_stats.md`, `r05z_pmc_*` | the campaign on the final source (`tools/campaign_r05.sh`): 1237-1248 M particle-steps/s (1.60-1.62 ms/step), 1018-1021 M over the default window, 607-610 M developed; DESIGN 4's table is generated from the ONE kernel trace here |
+| `r05_slab_overhead.txt`, `r05z_slab_overhead.txt`, `r05z_slab_nccl_world1.json` | slab driver on one GPU: +0.115 ms over the fused step (state store 0.052 + load 0.047) -> **+0.013 ... 0.018 ms** with the state resident in the library; the communicator called at every exchange point (Python callbacks or the native RCCL plane) adds 0.00-0.04 ms; the bench path on the real RCCL backend with one rank and the native data plane: 1184-1191 M |
 | `r05_c5.md` (+ `r05_c5_*_kernel_stats.md`) | C5 literal / repaired tension legs on the final source |
-| `r05z_gputests.log` | `pytest -m gpu` on the final source: 128 passed, 1 skipped |
+| `r05z_gputests.log` | `pytest -m gpu` on the final source: 130 passed, 1 skipped |
 | `r04_experiments.md`, `r03_experiments.md`, `r02b_wave_brick_experiment.md` | every earlier measured-and-rejected idea with its counters (the stop list of VERDICT r04 comes from these) |
 
 ## By round
