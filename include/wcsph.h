@@ -436,21 +436,26 @@ int wcsph_state_apply(wcsph_ctx *ctx, int32_t n_owned_new, const int64_t *d_fold
 
 /* ---- native data plane (wcsph_comm_init / wcsph_halo_exchange) -----------------------------------------
  * The library's own implementation of the communicator above on RCCL: grouped ncclSend / ncclRecv with the slab neighbours
- * and ncclAllReduce, all on the context's stream, no host code per exchange.  New work -- the reference step is single-device
+ * and ncclAllReduce, no host code per exchange.  Inside wcsph_slab_step a halo refresh runs on the communicator's own stream,
+ * fenced by events against the context's (pack -> send/recv -> unpack), so that the pass on the slab interior queued between
+ * post and wait runs while the rows travel; the all-reduces of the reduction slots are on the context's stream.  New work -- the reference step is single-device
  * (dfsph.py:606-617).  RCCL is loaded at run time (the copy already in the process, else ROCm's librccl.so.1); without it
  * wcsph_comm_init fails with WCSPH_EHIP and the caller keeps its own communicator behind wcsph_slab_callbacks.
  *   wcsph_comm_unique_id(id):  rank 0 fills the 128-byte ncclUniqueId; the caller hands it to every rank (any channel)
+ *   wcsph_comm_last_error():   why the last wcsph_comm_unique_id() of this process failed (it has no context to leave a message in)
  *   wcsph_comm_init(ctx, id, rank, nranks): ncclCommInitRank on the calling thread's current device (the context's); slab
  *                              neighbours rank - 1 / rank + 1.  wcsph_slab_step(ctx, NULL, ...) then uses this communicator
  *   wcsph_comm_set_neighbours: other neighbour ranks, -1 = none; left == right == rank makes a LOOP-BACK communicator (what is
  *                              sent to the left arrives from the right, as on a ring of one): the one-GPU test of the data plane
  *   wcsph_comm_set_halo_split: of the lists given to wcsph_slab_set_halo, the first n_send_left rows go to / the first
  *                              n_ghost_left rows come from the left neighbour, the others the right one; after every wcsph_slab_set_halo
- *   wcsph_halo_exchange(ctx, W, d_send, n_send, d_recv, n_ghost): ONE grouped exchange of rows of W floats, stream-ordered
+ *   wcsph_halo_exchange(ctx, W, d_send, n_send, d_recv, n_ghost): ONE grouped exchange of rows of W floats, stream-ordered on the
+ *                              context's stream (the caller's buffers); WCSPH_EARG when the split does not fit n_send / n_ghost
  *   wcsph_comm_allreduce(ctx, d_buf, n, op): in place; op 0 = int32 SUM, 1 = float64 SUM, 2 = int32 MAX
  *   wcsph_comm_stats(ctx, out): out[0] = exchanges, out[1] = all-reduces issued so far */
 #define WCSPH_COMM_ID_BYTES 128
 int wcsph_comm_unique_id(void *id_out);
+const char *wcsph_comm_last_error(void);
 int wcsph_comm_init(wcsph_ctx *ctx, const void *unique_id, int32_t rank, int32_t nranks);
 int wcsph_comm_destroy(wcsph_ctx *ctx);
 int wcsph_comm_set_neighbours(wcsph_ctx *ctx, int32_t left, int32_t right);

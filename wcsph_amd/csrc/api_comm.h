@@ -1,41 +1,65 @@
 // api_comm.h -- the native data plane of the slab decomposition (wcsph_comm_init / wcsph_halo_exchange): RCCL calls
-// on the context's stream, no host code between the library and the wire.  New work: the reference is single-device
+// issued by the library itself, no host code between the library and the wire.  New work: the reference is single-device
 // (dfsph.py:606-617).  RCCL is resolved at run time (dlopen of librccl.so.1: the one a torch process has already loaded, else
-// ROCm's), so the library has no link dependency on it and single-GPU users never load it.  The communicator behind
-// wcsph_slab_step is then this file's implementation of wcsph_slab_callbacks (include/wcsph.h) instead of the caller's.
+// ROCm's), so the library has no link dependency on it, single-GPU users never load it -- and building the library needs no
+// RCCL headers: the nine entry points are declared here (ABI of rccl.h, NCCL 2.x: the types below are stable across releases).
+// The communicator behind wcsph_slab_step is then this file's implementation of wcsph_slab_callbacks (include/wcsph.h).
+//
+// Streams (round 6): a halo refresh runs on the communicator's OWN stream (`halo`), fenced by events against the context's
+// stream: pack (context) -> ev_packed -> grouped ncclSend / ncclRecv (halo) -> ev_landed -> unpack (context).  The pass on the
+// slab interior that wcsph_slab_step queues between post and wait therefore runs WHILE the rows travel (until round 5 the
+// exchange sat on the context's stream and serialised with it).  The all-reduces of the reduction slots stay on the context's
+// stream (their result is the next thing that stream needs); the bucket histogram's all-reduce has its own side stream.
 #pragma once
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only
+#include <mutex>
+
+// ---- the part of rccl.h this file uses (types and values as in /opt/rocm/include/rccl/rccl.h) -------------------------------
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;     // ncclSuccess = 0
+typedef int ncclDataType_t;   // ncclInt32 = 2, ncclFloat32 = 7, ncclFloat64 = 8
+typedef int ncclRedOp_t;      // ncclSum = 0, ncclMax = 2
+enum { ncclSuccess = 0, ncclInt32 = 2, ncclFloat = 7, ncclDouble = 8, ncclSum = 0, ncclMax = 2 };
+static_assert(sizeof(ncclUniqueId) == WCSPH_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
 
 struct RcclApi {
   void *h = nullptr;
-  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  decltype(&ncclAllReduce) AllReduce = nullptr;
-  decltype(&ncclSend) Send = nullptr;
-  decltype(&ncclRecv) Recv = nullptr;
-  decltype(&ncclGroupStart) GroupStart = nullptr;
-  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  std::string why;            // why the library is not usable (empty when it is)
 };
+// resolved once per process (std::call_once: two contexts may initialise from two threads); a missing symbol closes the
+// handle again and the reason stays readable for every later caller
 static RcclApi *rccl_api(std::string *why) {
   static RcclApi api;
-  static bool tried = false;
-  if (tried) { if (!api.h && why) *why = "librccl.so.1 could not be loaded"; return api.h ? &api : nullptr; }
-  tried = true;
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void *h = nullptr;
-  for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // the copy already in the process (torch's), if any
-  for (int k = 0; !h && k < 3; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
-  if (!h) { if (why) *why = std::string("dlopen(librccl.so.1): ") + dlerror(); return nullptr; }
-#define RCCL_SYM(f) if (!(api.f = (decltype(api.f))dlsym(h, "nccl" #f))) { if (why) *why = "librccl lacks nccl" #f; return nullptr; }
-  RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(GetErrorString) RCCL_SYM(AllReduce)
-  RCCL_SYM(Send) RCCL_SYM(Recv) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd)
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // the copy already in the process (torch's), if any
+    for (int k = 0; !h && k < 3; k++) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+    if (!h) { const char *e = dlerror(); api.why = std::string("dlopen(librccl.so.1): ") + (e ? e : "not found"); return; }
+#define RCCL_SYM(f) if (api.why.empty() && !(api.f = (decltype(api.f))dlsym(h, "nccl" #f))) api.why = "librccl lacks nccl" #f;
+    RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(GetErrorString) RCCL_SYM(AllReduce)
+    RCCL_SYM(Send) RCCL_SYM(Recv) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd)
 #undef RCCL_SYM
-  api.h = h;
+    if (!api.why.empty()) { dlclose(h); return; }
+    api.h = h;
+  });
+  if (!api.h) { if (why) *why = api.why; return nullptr; }
   return &api;
 }
+// the reason wcsph_comm_unique_id failed (it has no context to leave a message in): wcsph_comm_last_error()
+static std::mutex g_comm_err_mu;
+static std::string g_comm_err;
 
 struct NativeComm {
   RcclApi *api = nullptr;
@@ -44,6 +68,9 @@ struct NativeComm {
   int n_send_left = 0, n_ghost_left = 0;   // how the lists of wcsph_slab_set_halo split between the neighbours (left first)
   struct Buf { float *send = nullptr, *recv = nullptr; size_t cap_send = 0, cap_recv = 0; };
   Buf buf;
+  hipStream_t halo = nullptr;              // the halo refreshes' sends / receives run here, beside the pass on the slab interior
+  hipEvent_t ev_packed = nullptr, ev_landed = nullptr;
+  bool halo_pending = false;               // an exchange is in flight on `halo` that the context's stream has not been made to wait for
   hipStream_t side = nullptr;              // the bucket histogram's all-reduce runs here beside the sort and the list build
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   bool words_pending = false;
@@ -64,13 +91,25 @@ struct NativeComm {
     if (e_ != hipSuccess) { c->ctx->fail(WCSPH_EHIP, #call, e_); return WCSPH_EHIP; }                          \
   } while (0)
 
-// one grouped exchange with the slab neighbours: rows [0, n_send_left) of d_send go left, the rest right; rows [0, n_ghost_left) of
-// d_recv come from the left, the rest from the right.  The receives are posted right-first: on a loop-back communicator
-// (left == right == this rank: the one-GPU test of the data plane) what goes out to the left comes in from the right, as on a ring.
-static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_recv, int n_send, int n_ghost) {
+// the split of the halo lists against the lists themselves (wcsph_slab_set_halo may have shrunk them since
+// wcsph_comm_set_halo_split; (n_send - n_send_left) * W would wrap around as size_t), and on a loop-back communicator what goes
+// out to the left must be as long as what comes in from the right
+static int comm_check_split(NativeComm *c, int n_send, int n_ghost) {
+  if (c->n_send_left < 0 || c->n_ghost_left < 0 || c->n_send_left > n_send || c->n_ghost_left > n_ghost)
+    return c->ctx->fail(WCSPH_EARG, "halo exchange: wcsph_comm_set_halo_split() names more rows to the left than the halo lists hold (call it after every wcsph_slab_set_halo)");
+  if (c->left == c->rank && c->right == c->rank && (c->n_send_left != n_ghost - c->n_ghost_left || n_send - c->n_send_left != c->n_ghost_left))
+    return c->ctx->fail(WCSPH_EARG, "halo exchange on a loop-back communicator: the rows sent to the left must be as many as the rows received from the right (and vice versa)");
+  return 0;
+}
+// one grouped exchange with the slab neighbours on stream s: rows [0, n_send_left) of d_send go left, the rest right; rows
+// [0, n_ghost_left) of d_recv come from the left, the rest from the right.  The receives are posted right-first: on a loop-back
+// communicator (left == right == this rank: the one-GPU test of the data plane) what goes out to the left comes in from the
+// right, as on a ring.
+static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_recv, int n_send, int n_ghost, hipStream_t s) {
+  int rc = comm_check_split(c, n_send, n_ghost);
+  if (rc) return rc;
   const size_t sl = (size_t)c->n_send_left * W, sr = (size_t)(n_send - c->n_send_left) * W;
   const size_t gl = (size_t)c->n_ghost_left * W, gr = (size_t)(n_ghost - c->n_ghost_left) * W;
-  hipStream_t s = c->ctx->stream;
   NCCLCHK(c->api->GroupStart());
   if (c->left >= 0 && sl) NCCLCHK(c->api->Send(d_send, sl, ncclFloat, c->left, c->comm, s));
   if (c->right >= 0 && sr) NCCLCHK(c->api->Send(d_send + sl, sr, ncclFloat, c->right, c->comm, s));
@@ -80,36 +119,62 @@ static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_rec
   c->n_exchanges++;
   return 0;
 }
-// ---- wcsph_slab_callbacks on RCCL (everything ordered on the context's stream; nothing waits on the host) -------------------
-// ONE send / receive buffer pair for every row width: the exchanges of a step are ordered on the context's stream (the pack
-// kernel of the next refresh runs after the previous refresh's sends).  Sized for rows of 4 floats with a quarter of slack when
-// the halo lists are set (wcsph_comm_set_halo_split), so that no allocation happens between the exchanges of a step.
+// The halo stream has the HIGHEST priority the device offers: the few workgroups of a send / receive kernel must be placed as soon
+// as they are launched, not when the thousands of workgroups of the interior pass queued beside them drain (measured, round 6,
+// profiles/r06_overlap.md: at default priority the 16 us exchange stretched to the length of its companion pass, 65-187 us).
+static hipError_t create_halo_stream(hipStream_t *s) {
+  int lo = 0, hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // (numerically lowest = highest priority)
+  if (e != hipSuccess) return e;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
+// ---- wcsph_slab_callbacks on RCCL (nothing waits on the host) -----------------------------------------------------------
+// ONE send / receive buffer pair for every row width.  It is safe because every refresh is awaited before the next one is
+// packed: ev_landed is recorded behind the WHOLE group (sends included), halo_wait makes the context's stream wait for it, and
+// the next refresh's pack kernel is queued on that stream afterwards -- so pack k+1 follows send k, and receive k+1 (behind
+// ev_packed k+1) follows unpack k.  Sized for rows of 4 floats with a quarter of slack when the halo lists are set
+// (wcsph_comm_set_halo_split), so that no allocation happens between the exchanges of a step.
 static int comm_reserve(NativeComm *c, size_t ns, size_t ng) {
   NativeComm::Buf &b = c->buf;
   if (ns > b.cap_send || !b.send) {
-    if (b.send) { CHIPCHK(hipStreamSynchronize(c->ctx->stream)); CHIPCHK(hipFree(b.send)); b.send = nullptr; }
+    if (b.send) { CHIPCHK(hipStreamSynchronize(c->ctx->stream)); CHIPCHK(hipStreamSynchronize(c->halo)); CHIPCHK(hipFree(b.send)); b.send = nullptr; }
     b.cap_send = ns + ns / 4 + 4096;
     CHIPCHK(hipMalloc((void **)&b.send, b.cap_send * sizeof(float)));
   }
   if (ng > b.cap_recv || !b.recv) {
-    if (b.recv) { CHIPCHK(hipStreamSynchronize(c->ctx->stream)); CHIPCHK(hipFree(b.recv)); b.recv = nullptr; }
+    if (b.recv) { CHIPCHK(hipStreamSynchronize(c->ctx->stream)); CHIPCHK(hipStreamSynchronize(c->halo)); CHIPCHK(hipFree(b.recv)); b.recv = nullptr; }
     b.cap_recv = ng + ng / 4 + 4096;
     CHIPCHK(hipMalloc((void **)&b.recv, b.cap_recv * sizeof(float)));
   }
   return 0;
 }
+static int ncb_wait(void *u);
 static int ncb_buffers(void *u, int32_t W, void **snd, void **rcv) {
   NativeComm *c = (NativeComm *)u;
-  int rc = comm_reserve(c, (size_t)c->ctx->n_halo_send * W, (size_t)c->ctx->n_halo_ghost * W);
-  if (rc) return rc;
+  int rc;
+  if (c->halo_pending && (rc = ncb_wait(u))) return rc;   // (a caller that posted without waiting: the buffers are about to be overwritten)
+  if ((rc = comm_reserve(c, (size_t)c->ctx->n_halo_send * W, (size_t)c->ctx->n_halo_ghost * W))) return rc;
   *snd = c->buf.send; *rcv = c->buf.recv;
   return 0;
 }
+// post: the sends / receives start on the halo stream as soon as the pack kernel (the last thing on the context's stream) is
+// done; whatever the caller queues on the context's stream next runs beside them
 static int ncb_post(void *u, int32_t W) {
   NativeComm *c = (NativeComm *)u;
-  return comm_exchange(c, W, c->buf.send, c->buf.recv, c->ctx->n_halo_send, c->ctx->n_halo_ghost);
+  CHIPCHK(hipEventRecord(c->ev_packed, c->ctx->stream));
+  CHIPCHK(hipStreamWaitEvent(c->halo, c->ev_packed, 0));
+  int rc = comm_exchange(c, W, c->buf.send, c->buf.recv, c->ctx->n_halo_send, c->ctx->n_halo_ghost, c->halo);
+  if (rc) return rc;
+  CHIPCHK(hipEventRecord(c->ev_landed, c->halo));
+  c->halo_pending = true;
+  return 0;
 }
-static int ncb_wait(void *) { return 0; }   // stream-ordered: the unpack kernel queued next runs after the receives
+// wait: the context's stream goes on (unpack, then the pass on the rows next to the cuts) once the group has completed
+static int ncb_wait(void *u) {
+  NativeComm *c = (NativeComm *)u;
+  if (c->halo_pending) { CHIPCHK(hipStreamWaitEvent(c->ctx->stream, c->ev_landed, 0)); c->halo_pending = false; }
+  return 0;
+}
 static int ncb_acc(void *u, int32_t slot) {
   NativeComm *c = (NativeComm *)u;
   double *p = c->ctx->d.acc + slot * ACC_STRIPES;
@@ -162,11 +227,23 @@ int wcsph_comm_unique_id(void *id_out) {
   if (!id_out) return WCSPH_EARG;
   std::string why;
   RcclApi *api = rccl_api(&why);
-  if (!api) return WCSPH_EHIP;
   ncclUniqueId id;
-  if (api->GetUniqueId(&id) != ncclSuccess) return WCSPH_EHIP;
+  ncclResult_t r = ncclSuccess;
+  if (api && (r = api->GetUniqueId(&id)) != ncclSuccess) why = std::string("ncclGetUniqueId: ") + api->GetErrorString(r);
+  if (!api || r != ncclSuccess) {
+    std::lock_guard<std::mutex> g(g_comm_err_mu);
+    g_comm_err = "RCCL is not available: " + why;
+    return WCSPH_EHIP;
+  }
   memcpy(id_out, &id, sizeof id);
   return WCSPH_OK;
+}
+// why the last wcsph_comm_unique_id() of this process failed (it has no context to leave a message in); "" if none did
+const char *wcsph_comm_last_error(void) {
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> g(g_comm_err_mu);
+  copy = g_comm_err;
+  return copy.c_str();
 }
 int wcsph_comm_destroy(wcsph_ctx *ctx) {
   if (!ctx) return WCSPH_EARG;
@@ -174,6 +251,9 @@ int wcsph_comm_destroy(wcsph_ctx *ctx) {
   if (!c) return WCSPH_OK;
   hipStreamSynchronize(ctx->stream);
   if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+  if (c->halo) { hipStreamSynchronize(c->halo); hipStreamDestroy(c->halo); }
+  if (c->ev_packed) hipEventDestroy(c->ev_packed);
+  if (c->ev_landed) hipEventDestroy(c->ev_landed);
   if (c->ev_ready) hipEventDestroy(c->ev_ready);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   if (c->buf.send) hipFree(c->buf.send);
@@ -203,7 +283,9 @@ int wcsph_comm_init(wcsph_ctx *ctx, const void *unique_id, int32_t rank, int32_t
     c->comm = nullptr; wcsph_comm_destroy(ctx);
     return WCSPH_EHIP;
   }
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || create_halo_stream(&c->halo) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess || hipMalloc((void **)&c->d_scalar, 2 * sizeof(double)) != hipSuccess) {
     wcsph_comm_destroy(ctx);
     return ctx->fail(WCSPH_EHIP, "wcsph_comm_init: stream / event / scratch allocation");
@@ -237,6 +319,8 @@ int wcsph_comm_detach(wcsph_ctx *ctx, void **handle) {
   if (!c) return WCSPH_OK;
   CHIPCHK(hipStreamSynchronize(ctx->stream));
   CHIPCHK(hipStreamSynchronize(c->side));
+  CHIPCHK(hipStreamSynchronize(c->halo));
+  c->halo_pending = false;
   c->ctx = nullptr; ctx->comm = nullptr;
   *handle = c;
   return WCSPH_OK;
@@ -252,8 +336,9 @@ int wcsph_comm_attach(wcsph_ctx *ctx, void *handle) {
 int wcsph_halo_exchange(wcsph_ctx *ctx, int32_t W, const void *d_send, int32_t n_send, void *d_recv, int32_t n_ghost) {
   if (!ctx || !ctx->comm || W < 1 || n_send < 0 || n_ghost < 0) return WCSPH_EARG;
   NativeComm *c = ctx->comm;
-  if (c->n_send_left > n_send || c->n_ghost_left > n_ghost) return ctx->fail(WCSPH_EARG, "wcsph_halo_exchange: fewer rows than wcsph_comm_set_halo_split() sends / expects to the left");
-  return comm_exchange(c, W, (const float *)d_send, (float *)d_recv, n_send, n_ghost);
+  if ((n_send > 0 && !d_send) || (n_ghost > 0 && !d_recv)) return WCSPH_EARG;
+  // (the stand-alone entry point is stream-ordered on the CONTEXT's stream: the caller's buffers, the caller's ordering)
+  return comm_exchange(c, W, (const float *)d_send, (float *)d_recv, n_send, n_ghost, ctx->stream);
 }
 // dtype_op: 0 = int32 SUM, 1 = float64 SUM, 2 = int32 MAX; in place on the device, on the context's stream
 int wcsph_comm_allreduce(wcsph_ctx *ctx, void *d_buf, int64_t n, int32_t dtype_op) {

@@ -34,6 +34,7 @@ struct wcsph_ctx {
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false, bk_rows_valid = false;
+  int *part_flags = nullptr;      // [nblk8(capacity)] per block of sorted rows: interior / rest present (api_slab.h k_part_flags)
   NativeComm *comm = nullptr;     // the native RCCL data plane of a slab decomposition (wcsph_comm_init), or none
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers
@@ -103,6 +104,11 @@ struct wcsph_ctx {
 #define NEED_SETUP()                                                                  \
   if (!ctx) return WCSPH_EARG;                                                        \
   if (!ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_setup() has not been called")
+// a resident slab state between wcsph_state_apply and the grid update that sorts it in has dead rows and last step's order:
+// only the grid update may run then (every accessor that iterates d.nl or where[] would read wrong or dead rows)
+#define NEED_COMPACT()                                                                \
+  NEED_SETUP();                                                                       \
+  if (ctx->nl_phys > 0) return ctx->fail(WCSPH_EARG, "the state has pending changes (wcsph_state_apply) that no grid update has sorted in yet: only wcsph_grid_update / wcsph_slab_step may run now")
 #define NEED_GRID()                                                                   \
   NEED_SETUP();                                                                       \
   if (!ctx->grid_valid) return ctx->fail(WCSPH_EARG, "wcsph_grid_update() has not been called since setup")

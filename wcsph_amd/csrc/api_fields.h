@@ -44,7 +44,7 @@ static FieldDesc field_desc(wcsph_ctx *ctx, int f) {
 }
 
 int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
-  NEED_SETUP();
+  NEED_COMPACT();
   if (!dst) return WCSPH_EARG;
   Dev &d = ctx->d;
   FieldDesc fd = field_desc(ctx, field);
@@ -101,7 +101,7 @@ int wcsph_field_to_host(wcsph_ctx *ctx, int field, void *dst, size_t bytes) {
 }
 
 int wcsph_field_from_host(wcsph_ctx *ctx, int field, const void *src, size_t bytes) {
-  NEED_SETUP();
+  NEED_COMPACT();
   if (!src) return WCSPH_EARG;
   Dev &d = ctx->d;
   FieldDesc fd = field_desc(ctx, field);
@@ -134,7 +134,7 @@ __global__ void k_rows_in(float *f, int stride, int per, const int *where, int i
   f[(size_t)where[i0 + t / per] * stride + t % per] = in[t];
 }
 int wcsph_field_rows_to_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n, void *dst) {
-  NEED_SETUP();
+  NEED_COMPACT();
   FieldDesc fd = field_desc(ctx, field);
   if (fd.kind != 3 && fd.kind != 1 && fd.kind != -1) return ctx->fail(WCSPH_EARG, "field_rows: vec3 / scalar fields only");
   if (i0 < 0 || n < 0 || i0 + n > ctx->d.nl || !dst) return WCSPH_EARG;
@@ -148,7 +148,7 @@ int wcsph_field_rows_to_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n, v
   return WCSPH_OK;
 }
 int wcsph_field_rows_from_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n, const void *src) {
-  NEED_SETUP();
+  NEED_COMPACT();
   FieldDesc fd = field_desc(ctx, field);
   if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "field_rows: writable vec3 / scalar fields only");
   if (i0 < 0 || n < 0 || i0 + n > ctx->d.nl || !src) return WCSPH_EARG;
@@ -164,7 +164,7 @@ int wcsph_field_rows_from_host(wcsph_ctx *ctx, int field, int32_t i0, int32_t n,
 }
 
 int wcsph_field_gather_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, void *d_dst) {
-  NEED_SETUP();
+  NEED_COMPACT();
   FieldDesc fd = field_desc(ctx, field);
   if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "gather_rows: vec3 / scalar fields only");
   if (n <= 0) return WCSPH_OK;
@@ -174,7 +174,7 @@ int wcsph_field_gather_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int
   return WCSPH_OK;
 }
 int wcsph_field_scatter_rows(wcsph_ctx *ctx, int field, const int32_t *d_idx, int32_t n, const void *d_src) {
-  NEED_SETUP();
+  NEED_COMPACT();
   FieldDesc fd = field_desc(ctx, field);
   if (fd.kind != 3 && fd.kind != 1) return ctx->fail(WCSPH_EARG, "scatter_rows: vec3 / scalar fields only");
   if (n <= 0) return WCSPH_OK;

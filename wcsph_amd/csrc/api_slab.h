@@ -87,7 +87,7 @@ int wcsph_state_apply(wcsph_ctx *ctx, int32_t n_owned_new, const int64_t *d_fold
   return WCSPH_OK;
 }
 int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, void *d_out) {
-  NEED_SETUP();
+  NEED_COMPACT();
   HaloFields h;
   int rc = halo_fields(ctx, n_fields, fields, &h);
   if (rc) return rc;
@@ -97,7 +97,7 @@ int wcsph_halo_pack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, con
   return WCSPH_OK;
 }
 int wcsph_halo_unpack(wcsph_ctx *ctx, int32_t n_fields, const int32_t *fields, const int32_t *d_idx, int32_t n, const void *d_in) {
-  NEED_SETUP();
+  NEED_COMPACT();
   HaloFields h;
   int rc = halo_fields(ctx, n_fields, fields, &h);
   if (rc) return rc;
@@ -234,6 +234,9 @@ int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_sen
   NEED_SETUP();
   if (n_send < 0 || n_ghost < 0 || (n_send > 0 && !d_send_idx) || (n_ghost > 0 && !d_ghost_idx)) return WCSPH_EARG;
   ctx->halo_send = d_send_idx; ctx->n_halo_send = n_send; ctx->halo_ghost = d_ghost_idx; ctx->n_halo_ghost = n_ghost;
+  // new lists: how they split between the two neighbours has to be said again (wcsph_comm_set_halo_split) before the next
+  // exchange of a native communicator -- a stale split against shorter lists would make a row count wrap around
+  if (ctx->comm) ctx->comm->n_send_left = ctx->comm->n_ghost_left = -1;
   return WCSPH_OK;
 }
 }  // extern "C" (templates below)
@@ -246,7 +249,20 @@ __global__ void k_ghost_records(Dev d) {
   d.pk[i] = make_float4(p.x, p.y, p.z, 0.f);
   d.pr[i] = make_float4(p.x, p.y, p.z, 0.f);
 }
+// which blocks of BLOCK consecutive sorted rows hold owned particles of the slab interior (bit 0) / of the rest (bit 1), for the
+// split launches of the halo / compute overlap (PART_GATE): d.part_x0 / part_x1 are set, the test is part_ok's
+__global__ void __launch_bounds__(BLOCK) k_part_flags(Dev d, int *flags) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  bool in = false, out = false;
+  if (i < d.nl && owned(d, i)) {
+    Dev e = d; e.part_mode = 1;
+    in = part_ok(e, d.pos[i]); out = !in;
+  }
+  const int a = __syncthreads_or(in), b = __syncthreads_or(out);
+  if (threadIdx.x == 0) flags[blockIdx.x] = (a ? 1 : 0) | (b ? 2 : 0);
+}
 namespace {
+struct PartGuard { Dev &d; ~PartGuard() { d.part_flags = nullptr; d.part_mode = 0; } };
 struct SlabRun {
   wcsph_ctx *ctx;
   const wcsph_slab_callbacks *cb;
@@ -320,6 +336,7 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   Dev &d = ctx->d;
   int rc;
   d.pred = nullptr; d.dtp = nullptr;
+  PartGuard part_guard{d};
   const double N = (double)n_global;
   const bool tension = (flags & 2) && !(d.tension == 0.0f && d.tension_b == 0.0f);
   if (tension && ctx->p.tension_fixed == 0 && R.multi) return ctx->fail(WCSPH_EARG, "the literal compute_tension reads the reference's raw bucket rows, which span all slabs: tension_fixed = 1 on a decomposition");
@@ -348,6 +365,20 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   } else SRC(wcsph_grid_update(ctx));
   if (d.nl == 0) { if (stats) stats[0] = stats[1] = 0; return WCSPH_OK; }
   if (d.n_owned < d.nl) ELEM(k_ghost_records);
+  if (R.overlap) {
+    // The interior is taken to whole TILES of the cell order along x (4 columns when x is the middle axis, 2 when it is the outer
+    // one; device.h cell_lin): 64 consecutive sorted particles are then all interior or all rest except where a run of tiles ends,
+    // so a split launch does not run its waves half empty -- measured on the 32 x 252 x 252 ring (profiles/r06_overlap.md): with
+    // the cut columns themselves as the boundary set the two launches of a pass cost 1.16 x the whole pass, 0.27 ms per step.
+    // Rounding inwards keeps every interior particle at least two columns from a ghost.
+    const int T = d.perm ? (1 << T1B) : (1 << T0B);
+    if (R.ilo > d.x0) R.ilo = d.x0 + ((R.ilo - d.x0 + T - 1) / T) * T;
+    if (R.ihi < d.x0 + d.nx) R.ihi = d.x0 + ((R.ihi - d.x0) / T) * T;
+    d.part_x0 = R.ilo; d.part_x1 = R.ihi > R.ilo ? R.ihi : R.ilo;
+    hipLaunchKernelGGL(k_part_flags, dim3(nblk8(d.nl)), dim3(BLOCK), 0, ctx->stream, d, ctx->part_flags);
+    LAUNCHCHK();
+    d.part_flags = ctx->part_flags;
+  }
   // ---- compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146): they read
   // pos_j / vel_j only, which the ghost rows brought with them
   PASS(k_density_coff_warm, ctx->dt);

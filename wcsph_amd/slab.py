@@ -440,25 +440,45 @@ class SlabSim:
         self._rows = value
 
     # ---- the native data plane: RCCL inside the library instead of torch.distributed behind callbacks ----------------------
+    def _agree(self, ok):
+        """AND of a rank-local verdict over every rank of the job, over the control plane (the job's default process group,
+        whatever its backend): decisions about the data plane are taken by all ranks or by none"""
+        if self.world == 1:
+            return bool(ok)
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(ok))
+        return all(flags)
+
     def enable_native_comm(self, neighbours=None):
         """Every rank of the job calls this (collective): rank 0 draws the ncclUniqueId, it travels over the job's default
         process group (the control plane), every rank joins with ncclCommInitRank inside the library.  The halo refreshes and
         all-reduces of wcsph_slab_step then never leave the library; migration and ghost rebuild (redistribute) stay on
-        torch.distributed."""
+        torch.distributed.
+        Collective in its FAILURES too: the ranks agree over the control plane (a) that librccl is loadable
+        everywhere BEFORE any of them enters ncclCommInitRank -- a rank that cannot load it would otherwise leave the others
+        blocked in there for good -- and (b) that every rank came out of it with a communicator; either every rank returns
+        with the native plane on, or every rank raises with it off."""
         if not hasattr(self.B, "comm_init"):
             raise RuntimeError("the native data plane needs the HIP backend")
         lib = self.B.lib
-        ident = [None]
-        if self.rank == 0:
-            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
-            rc = lib.wcsph_comm_unique_id(buf)
-            ident = [bytes(buf.raw) if rc == 0 else None]
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = lib.wcsph_comm_unique_id(buf)         # every rank: this is also the test that librccl loads here (only rank 0's id is used)
+        why = (lib.wcsph_comm_last_error() or b"").decode(errors="replace") if rc else ""
+        if not self._agree(rc == 0):
+            raise RuntimeError("native data plane: RCCL is not usable on at least one rank%s" % (" (here: %s)" % why if why else ""))
+        ident = [bytes(buf.raw) if self.rank == 0 else None]
         if self.world > 1:
             dist.broadcast_object_list(ident, src=0)
-        if ident[0] is None:
-            raise RuntimeError("wcsph_comm_unique_id failed on rank 0 (RCCL not loadable)")
-        with torch.cuda.device(self.device):
-            self.B.comm_init(ident[0], self.rank, self.world, neighbours)
+        err = None
+        try:
+            with torch.cuda.device(self.device):
+                self.B.comm_init(ident[0], self.rank, self.world, neighbours)
+        except Exception as e:      # noqa: BLE001 -- the verdict must be collective
+            err = e
+        if not self._agree(err is None):
+            if err is None:
+                self.disable_native_comm()
+            raise RuntimeError("native data plane: wcsph_comm_init failed on at least one rank%s" % (" (here: %s)" % err if err else ""))
 
     def disable_native_comm(self):
         if self.B is not None and getattr(self.B, "native_comm", False):
@@ -469,6 +489,16 @@ class SlabSim:
         """(re)build this rank's backend for the slab [cuts[rank], cuts[rank+1]): cell window, static boundary particles
         of the window, and in faithful mode the global static bucket histogram"""
         rank, world = self.rank, self.world
+        keep = (getattr(self, "cuts", None), getattr(self, "lo", None), getattr(self, "hi", None), getattr(self, "window", None))
+        try:
+            self._set_cuts_(list(cuts))
+        except Exception:
+            if self.B is not None:                    # the old backend is whole and keeps serving the old decomposition
+                self.cuts, self.lo, self.hi, self.window = keep
+            raise
+
+    def _set_cuts_(self, cuts):
+        rank, world = self.rank, self.world
         self.cuts = list(cuts)
         self.lo, self.hi = self.cuts[rank], self.cuts[rank + 1]
         w0, w1 = max(self.lo - GHOST_CELLS, 0), min(self.hi + GHOST_CELLS, self.nx)
@@ -477,13 +507,9 @@ class SlabSim:
         scx = self._cellx_np(sol32[:, 0]) if len(sol32) else np.zeros(0, np.int64)
         solid_local = self.solid_all[(scx >= w0) & (scx < w1)]
         capacity = int(max(self.rows.shape[0], self.n_global // world) * self._cap_factor) + 4096
-        comm_handle = None
-        if self.B is not None:
-            if self.device.type == "cuda":
-                torch.cuda.synchronize(self.device)   # nothing of the old backend may still be in flight when it is freed
-            if getattr(self.B, "native_comm", False):
-                comm_handle = self.B.comm_detach()    # the communicator outlives the context (a rebalance rebuilds it)
-            self.B.close()
+        # Everything that can fail comes BEFORE the old backend and its communicator are touched (a ValueError or a
+        # failed allocation after the detach lost the ncclComm, its streams and buffers, and left the other ranks with a
+        # communicator whose peer had gone): the width check, then the NEW backend, built beside the old one.
         if self.hi - self.lo < MIN_SLAB and world > 1:
             raise ValueError("rank %d: slab [%d, %d) is narrower than %d cell columns" % (rank, self.lo, self.hi, MIN_SLAB))
         kw = dict(capacity=capacity, solid_local=solid_local, bounds=(self.minb, self.maxb), window=self.window,
@@ -494,9 +520,21 @@ class SlabSim:
             big = 1 << 30
             kw.update(neighbor_mode="faithful", owned=(self.lo if rank > 0 else -big, self.hi if rank < world - 1 else big),
                       n_global=(self.n_global, len(self.solid_all)))
-        self.B = self._factory(**kw)
-        if comm_handle is not None:
-            self.B.comm_attach(comm_handle)
+        old = self.B
+        if old is not None and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)       # nothing of the old backend may still be in flight when it is freed
+        new = self._factory(**kw)
+        if old is not None:
+            if getattr(old, "native_comm", False):    # the communicator outlives the context (a rebalance rebuilds it)
+                handle = old.comm_detach()
+                try:
+                    new.comm_attach(handle)
+                except Exception:
+                    old.comm_attach(handle)           # still whole: the old context keeps it
+                    new.close()
+                    raise
+            old.close()
+        self.B = new
         if self.neighbor_mode == "faithful" and world > 1:
             self._allreduce_tensor(self.B.bucket_hist(1))      # static boundary particles: once per backend
         # halo/compute overlap: a neighbour pass that needs a halo refresh runs on the slab interior (columns at least
@@ -1228,18 +1266,30 @@ def bench_main(args):
     # otherwise this rank's torch.distributed group behind wcsph_slab_callbacks, as before.  WCSPH_BENCH_NATIVE=0 keeps the callbacks.
     plane = "torch.distributed (%s) behind wcsph_slab_callbacks" % ("RCCL" if not staged else "gloo, host-staged")
     if not staged and sim.native and os.environ.get("WCSPH_BENCH_NATIVE", "1") != "0":
+        # Every stage is agreed over the control plane before the next RCCL collective is entered: a rank that drops out
+        # early must not leave the others blocked inside ncclCommInitRank or the probe's all-reduce.  enable_native_comm() is
+        # collective in its failures (every rank raises, or none); the probe's own verdict is agreed below.  A rank that HANGS
+        # inside RCCL is not recoverable: a shorter watchdog covers these first calls.
         ok, why = 1, ""
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(int(os.environ.get("WCSPH_BENCH_PROBE_WATCHDOG_S", "300")), exit=True)
         try:
             sim.enable_native_comm()
-            sim.B.comm_probe(rank, world)
-            if os.environ.get("WCSPH_BENCH_FAIL_NATIVE_PROBE"):        # test hook: the fall-back to the callbacks on a healthy box
-                raise RuntimeError("WCSPH_BENCH_FAIL_NATIVE_PROBE is set")
-        except Exception as e:      # noqa: BLE001 -- the decision must be collective
+        except Exception as e:      # noqa: BLE001 -- raised on every rank alike
             ok, why = 0, "%s: %s" % (type(e).__name__, (str(e).strip().splitlines() or [""])[0][:200])
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            plane = "native RCCL inside the library (wcsph_comm_init / wcsph_halo_exchange: grouped ncclSend/ncclRecv + ncclAllReduce on the context's stream); migration + ghost rebuild over torch.distributed (RCCL)"
+        if ok:
+            try:
+                if os.environ.get("WCSPH_BENCH_FAIL_NATIVE_PROBE"):    # test hook: the fall-back to the callbacks on a healthy box
+                    raise RuntimeError("WCSPH_BENCH_FAIL_NATIVE_PROBE is set")
+                sim.B.comm_probe(rank, world)
+            except Exception as e:  # noqa: BLE001 -- the decision must be collective
+                ok, why = 0, "%s: %s" % (type(e).__name__, (str(e).strip().splitlines() or [""])[0][:200])
+            ok = 1 if sim._agree(ok) else 0
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(int(os.environ.get("WCSPH_BENCH_WATCHDOG_S", "1200")), exit=True)
+        if ok:
+            plane = ("native RCCL inside the library (wcsph_comm_init / wcsph_halo_exchange: grouped ncclSend/ncclRecv on the communicator's halo stream "
+                     "beside the interior pass, ncclAllReduce on the context's stream); migration + ghost rebuild over torch.distributed (RCCL)")
         else:
             if why:
                 print("[bench rank %d] native data plane not used (%s): torch.distributed callbacks" % (rank, why), file=sys.stderr, flush=True)
