@@ -231,6 +231,76 @@ def timed_steps(dfsph, pd, warmup, steps, tsync, fixed=None, profile=False):
     return out
 
 
+# ---- per-group breakdown of a step, in situ -------------------------------------------------------------
+def lap_group(tag):
+    """kernel tag of a lap (csrc PROF_LAP) -> the group names the `rest` leg's other_kernels use"""
+    if tag.startswith("grid:"):
+        return "grid_update"
+    if tag == "k_build_lists":
+        return "build_lists"
+    if tag.startswith("k_density"):
+        return "density_coff"
+    if tag in ("divergence_iter", "pressure_iter", "step_boundary"):
+        return tag
+    if "k_drho_div<DRHO_BEGIN" in tag or tag.startswith("k_vel_from_k<1>"):
+        return "divergence_open"            # warm-start velocities + begin_divergence_iter (dfsph.py:415-446)
+    if "k_drho_press<DRHO_BEGIN" in tag or "k_warm_press" in tag:
+        return "pressure_open"              # warmstart_pressure + begin_pressure_iter (dfsph.py:487-516)
+    if tag in ("k_visc_minv_residual", "k_visc_minv_residual_vort", "k_visc_Ad", "k_visc_update", "k_visc_dir", "k_vorticity"):
+        return "visc_iter"                  # the PCG (its opening walk + every iteration) and the vorticity sums that ride on it
+    return "elementwise"                    # k_end_div_begin_nonpressure, k_finish_nonpressure (+ CFL tail), k_update_vel_warm_scale, k_end_press_update_pos ...
+
+
+def lap_breakdown(dfsph, pd, steps):
+    """`steps` more steps with a HIP event behind every tagged launch (wcsph_profile_laps_*): us per step by group.  The laps tile
+    the stream's time line, so the groups sum to the profiled steps' own duration; `after_host_wait_us` is the part of it
+    in laps that began behind a host wait (an upper bound of the GPU's idle time there)."""
+    from wcsph_amd import _lib
+    import ctypes as C
+    ctx, lib = pd._need_ctx(), _lib.load()
+    pd.sync()
+    _lib.check(ctx, lib.wcsph_profile_laps_begin(ctx, 160 * steps + 16))
+    t0 = time.perf_counter()
+    iters = []
+    for _ in range(steps):
+        dfsph.step()
+        iters.append((dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter))
+    pd.sync()
+    wall = time.perf_counter() - t0
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(ctx, lib.wcsph_profile_laps_end(ctx, buf, len(buf)))
+    laps = json.loads(buf.value.decode())
+    groups, waits, by_kernel = {}, 0.0, {}
+    for tag, (ms, n, ms_wait) in laps.items():
+        g = lap_group(tag)
+        groups[g] = groups.get(g, 0.0) + ms
+        waits += ms_wait
+        by_kernel[tag] = [round(ms / steps * 1e3, 1), round(n / steps, 2)]
+    tot = sum(groups.values())
+    it = np.array(iters, dtype=np.float64)
+    return {"steps": steps, "ms_per_step_profiled": round(wall / steps * 1e3, 3),
+            "groups_us_per_step": {k: round(v / steps * 1e3, 1) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])},
+            "groups_sum_ms_per_step": round(tot / steps, 3), "after_host_wait_us_per_step": round(waits / steps * 1e3, 1),
+            "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)},
+            "laps_us_per_step_and_count": by_kernel,
+            "note": "one HIP event behind every tagged launch; a lap = the launch + the idle time before it; the events cost a few per cent"}
+
+
+def state_facts(pd):
+    """what the neighbour passes walk in this state: mean compact-list length (8-slot blocks), liquid bounding box"""
+    from wcsph_amd import _lib
+    import ctypes as C
+    ctx, lib = pd._need_ctx(), _lib.load()
+    hist = ((C.c_int64 * 64) * 5)()
+    _lib.check(ctx, lib.wcsph_list_stats(ctx, hist))
+    h = np.array([[hist[a][b] for b in range(64)] for a in range(5)], dtype=np.float64)
+    k = np.arange(64)
+    pos = pd.pos.to_numpy()[:pd.liquid_count]
+    return {"mean_liquid_list_blocks": round(float((h[0] * k).sum() / max(h[0].sum(), 1)), 2), "mean_solid_list_blocks": round(float((h[1] * k).sum() / max(h[1].sum(), 1)), 3),
+            "mean_wave_trips": round(float((h[4] * k).sum() / max(h[4].sum(), 1)), 2),
+            "liquid_bbox": [[round(float(v), 3) for v in pos.min(0)], [round(float(v), 3) for v in pos.max(0)]]}
+
+
 def leg(value_n, r, steps):
     return {"value": round(value_n * steps / r["elapsed"] / 1e6, 3), "ms_per_step": round(r["elapsed"] / steps * 1e3, 3)}
 
@@ -298,6 +368,8 @@ def _main():
     nl, ns = pd.liquid_count, pd.solid_count
     elapsed = r["elapsed"]
     value = nl * args.steps / elapsed / 1e6
+    rest_breakdown = lap_breakdown(dfsph, pd, 10)      # the ten steps behind the timed window, before the replays disturb the state
+    rest_state = state_facts(pd)
 
     # the same kernel pair replayed back to back after the run (a replay finds more of its stream in the Infinity Cache)
     ms_replay = C.c_float()
@@ -332,7 +404,8 @@ def _main():
                    "state": "steps %d..%d from rest (column not yet collapsed: minimum iteration counts)" % (args.warmup + 1, args.warmup + args.steps),
                    "neighbor_mode": args.mode, "n_liquid": nl, "n_solid": ns,
                    "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)},
-                   "dt_end": float(dfsph.deltaT[0]), "setup_s": round(t_setup, 2)},
+                   "dt_end": float(dfsph.deltaT[0]), "setup_s": round(t_setup, 2),
+                   "breakdown": rest_breakdown, "state_facts": rest_state},
         "roofline": {"bound": "hbm", "kernel": "pressure_iter as the fused solver launches it: k_vel_from_k (kappa += k) + k_drho_press<ITER> (k epilogue), ref dfsph.py:518-547",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "frac_is": "ALGORITHMIC bytes (84 + 24 s) B x n_liquid per launch / measured launch time / 8 TB/s",
@@ -356,6 +429,8 @@ def _main():
                                                mean_iters={"vs": round(rw["iters"][:, 0].mean(), 2), "dv": round(rw["iters"][:, 1].mean(), 2), "pr": round(rw["iters"][:, 2].mean(), 2)},
                                                pressure_iter_us=round(rw["launch_ms"] * 1e3, 1),
                                                pressure_iter_frac=round(alg_bytes / (rw["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        out["config"]["default_window"]["breakdown"] = lap_breakdown(dfw, pdw, 20)      # steps 121..140
+        out["config"]["default_window"]["state"] = state_facts(pdw)
         pdw.close()
     if not args.no_developed:
         # the same workload after the column has collapsed (t ~ 1.1 s): longer lists, disordered neighbourhoods, a grid
@@ -370,6 +445,15 @@ def _main():
             mean_iters={"vs": round(rd["iters"][:, 0].mean(), 2), "dv": round(rd["iters"][:, 1].mean(), 2), "pr": round(rd["iters"][:, 2].mean(), 2)},
             pressure_iter_us=round(rd["launch_ms"] * 1e3, 1),
             pressure_iter_frac=round(alg_bytes / (rd["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        # a second window right behind the first (how far two windows of ONE run differ), then 20 steps with the per-group laps
+        # (what the step is made of in this state), then the state's own facts
+        rd2 = timed_steps(dfd, pdd, 0, 20, tsync, profile=True)
+        dev = out["config"]["developed_flow"]
+        dev["window_2"] = dict(leg(nl, rd2, 20), steps="%d..%d" % (args.developed_after + 21, args.developed_after + 40),
+                               mean_iters={"vs": round(rd2["iters"][:, 0].mean(), 2), "dv": round(rd2["iters"][:, 1].mean(), 2), "pr": round(rd2["iters"][:, 2].mean(), 2)},
+                               pressure_iter_us=round(rd2["launch_ms"] * 1e3, 1))
+        dev["breakdown"] = lap_breakdown(dfd, pdd, 20)
+        dev["state"] = state_facts(pdd)
         pdd.close()
     if args.mode == "faithful" and not args.no_clean:
         # the N > 1 slab runs can use either neighbour semantics; clean mode for a like-for-like reading

@@ -260,6 +260,13 @@ int wcsph_sample_surface(const float *tri_xyz, int32_t n_tri, double particle_ra
  * events on the context's stream (at most max_launches of them); end returns their average duration. */
 int wcsph_profile_begin(wcsph_ctx *ctx, int32_t max_launches);
 int wcsph_profile_end(wcsph_ctx *ctx, float *avg_ms, int32_t *launches);
+/* lap profiling (bench.py's per-group breakdown of a step): between _begin and _end every tagged launch of the fused step is
+ * followed by a HIP event; the time between two consecutive events is booked to the tag of the later one (the launch itself plus
+ * whatever idle time preceded it).  _end waits for the stream and writes JSON text {"<tag>": [ms, laps, ms of the laps that
+ * began behind a host wait], ...} (tags: kernel names, "grid:cells", "grid:scan+sort", "grid:neighborCount", "step_boundary").
+ * The events perturb the step by a few per cent: time a window WITHOUT them for the rate. */
+int wcsph_profile_laps_begin(wcsph_ctx *ctx, int32_t max_laps);
+int wcsph_profile_laps_end(wcsph_ctx *ctx, char *json_out, size_t cap);
 /* Times `reps` back-to-back launches of one named kernel group with hipEvents on the context's
  * stream; *ms_per_launch is the average.  Names: "pressure_iter", "divergence_iter", "density",
  * "grid_update", "visc_iter".  State is not preserved across the call. */
@@ -447,6 +454,11 @@ int wcsph_state_apply(wcsph_ctx *ctx, int32_t n_owned_new, const int64_t *d_fold
  *                              neighbours rank - 1 / rank + 1.  wcsph_slab_step(ctx, NULL, ...) then uses this communicator
  *   wcsph_comm_set_neighbours: other neighbour ranks, -1 = none; left == right == rank makes a LOOP-BACK communicator (what is
  *                              sent to the left arrives from the right, as on a ring of one): the one-GPU test of the data plane
+ *   wcsph_comm_set_mode(ctx, m): where the halo refreshes of wcsph_slab_step run: 2 = exchange, unpack and the pass on the rows
+ *                              next to the cuts on the communicator's own stream, beside the pass on the slab interior, one join at
+ *                              the end; 1 (default) = only the exchange there (the context's stream waits for it before the unpack) -- both
+ *                              with flags bit 0 of wcsph_slab_step; 0 = inline on the context's stream between pack and unpack
+ *                              (no event hops; for steps whose passes are not split)
  *   wcsph_comm_set_halo_split: of the lists given to wcsph_slab_set_halo, the first n_send_left rows go to / the first
  *                              n_ghost_left rows come from the left neighbour, the others the right one; after every wcsph_slab_set_halo
  *   wcsph_halo_exchange(ctx, W, d_send, n_send, d_recv, n_ghost): ONE grouped exchange of rows of W floats, stream-ordered on the
@@ -459,6 +471,7 @@ const char *wcsph_comm_last_error(void);
 int wcsph_comm_init(wcsph_ctx *ctx, const void *unique_id, int32_t rank, int32_t nranks);
 int wcsph_comm_destroy(wcsph_ctx *ctx);
 int wcsph_comm_set_neighbours(wcsph_ctx *ctx, int32_t left, int32_t right);
+int wcsph_comm_set_mode(wcsph_ctx *ctx, int32_t mode);
 int wcsph_comm_set_halo_split(wcsph_ctx *ctx, int32_t n_send_left, int32_t n_ghost_left);
 int wcsph_halo_exchange(wcsph_ctx *ctx, int32_t W, const void *d_send, int32_t n_send, void *d_recv, int32_t n_ghost);
 int wcsph_comm_allreduce(wcsph_ctx *ctx, void *d_buf, int64_t n, int32_t dtype_op);

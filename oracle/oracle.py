@@ -118,6 +118,7 @@ def _load():
             getattr(lib, "orc_ptr_" + f).argtypes = [C.c_void_p]
             getattr(lib, "orc_ptr_" + f).restype = C.POINTER(C.c_int)
         lib.orc_set_num_threads.argtypes = [C.c_int]
+        lib.orc_diag_drho_divergence.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_mc_value.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.orc_mc_crossings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_float, C.c_void_p, C.c_long]
         lib.orc_mc_crossings.restype = C.c_long
@@ -281,6 +282,15 @@ class Oracle:
 
     def adh_W(self, r):
         return float(self.lib.orc_adh_W(self.h, float(r)))
+
+    def diag_drho_divergence(self):
+        """(S, A, G) per liquid particle on the current lists / positions / velocities: the un-clamped sum of
+        update_drho_divergence (dfsph.py:374-392), sum |term| and sum V |gradW| -- how close a particle sits to the gate
+        `if adv_rho[i] > 0` of dfsph.py:421 (test diagnostic; call update_grid() first)"""
+        nl = self.liquid_count
+        S, A, G = (np.zeros(nl, np.float64) for _ in range(3))
+        self.lib.orc_diag_drho_divergence(self.h, S.ctypes.data, A.ctypes.data, G.ctypes.data)
+        return S, A, G
 
     def get_dAd(self): return float(self.lib.orc_get_dAd(self.h))          # noqa: E704
     def set_dAd(self, v): self.lib.orc_set_dAd(self.h, float(v))           # noqa: E704

@@ -390,6 +390,22 @@ static inline void update_drho_pressure(orc_ctx *c, int i) {
   c->adv_rho[i] = fmaxf(1.0f, a);
 }
 void orc_update_drho_divergence(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) update_drho_divergence(c, i); }
+/* Test diagnostic (no reference counterpart): how close the sum of update_drho_divergence (dfsph.py:374-392) is to the
+ * discontinuity that follows it -- `if adv_rho[i] > 0` (dfsph.py:421) gives a particle the whole warm-start kick or none.  On the
+ * CURRENT lists, positions and velocities, per liquid particle: S = the un-clamped sum (double), A = sum |term| (what a change of
+ * the summation order can move S by, times an ulp), G = sum V |gradW| (what a velocity error dv can move S by, times 2 dv). */
+void orc_diag_drho_divergence(orc_ctx *c, double *S, double *A, double *G) {
+  PFOR for (int i = 0; i < NL; i++) {
+    double s = 0.0, a = 0.0, g = 0.0;
+    NB_BEGIN(i)
+      v3 gradV = CubicGradW(c, r);
+      const float t = (j < NL) ? c->VL0 * dot(sub(c->vel[i], c->vel[j]), gradV) : c->VS0 * dot(c->vel[i], gradV);
+      s += (double)t; a += fabs((double)t);
+      g += (double)((j < NL) ? c->VL0 : c->VS0) * sqrt((double)nsq(gradV));
+    NB_END
+    S[i] = s; A[i] = a; G[i] = g;
+  }
+}
 void orc_update_drho_pressure(orc_ctx *c) { PFOR for (int i = 0; i < NL; i++) update_drho_pressure(c, i); }
 
 /* ref: dfsph.py:415-439, first parallel loop (:417-418) */

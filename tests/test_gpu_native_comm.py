@@ -65,34 +65,27 @@ def _ring_sim(mode, n=12):
 @pytest.mark.parametrize("mode", ["clean", "faithful"])
 def test_native_rccl_data_plane_loopback_equals_the_callback_path(mode):
     out = {}
-    for plane in ("callbacks", "native"):
+    # native0 / 1 / 2: wcsph_comm_set_mode -- the exchange inline on the context's stream (passes not split), on the halo stream
+    # beside the interior pass, and with the unpack and the boundary pass on the halo stream as well (round 6)
+    for plane in ("callbacks", "native0", "native1", "native2"):
         sim = _ring_sim(mode)
-        if plane == "native":
+        if plane.startswith("native"):
             sim.enable_native_comm(neighbours=(0, 0))
+            sim.B.comm_set_mode(int(plane[-1]))
+            if plane == "native0":
+                sim.overlap = False
         log = []
         for _ in range(3):
             sim.step()
             log.append((sim.vs_iter, sim.dv_iter, sim.pr_iter, float(sim.dt)))
         torch.cuda.synchronize()
-        out[plane] = (sim.rows.cpu().numpy().copy(), log, sim.n_exchanges, sim.B.comm_stats() if plane == "native" else None)
+        out[plane] = (sim.rows.cpu().numpy().copy(), log, sim.n_exchanges, sim.B.comm_stats() if plane.startswith("native") else None)
         assert sim.send_all.numel() > 100 and sim.ghost_all.numel() > 100          # real rows travelled
         sim.B.close()
-    (ra, la, xa, _), (rb, lb, xb, st) = out["callbacks"], out["native"]
-    assert la == lb, (la, lb)
-    assert xa == xb and xa >= 3 * 10, (xa, xb)                                       # the same number of halo refreshes, >= 10 per step
-    assert st[0] == xb and st[1] >= 3 * 5, st                                       # ... issued by the library itself, and its all-reduces
-    # The state after three steps.  Two runs of the SAME path already differ in the last bits (the PCG's dot products and the
-    # solvers' error sums are double-precision atomics over workgroup partials: their order is the scheduler's), so the two
-    # planes are compared at rounding level on the velocity's scale -- three orders of magnitude below what the ghosts change
-    # (checked last) -- and bit for bit where nothing is summed: the exchange itself (next test).
-    names = ["pos"] * 3 + ["vel"] * 3 + ["omega"] * 3 + ["vel_guess"] * 3 + ["kappa", "kappa_v"]
+    for plane in ("native0", "native1", "native2"):
+        _compare_planes(out["callbacks"], out[plane], plane)
+    ra = out["callbacks"][0]
     vscale = float(np.abs(ra[:, 3:6]).max())
-    for c, nm in enumerate(names):
-        scale = {"pos": 1.0, "vel": vscale, "vel_guess": vscale}.get(nm, max(float(np.abs(ra[:, c]).max()), 1e-12))
-        d = float(np.abs(ra[:, c] - rb[:, c]).max()) / scale
-        print("native vs callbacks %-9s col %2d: max diff / scale = %.2e" % (nm, c, d))
-        assert d < (5e-7 if nm == "pos" else 5e-6), (nm, c, d)
-    np.testing.assert_array_equal(ra[:, 14].view(np.int32), rb[:, 14].view(np.int32))
     # and the ghosts mattered: the same rows without any ghost evolve differently
     sim = _ring_sim(mode)
     sim.loopback = sim.force_comm = sim.overlap = False
@@ -105,6 +98,25 @@ def test_native_rccl_data_plane_loopback_equals_the_callback_path(mode):
     print("without the ghosts: velocity differs by %.2e of its scale" % dv)
     assert dv > 2e-2
     sim.B.close()
+
+
+def _compare_planes(a, b, label):
+    (ra, la, xa, _), (rb, lb, xb, st) = a, b
+    assert la == lb, (label, la, lb)
+    assert xa == xb and xa >= 3 * 10, (xa, xb)                                       # the same number of halo refreshes, >= 10 per step
+    assert st[0] == xb and st[1] >= 3 * 5, st                                       # ... issued by the library itself, and its all-reduces
+    # The state after three steps.  Two runs of the SAME path already differ in the last bits (the PCG's dot products and the
+    # solvers' error sums are double-precision atomics over workgroup partials: their order is the scheduler's), so the two
+    # planes are compared at rounding level on the velocity's scale -- three orders of magnitude below what the ghosts change
+    # (checked last) -- and bit for bit where nothing is summed: the exchange itself (next test).
+    names = ["pos"] * 3 + ["vel"] * 3 + ["omega"] * 3 + ["vel_guess"] * 3 + ["kappa", "kappa_v"]
+    vscale = float(np.abs(ra[:, 3:6]).max())
+    for c, nm in enumerate(names):
+        scale = {"pos": 1.0, "vel": vscale, "vel_guess": vscale}.get(nm, max(float(np.abs(ra[:, c]).max()), 1e-12))
+        d = float(np.abs(ra[:, c] - rb[:, c]).max()) / scale
+        print("%s vs callbacks %-9s col %2d: max diff / scale = %.2e" % (label, nm, c, d))
+        assert d < (5e-7 if nm == "pos" else 5e-6), (nm, c, d)
+    np.testing.assert_array_equal(ra[:, 14].view(np.int32), rb[:, 14].view(np.int32))
 
 
 def test_halo_exchange_and_allreduce_entry_points():
@@ -167,3 +179,19 @@ def test_native_communicator_survives_a_rebuilt_context():
     assert sa == sb and sa[0] >= 30                                  # the same exchanges went through the one communicator
     vscale = float(np.abs(ra[:, 3:6]).max())
     assert np.abs(ra[:, :3] - rb[:, :3]).max() < 5e-7 and np.abs(ra[:, 3:6] - rb[:, 3:6]).max() < 5e-6 * vscale
+
+
+def test_halo_schedule_tuning_picks_a_candidate_and_the_run_goes_on():
+    """SlabSim.tune_halo_schedule (bench.py --gpus N calls it before the warm-up): every candidate runs, the fastest stays on."""
+    sim = _ring_sim("clean")
+    sim.enable_native_comm(neighbours=(0, 0))
+    t = sim.tune_halo_schedule(steps=2)
+    assert len(t["candidates_ms_per_step"]) == 3 and t["chosen"] in t["candidates_ms_per_step"], t
+    assert t["candidates_ms_per_step"][t["chosen"]] == min(t["candidates_ms_per_step"].values())
+    chosen = [c for c in sim.HALO_SCHEDULES if c[0] == t["chosen"]][0]
+    assert sim.overlap == chosen[2]
+    x0 = sim.n_exchanges
+    sim.step()
+    torch.cuda.synchronize()
+    assert sim.n_exchanges - x0 >= 10 and np.isfinite(sim.rows.cpu().numpy()).all()
+    sim.B.close()

@@ -69,8 +69,14 @@ struct NativeComm {
   struct Buf { float *send = nullptr, *recv = nullptr; size_t cap_send = 0, cap_recv = 0; };
   Buf buf;
   hipStream_t halo = nullptr;              // the halo refreshes' sends / receives run here, beside the pass on the slab interior
-  hipEvent_t ev_packed = nullptr, ev_landed = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_landed = nullptr, ev_chain = nullptr;
   bool halo_pending = false;               // an exchange is in flight on `halo` that the context's stream has not been made to wait for
+  // wcsph_comm_set_mode: 0 = refreshes inline on the context's stream; 1 = on the halo stream beside the interior pass, the
+  // context's stream waits for them before the unpack; 2 = exchange, unpack AND the pass on the rows next to the cuts on the halo
+  // stream beside the interior pass (api_slab.h SlabRun::xp), one join at the end.  Which is fastest depends on what an exchange
+  // costs on the machine (profiles/r06_overlap.md: on ONE GPU, where it is a 16 us copy, mode 0 without the split): bench.py
+  // --gpus N measures the candidates during warm-up and keeps the fastest.
+  int mode = 1;
   hipStream_t side = nullptr;              // the bucket histogram's all-reduce runs here beside the sort and the list build
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   bool words_pending = false;
@@ -161,6 +167,22 @@ static int ncb_buffers(void *u, int32_t W, void **snd, void **rcv) {
 // done; whatever the caller queues on the context's stream next runs beside them
 static int ncb_post(void *u, int32_t W) {
   NativeComm *c = (NativeComm *)u;
+  // inline: the exchange sits between the pack and the unpack on the context's stream -- no event hop (two of ~12 us each on
+  // this platform), nothing beside it: the cheaper form when the pass is not split (profiles/r06_overlap.md)
+  if (c->mode == 0) return comm_exchange(c, W, c->buf.send, c->buf.recv, c->ctx->n_halo_send, c->ctx->n_halo_ghost, c->ctx->stream);
+#ifdef WCSPH_DEV
+  // diagnostic (development builds): the loop-back exchange as two plain copies on the halo stream instead of RCCL's kernel
+  if (c->left == c->rank && c->right == c->rank && getenv("WCSPH_COMM_LOOPBACK_MEMCPY")) {
+    CHIPCHK(hipEventRecord(c->ev_packed, c->ctx->stream));
+    CHIPCHK(hipStreamWaitEvent(c->halo, c->ev_packed, 0));
+    const size_t sl = (size_t)c->n_send_left * W, sr = (size_t)(c->ctx->n_halo_send - c->n_send_left) * W, gl = (size_t)c->n_ghost_left * W;
+    if (sl) CHIPCHK(hipMemcpyAsync(c->buf.recv + gl, c->buf.send, sl * sizeof(float), hipMemcpyDeviceToDevice, c->halo));
+    if (sr) CHIPCHK(hipMemcpyAsync(c->buf.recv, c->buf.send + sl, sr * sizeof(float), hipMemcpyDeviceToDevice, c->halo));
+    CHIPCHK(hipEventRecord(c->ev_landed, c->halo));
+    c->halo_pending = true; c->n_exchanges++;
+    return 0;
+  }
+#endif
   CHIPCHK(hipEventRecord(c->ev_packed, c->ctx->stream));
   CHIPCHK(hipStreamWaitEvent(c->halo, c->ev_packed, 0));
   int rc = comm_exchange(c, W, c->buf.send, c->buf.recv, c->ctx->n_halo_send, c->ctx->n_halo_ghost, c->halo);
@@ -254,6 +276,7 @@ int wcsph_comm_destroy(wcsph_ctx *ctx) {
   if (c->halo) { hipStreamSynchronize(c->halo); hipStreamDestroy(c->halo); }
   if (c->ev_packed) hipEventDestroy(c->ev_packed);
   if (c->ev_landed) hipEventDestroy(c->ev_landed);
+  if (c->ev_chain) hipEventDestroy(c->ev_chain);
   if (c->ev_ready) hipEventDestroy(c->ev_ready);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   if (c->buf.send) hipFree(c->buf.send);
@@ -285,6 +308,7 @@ int wcsph_comm_init(wcsph_ctx *ctx, const void *unique_id, int32_t rank, int32_t
   }
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || create_halo_stream(&c->halo) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_landed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess || hipMalloc((void **)&c->d_scalar, 2 * sizeof(double)) != hipSuccess) {
     wcsph_comm_destroy(ctx);
@@ -301,6 +325,13 @@ int wcsph_comm_set_neighbours(wcsph_ctx *ctx, int32_t left, int32_t right) {
   NativeComm *c = ctx->comm;
   if (left >= c->nranks || right >= c->nranks) return ctx->fail(WCSPH_EARG, "wcsph_comm_set_neighbours: no such rank");
   c->left = left < 0 ? -1 : left; c->right = right < 0 ? -1 : right;
+  return WCSPH_OK;
+}
+int wcsph_comm_set_mode(wcsph_ctx *ctx, int32_t mode) {
+  if (!ctx || !ctx->comm || mode < 0 || mode > 2) return WCSPH_EARG;
+  NativeComm *c = ctx->comm;
+  if (c->halo_pending) { int rc = ncb_wait(c); if (rc) return rc; }
+  c->mode = mode;
   return WCSPH_OK;
 }
 int wcsph_comm_set_halo_split(wcsph_ctx *ctx, int32_t n_send_left, int32_t n_ghost_left) {

@@ -62,6 +62,13 @@ struct wcsph_ctx {
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   bool prof_on = false;
+  // lap profiling (wcsph_profile_laps_begin / _end): one event behind every tagged launch of the step; the time between two
+  // consecutive events goes to the tag of the later one (stream order: the launch itself + whatever idle time preceded it)
+  std::vector<hipEvent_t> lap_ev;
+  std::vector<const char *> lap_tag;
+  std::vector<unsigned char> lap_waited;   // the host waited for the device (a mail, a scalar pull) since the previous lap
+  bool lap_on = false, lap_wait_flag = false;
+  const char *lap_scope = nullptr;          // != nullptr: laps are booked to this name instead of the kernel's (the two solver iterations share k_vel_from_k<0>)
   bool in_step = false, cfl_done = false;   // wcsph_dfsph_step in progress; CFL maxima already taken
   bool warm_fused = false;        // wcsph_dfsph_step -> solve_divergence: the warm-start density-change pass is already done
   bool fuse_elem = false;         // wcsph_dfsph_step: elementwise neighbours of the launch sequence run fused (set per step)
@@ -101,6 +108,15 @@ struct wcsph_ctx {
     hipError_t e_ = hipGetLastError();                               \
     if (e_ != hipSuccess) return ctx->fail(WCSPH_EHIP, "kernel launch", e_); \
   } while (0)
+// lap profiling: see wcsph_ctx::lap_ev
+static inline void prof_lap(wcsph_ctx *ctx, const char *tag) {
+  if (ctx->lap_tag.size() >= ctx->lap_ev.size()) return;
+  if (hipEventRecord(ctx->lap_ev[ctx->lap_tag.size()], ctx->stream) != hipSuccess) return;
+  ctx->lap_tag.push_back(ctx->lap_scope ? ctx->lap_scope : tag);
+  ctx->lap_waited.push_back(ctx->lap_wait_flag ? 1 : 0);
+  ctx->lap_wait_flag = false;
+}
+#define PROF_LAP(ctx, tag) do { if ((ctx)->lap_on) prof_lap(ctx, tag); } while (0)
 #define NEED_SETUP()                                                                  \
   if (!ctx) return WCSPH_EARG;                                                        \
   if (!ctx->is_setup) return ctx->fail(WCSPH_EARG, "wcsph_setup() has not been called")
@@ -220,6 +236,7 @@ static int collect_mail(wcsph_ctx *ctx, bool check_acc, unsigned long long seq =
   if (seq == 0) seq = ctx->mail_seq;
   HostMail *m = reinterpret_cast<HostMail *>(ctx->h_acc_raw) + seq % MAIL_RING;
   volatile unsigned long long *flag = &m->seq;
+  if (ctx->lap_on && *flag != seq) ctx->lap_wait_flag = true;   // the host is about to spin: the next lap starts behind a host wait
   for (unsigned long spins = 0; *flag != seq; spins++) {
     if ((spins & 0xfffff) == 0xfffff) {   // every ~1 M polls: is the stream still alive?
       hipError_t q = hipStreamQuery(ctx->stream);

@@ -8,6 +8,7 @@ extern "C" {
     if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk8(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
     ctx->d.rev ^= 1;   /* the next neighbour pass walks the particles the other way round (device.h sorted_index) */ \
     LAUNCHCHK();                                                                                  \
+    PROF_LAP(ctx, #kern);                                                                         \
   } while (0)
 /* walks over the (pos, rho) records: packed first unless this context's own density pass just wrote them for every row */
 #define RPASS(kern, ...)                                                                          \
@@ -22,6 +23,7 @@ extern "C" {
   do {                                                                                            \
     if (ctx->d.nl > 0) hipLaunchKernelGGL(kern, dim3(nblk(ctx->d.nl)), dim3(BLOCK), 0, ctx->stream, ctx->d, ##__VA_ARGS__); \
     LAUNCHCHK();                                                                                  \
+    PROF_LAP(ctx, #kern);                                                                         \
   } while (0)
 
 #define HOT_DRHO_DIV(mode, dtv) PASS(k_drho_div<mode>, dtv)
@@ -71,19 +73,23 @@ static int pressure_iter_async(wcsph_ctx *ctx) {
 // fused-loop variants: k_i comes from the previous drho launch's epilogue (FUSEK), kappa += k_i in the vel launch
 static int divergence_iter_fused(wcsph_ctx *ctx) {
   if (ctx->d.n_owned < ctx->d.nl) return divergence_iter_async(ctx);
+  ctx->lap_scope = "divergence_iter";
   PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa_v);   // also clears ACC_ERR
   if (ctx->fuse_elem && ctx->vort_fuse && ctx->pr_valid) {
     PASS(k_drho_div_iter_vort, ctx->dt);
     ctx->vort_in_div = true;
   } else PASS((k_drho_div<DRHO_ITER, true>), ctx->dt);
+  ctx->lap_scope = nullptr;
   return 0;
 }
 static int pressure_iter_fused(wcsph_ctx *ctx) {
   if (ctx->d.n_owned < ctx->d.nl) return pressure_iter_async(ctx);
   const bool prof = ctx->prof_on && ctx->prof_used + 2 <= ctx->prof_ev.size();
   if (prof) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
+  ctx->lap_scope = "pressure_iter";
   PASS(k_vel_from_k<0>, (const float4 *)ctx->d.pk, ctx->dt, ctx->d.kappa);     // also clears ACC_ERR
   PASS((k_drho_press<DRHO_ITER, true>), ctx->dt);
+  ctx->lap_scope = nullptr;
   if (prof) { HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream)); ctx->prof_used += 2; }
   return 0;
 }
@@ -485,6 +491,7 @@ int wcsph_dfsph_step(wcsph_ctx *ctx) {  // ref: dfsph.py:606-617
   // a step that failed half-way (launch error, reported device condition) must not leave its speculation state behind
   ctx->d.pred = nullptr; ctx->d.dtp = nullptr;
   ctx->spec_visc_seq = ctx->spec_cfl_seq = ctx->spec_press_seq = 0; ctx->spec_dt = false; ctx->pr_resume = false;
+  PROF_LAP(ctx, "step_boundary");   // since the last launch of the previous step: the host between two steps
   if ((rc = wcsph_grid_update(ctx))) return rc;
   if (ctx->d.n_owned == ctx->d.nl) {
     PASS(k_density_coff_warm, ctx->dt);  // compute_density + compute_dfsph_coff + first warm-start pass in one walk

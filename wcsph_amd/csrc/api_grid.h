@@ -154,9 +154,13 @@ static int grid_finish(wcsph_ctx *ctx, bool single) {
 int wcsph_grid_update(wcsph_ctx *ctx) {
   NEED_SETUP();
   int rc = grid_assign(ctx, true);
+  PROF_LAP(ctx, "grid:cells");
   if (!rc) rc = grid_sort(ctx);
+  PROF_LAP(ctx, "grid:scan+sort");
   if (!rc) rc = grid_counts(ctx);
+  PROF_LAP(ctx, "grid:neighborCount");
   if (!rc) rc = grid_lists(ctx);
+  PROF_LAP(ctx, "k_build_lists");
   if (!rc) rc = grid_finish(ctx, true);
   return rc;
 }

@@ -31,6 +31,52 @@ int wcsph_profile_end(wcsph_ctx *ctx, float *avg_ms, int32_t *launches) {
   return WCSPH_OK;
 }
 
+// lap profiling of the steps that follow (wcsph_ctx::lap_ev): per tag the summed time and the number of laps, as JSON text
+// {"<tag>": [ms, laps, ms_of_laps_that_followed_a_host_wait], ...}
+int wcsph_profile_laps_begin(wcsph_ctx *ctx, int32_t max_laps) {
+  NEED_SETUP();
+  if (max_laps < 2 || max_laps > (1 << 22)) return WCSPH_EARG;
+  while (ctx->lap_ev.size() < (size_t)max_laps) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    ctx->lap_ev.push_back(e);
+  }
+  ctx->lap_tag.clear(); ctx->lap_waited.clear();
+  ctx->lap_on = true; ctx->lap_wait_flag = false;
+  return WCSPH_OK;
+}
+int wcsph_profile_laps_end(wcsph_ctx *ctx, char *json_out, size_t cap) {
+  NEED_SETUP();
+  if (!json_out || cap < 64) return WCSPH_EARG;
+  ctx->lap_on = false;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  struct Acc { double ms = 0, ms_wait = 0; long n = 0; };
+  std::vector<std::pair<std::string, Acc>> acc;
+  for (size_t k = 1; k < ctx->lap_tag.size(); k++) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, ctx->lap_ev[k - 1], ctx->lap_ev[k]));
+    std::string tag(ctx->lap_tag[k]);
+    size_t q = 0;
+    while (q < acc.size() && acc[q].first != tag) q++;
+    if (q == acc.size()) acc.push_back({tag, Acc()});
+    acc[q].second.ms += t; acc[q].second.n++;
+    if (ctx->lap_waited[k]) acc[q].second.ms_wait += t;
+  }
+  std::string out = "{";
+  for (size_t q = 0; q < acc.size(); q++) {
+    char buf[128];
+    snprintf(buf, sizeof buf, "[%.6f, %ld, %.6f]", acc[q].second.ms, acc[q].second.n, acc[q].second.ms_wait);
+    std::string tag;
+    for (char ch : acc[q].first) if (ch != '"' && ch != '\\') tag += ch;
+    out += (q ? ", \"" : "\"") + tag + "\": " + buf;
+  }
+  out += "}";
+  ctx->lap_tag.clear(); ctx->lap_waited.clear();
+  if (out.size() + 1 > cap) return ctx->fail(WCSPH_EARG, "wcsph_profile_laps_end: buffer too small");
+  memcpy(json_out, out.c_str(), out.size() + 1);
+  return WCSPH_OK;
+}
+
 int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
   NEED_GRID();
   if (!name || reps < 1 || !ms) return WCSPH_EARG;

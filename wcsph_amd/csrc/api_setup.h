@@ -92,6 +92,7 @@ int wcsph_destroy(wcsph_ctx *ctx) {
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->lap_ev) hipEventDestroy(e);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;

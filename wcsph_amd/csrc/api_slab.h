@@ -289,8 +289,37 @@ struct SlabRun {
     if ((rc = cb->halo_post(cb->user, h.W))) return ctx->fail(rc, "slab callback halo_post failed");
     n_xchg++;
     const bool split = overlap && has_pass;
+    // Native plane, mode 2 (csrc/api_comm.h): the whole boundary chain -- exchange, unpack, the pass on the rows next to the cuts --
+    // runs on the communicator's halo stream BESIDE the pass on the interior; the context's stream joins it once, at the end.
+    // In stream order there is then no event hop between the exchange and the unpack, and the short boundary launch (latency-bound
+    // on its own: ~20 us for an eighth of the rows) shares the GPU with the interior launch instead of following it.  Safe
+    // because the two launches write disjoint rows, interior rows read no ghost row, and every reduction slot is only added to.
+    NativeComm *nc = (split && ctx->comm && cb == &ctx->comm->cb && ctx->comm->mode == 2) ? ctx->comm : nullptr;
+    if (nc) {
+      ctx->d.part_mode = 1; ctx->d.part_x0 = ilo; ctx->d.part_x1 = ihi > ilo ? ihi : ilo;
+      if ((rc = launch())) { ctx->d.part_mode = 0; return rc; }
+      hipStream_t keep = ctx->stream;
+      ctx->stream = nc->halo;
+      rc = unpack(rcv, also);
+      if (!rc) { ctx->d.part_mode = 2; rc = launch(); }
+      ctx->stream = keep;
+      ctx->d.part_mode = 0;
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(nc->ev_chain, nc->halo));
+      HIPCHK(hipStreamWaitEvent(ctx->stream, nc->ev_chain, 0));
+      nc->halo_pending = false;
+      return 0;
+    }
     if (split) { ctx->d.part_mode = 1; ctx->d.part_x0 = ilo; ctx->d.part_x1 = ihi > ilo ? ihi : ilo; if ((rc = launch())) return rc; }
     if ((rc = cb->halo_wait(cb->user))) return ctx->fail(rc, "slab callback halo_wait failed");
+    if ((rc = unpack(rcv, also))) return rc;
+    if (!has_pass) return 0;
+    if (split) ctx->d.part_mode = 2;
+    rc = launch();
+    ctx->d.part_mode = 0;
+    return rc;
+  }
+  int unpack(const void *rcv, const HaloFields *also) {   // on ctx->stream (whichever stream that currently is)
     if (ctx->n_halo_ghost > 0) {
       hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ctx->n_halo_ghost * h.W)), dim3(BLOCK), 0, ctx->stream, h, (const int *)ctx->d.where, ctx->halo_ghost, ctx->n_halo_ghost, (const float *)rcv);
       if (also) {
@@ -299,11 +328,7 @@ struct SlabRun {
       }
       LAUNCHCHK();
     }
-    if (!has_pass) return 0;
-    if (split) ctx->d.part_mode = 2;
-    rc = launch();
-    ctx->d.part_mode = 0;
-    return rc;
+    return 0;
   }
   int allreduce(int slot) {   // the stripes of a reduction slot summed over the ranks, in place on the device
     int rc;

@@ -252,6 +252,10 @@ class HipBackend:
             self._chk(self.lib.wcsph_comm_set_neighbours(self.ctx, int(neighbours[0]), int(neighbours[1])))
         self.native_comm = True
 
+    def comm_set_mode(self, mode):
+        """1: halo refreshes on the communicator's own stream (beside the interior pass); 0: inline on the context's stream"""
+        self._chk(self.lib.wcsph_comm_set_mode(self.ctx, int(mode)))
+
     def comm_detach(self):
         h = C.c_void_p()
         self._chk(self.lib.wcsph_comm_detach(self.ctx, C.byref(h)))
@@ -480,6 +484,43 @@ class SlabSim:
                 self.disable_native_comm()
             raise RuntimeError("native data plane: wcsph_comm_init failed on at least one rank%s" % (" (here: %s)" % err if err else ""))
 
+    def set_overlap(self, on):
+        """split the neighbour passes into interior / rest around the halo refreshes (kept across a rebalance)"""
+        self._overlap_choice = bool(on)
+        self.overlap = bool(on)
+
+    HALO_SCHEDULES = [("exchange inline on the context's stream, passes not split", 0, False),
+                      ("exchange on the halo stream beside the interior pass", 1, True),
+                      ("exchange + unpack + boundary pass on the halo stream beside the interior pass", 2, True)]
+
+    def _max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        vals = [None] * self.world
+        dist.all_gather_object(vals, float(x))
+        return max(vals)
+
+    def tune_halo_schedule(self, steps=3):
+        """Native data plane only, collective: `steps` steps (after one to settle) of each way of scheduling a halo refresh
+        (wcsph_comm_set_mode x the interior / boundary split), the maximum over the ranks decides -- the same numbers on every
+        rank -- and the fastest is left switched on.  Advances the simulation by (steps + 1) x 3 steps."""
+        if not getattr(self.B, "native_comm", False):
+            raise RuntimeError("tune_halo_schedule: the native data plane is not on")
+        sync = (lambda: torch.cuda.synchronize(self.device)) if self.device.type == "cuda" else (lambda: None)
+        times = []
+        for _label, m, ov in self.HALO_SCHEDULES:
+            self.B.comm_set_mode(m); self.set_overlap(ov)
+            self.step()
+            sync(); self._max_over_ranks(0.0); t0 = time.perf_counter()      # (the exchange of the maximum is the barrier)
+            for _ in range(steps):
+                self.step()
+            sync()
+            times.append(self._max_over_ranks(time.perf_counter() - t0) / steps)
+        best = int(np.argmin(times))
+        self.B.comm_set_mode(self.HALO_SCHEDULES[best][1]); self.set_overlap(self.HALO_SCHEDULES[best][2])
+        return {"candidates_ms_per_step": {c[0]: round(t * 1e3, 3) for c, t in zip(self.HALO_SCHEDULES, times)},
+                "chosen": self.HALO_SCHEDULES[best][0], "steps_spent": (steps + 1) * len(self.HALO_SCHEDULES)}
+
     def disable_native_comm(self):
         if self.B is not None and getattr(self.B, "native_comm", False):
             _lib.check(self.B.ctx, self.B.lib.wcsph_comm_destroy(self.B.ctx))     # (drains the context's stream first)
@@ -540,7 +581,7 @@ class SlabSim:
         # halo/compute overlap: a neighbour pass that needs a halo refresh runs on the slab interior (columns at least
         # GHOST_CELLS away from a cut with a neighbour: no ghost within reach) while the exchange is in flight, then on
         # the rest.  WCSPH_SLAB_OVERLAP=0 switches it off.
-        self.overlap = world > 1 and os.environ.get("WCSPH_SLAB_OVERLAP", "1") != "0"
+        self.overlap = (world > 1 and os.environ.get("WCSPH_SLAB_OVERLAP", "1") != "0") if getattr(self, "_overlap_choice", None) is None else self._overlap_choice
         big = 1 << 20
         self.interior = (self.lo + GHOST_CELLS if rank > 0 else -big, self.hi - GHOST_CELLS if rank < world - 1 else big)
         # preallocated halo buffers (sized for the widest exchange: two vec3 fields), grown on demand
@@ -1297,6 +1338,13 @@ def bench_main(args):
                 sim.disable_native_comm()
             except Exception:       # noqa: BLE001
                 sim.B.native_comm = False
+    # How a halo refresh is scheduled is MEASURED, not assumed (round 6, profiles/r06_overlap.md): on one GPU, where an exchange is a
+    # 16 us copy, the inline form without the interior / boundary split is fastest; with real neighbours it depends on what an
+    # exchange costs over xGMI.  Three steps of each candidate before the warm-up, the maximum over the ranks decides (the same
+    # numbers on every rank: all-reduced over the control plane).
+    tuning = None
+    if getattr(sim.B, "native_comm", False) and os.environ.get("WCSPH_BENCH_TUNE", "1") != "0":
+        tuning = sim.tune_halo_schedule()
     iters = []
     for _ in range(args.warmup):
         sim.step()
@@ -1345,10 +1393,11 @@ def bench_main(args):
                        "neighbor_mode": args.mode, "n_liquid": n_global, "cuts": sim.cuts, "comm": comm, "data_plane": plane,
                        "step_driver": ("wcsph_slab_step (library, its own RCCL communicator)" if getattr(sim.B, "native_comm", False) else
                                        "wcsph_slab_step (library, communicator behind callbacks)") if sim.native else "python phase driver",
-                       "host_waits_per_step": round(sim.n_host_waits / float(args.steps + args.warmup), 1),
+                       "halo_schedule_tuning": tuning,
+                       "host_waits_per_step": round(sim.n_host_waits / float(max(sim.steps_done, 1)), 1),
                        "rebalance_every": sim.rebalance_every, "rebalanced": sim.n_rebalanced,
                        "owned_per_rank": [int(c.item()) for c in allc],
-                       "halo_exchanges_per_step": round(sim.n_exchanges / float(args.steps + args.warmup), 1),
+                       "halo_exchanges_per_step": round(sim.n_exchanges / float(max(sim.steps_done, 1)), 1),
                        "mean_iters": {"vs": round(it[:, 0].mean(), 2), "dv": round(it[:, 1].mean(), 2), "pr": round(it[:, 2].mean(), 2)}},
             "roofline": {"bound": "hbm", "kernel": "pressure_iter on rank 0's slab (k_make_k + k_vel_from_k + k_drho_press<ITER>), ref dfsph.py:518-547",
                          "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
