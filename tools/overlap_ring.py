@@ -5,12 +5,12 @@
 tests/test_gpu_native_comm.py (the ghosts are the slab's own rows near the opposite end, shifted by the slab's width).  Every halo
 refresh of wcsph_slab_step moves real rows through
    callbacks   the caller's communicator behind wcsph_slab_callbacks (torch copies on torch's side stream)
-   native      grouped ncclSend / ncclRecv on the library's halo stream (csrc/api_comm.h), mode 2: exchange, unpack and the pass on the
-               rows next to the cuts on the halo stream beside the interior pass; _m1: only the exchange there; _inline: the exchange
-               on the context's stream, passes not split
+   native      grouped ncclSend / ncclRecv inside the library (csrc/api_comm.h); _m1: the exchange on the halo stream beside the
+               interior pass (the default); _m2: exchange, unpack and the pass on the rows next to the cuts on the halo stream beside
+               the interior pass; _inline: the exchange on the context's stream, passes not split
 with and without the interior / boundary split of the neighbour passes (_nosplit).
 
-   python tools/overlap_ring.py [nx=32] [ny=252] [nz=252] [mode=clean] [steps=20] [variants=callbacks,callbacks_nosplit,native,native_m1,native_inline]
+   python tools/overlap_ring.py [nx=32] [ny=252] [nz=252] [mode=clean] [steps=20] [variants=callbacks,callbacks_nosplit,native_m1,native_m2,native_m1_nosplit,native_inline]
 prints one JSON line (ms per step per variant; the ring's own redistribute -- a full state store + load per step, the price of the
 periodic seam -- is measured separately and is the same for every variant).
    WCSPH_RING_TRACE=1 python tools/overlap_ring.py ...   -> only `native`, for rocprofv3 --kernel-trace (tools/rocpd_overlap.py)"""
@@ -26,10 +26,10 @@ ny = int(a[1]) if len(a) > 1 else 252
 nz = int(a[2]) if len(a) > 2 else 252
 mode = a[3] if len(a) > 3 else "clean"
 steps = int(a[4]) if len(a) > 4 else 20
-variants = (a[5] if len(a) > 5 else "callbacks,callbacks_nosplit,native,native_m1,native_inline").split(",")
+variants = (a[5] if len(a) > 5 else "callbacks,callbacks_nosplit,native_m1,native_m2,native_m1_nosplit,native_inline").split(",")
 trace = os.environ.get("WCSPH_RING_TRACE") == "1"
 if trace:
-    variants = [os.environ.get("WCSPH_RING_VARIANT", "native")]
+    variants = [os.environ.get("WCSPH_RING_VARIANT", "native_m1")]
 warm = 6
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -96,8 +96,10 @@ for v in variants:
         sim.overlap = False
     if v.endswith("inline"):
         sim.B.comm_set_mode(0)
-    if v.endswith("m1"):
+    if "_m1" in v:
         sim.B.comm_set_mode(1)
+    if "_m2" in v:
+        sim.B.comm_set_mode(2)
     for _ in range(warm):
         sim.step()
     sim.t_red[0], sim.t_red[1] = 0.0, 0

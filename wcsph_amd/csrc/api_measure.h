@@ -100,6 +100,7 @@ int wcsph_time_kernel(wcsph_ctx *ctx, const char *name, int reps, float *ms) {
     if (nm == "visc_minv_residual") { int r = zero_acc(ctx, ACC_DZERO); if (r) return r; RPASS(k_visc_minv_residual, ctx->dt); return 0; }
     if (nm == "build_lists") { PASS(k_build_lists, 1); return 0; }
     if (nm == "visc_iter") { int r = zero_acc(ctx, ACC_DAD); if (r) return r; RPASS(k_visc_Ad, ctx->dt); return 0; }
+    if (nm == "drho_press_rec") { PASS((k_drho_press<DRHO_ITER, true>), ctx->dt); return 0; }   // the density-change pass as the fused loop launches it
     return ctx->fail(WCSPH_EARG, "wcsph_time_kernel: unknown kernel group");
   };
   if (nm == "pressure_iter" && (rc = pressure_iter_async(ctx))) return rc;      // primes the (pos, k) records
