@@ -382,17 +382,9 @@ def _main():
         m2 = C.c_float()
         _lib.check(ctx, lib.wcsph_time_kernel(ctx, name.encode(), max(args.kernel_reps // 2, 2), C.byref(m2)))
         extra[name + "_us"] = round(m2.value * 1e3, 1)
-    # HBM traffic of the pair from the PMC counters: recorded by tools/pmc_traffic.sh (rocprofv3 cannot run inside this
-    # process); quoted only if it was taken on THIS kernel source and THIS workload, otherwise null
+    # HBM traffic of the pair from the PMC counters, measured in THIS run by child rocprofv3 passes (null when they fail: a recorded
+    # figure from another source tree is never substituted)
     traffic, traffic_note = (None, "skipped (--no-pmc)") if args.no_pmc else measure_traffic_live(n, args.mode)
-    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if traffic is None and os.path.exists(tf):   # fall back to the committed record, only if it was taken on THIS kernel source
-        try:
-            t = json.load(open(tf))
-            if t.get("n_liquid") == nl and t.get("kernel_source_sha16") == kernel_source_sha16():
-                traffic, traffic_note = t.get("pressure_iter_bytes_per_launch"), "%s (recorded; live pass: %s)" % (t.get("source"), traffic_note)
-        except Exception:
-            pass
     pipes = {"note": "skipped (--no-pmc)"} if args.no_pmc else measure_pipes_live(n, args.mode)
     it = r["iters"]
     out = {

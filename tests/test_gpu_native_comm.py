@@ -103,8 +103,8 @@ def test_native_rccl_data_plane_loopback_equals_the_callback_path(mode):
 def _compare_planes(a, b, label):
     (ra, la, xa, _), (rb, lb, xb, st) = a, b
     assert la == lb, (label, la, lb)
-    assert xa == xb and xa >= 3 * 10, (xa, xb)                                       # the same number of halo refreshes, >= 10 per step
-    assert st[0] == xb and st[1] >= 3 * 5, st                                       # ... issued by the library itself, and its all-reduces
+    assert xa == xb and xa >= 3 * 9, (xa, xb)                                        # the same number of halo refreshes, >= 9 per step
+    assert st[0] == xb and st[1] >= 3 * 4, st                                       # ... issued by the library itself, and its all-reduces
     # The state after three steps.  Two runs of the SAME path already differ in the last bits (the PCG's dot products and the
     # solvers' error sums are double-precision atomics over workgroup partials: their order is the scheduler's), so the two
     # planes are compared at rounding level on the velocity's scale -- three orders of magnitude below what the ghosts change
@@ -176,7 +176,7 @@ def test_native_communicator_survives_a_rebuilt_context():
         out[rebuild] = (sim.rows.cpu().numpy().copy(), sim.B.comm_stats())
         sim.B.close()
     (ra, sa), (rb, sb) = out[False], out[True]
-    assert sa == sb and sa[0] >= 30                                  # the same exchanges went through the one communicator
+    assert sa == sb and sa[0] >= 27                                  # the same exchanges went through the one communicator
     vscale = float(np.abs(ra[:, 3:6]).max())
     assert np.abs(ra[:, :3] - rb[:, :3]).max() < 5e-7 and np.abs(ra[:, 3:6] - rb[:, 3:6]).max() < 5e-6 * vscale
 
@@ -193,5 +193,5 @@ def test_halo_schedule_tuning_picks_a_candidate_and_the_run_goes_on():
     x0 = sim.n_exchanges
     sim.step()
     torch.cuda.synchronize()
-    assert sim.n_exchanges - x0 >= 10 and np.isfinite(sim.rows.cpu().numpy()).all()
+    assert sim.n_exchanges - x0 >= 9 and np.isfinite(sim.rows.cpu().numpy()).all()
     sim.B.close()

@@ -104,7 +104,7 @@ def test_three_slabs_on_a_live_squeezed_state_equal_the_single_context(tmp_path,
         rows, rho = rows[order], rho[order]
         for l in logs:
             assert tuple(int(x) for x in l[:3]) == (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter), (s, l, (dfsph.vs_iter, dfsph.dv_iter, dfsph.pr_iter))
-            assert abs(l[3] - dt) <= 1e-6 * dt
+            assert abs(l[3] - dt) <= (1e-6 if s == 0 else 2e-5) * dt      # (step 1: dt follows the CFL maximum of velocities that agree to ~1e-5 on this state)
         assert min(l[6] - l[5] for l in logs[1:-1]) >= 6, [tuple(l[5:7]) for l in logs]     # the middle rank has an interior of >= 6 columns
         one = {"pos": pd.pos.to_numpy()[:nl], "vel": pd.vel.to_numpy(), "omega": pd.omega.to_numpy(), "vel_guess": pd.vel_guess.to_numpy(),
                "kappa": dfsph.kappa.to_numpy(), "kappa_v": dfsph.kappa_v.to_numpy(), "rho": pd.rho.to_numpy()}

@@ -204,6 +204,12 @@ static int ncb_acc(void *u, int32_t slot) {
   c->n_allreduces++;
   return 0;
 }
+static int native_allreduce_slots(NativeComm *c, int slot0, int nslots) {   // a contiguous range of reduction slots in one call
+  double *p = c->ctx->d.acc + slot0 * ACC_STRIPES;
+  NCCLCHK(c->api->AllReduce(p, p, (size_t)nslots * ACC_STRIPES, ncclDouble, ncclSum, c->comm, c->ctx->stream));
+  c->n_allreduces++;
+  return 0;
+}
 static int ncb_max(void *u, double *v) {   // (only without allreduce_max_bits: never on this communicator; kept complete)
   NativeComm *c = (NativeComm *)u;
   CHIPCHK(hipMemcpyAsync(c->d_scalar, v, sizeof(double), hipMemcpyHostToDevice, c->ctx->stream));

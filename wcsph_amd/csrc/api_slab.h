@@ -240,13 +240,15 @@ int wcsph_slab_set_halo(wcsph_ctx *ctx, const int32_t *d_send_idx, int32_t n_sen
   return WCSPH_OK;
 }
 }  // extern "C" (templates below)
-// ghost rows' gather records: (pos, 0) -- their payload (.w) arrives with the halo refreshes, their positions do not
-// change during the step
-__global__ void k_ghost_records(Dev d) {
+// ghost rows' gather records.  (pos, rho) record: rho arrives with the first halo refresh of the step.  (pos, k) record of the
+// warm-start velocity pass: k = the rescaled kappa_v (dfsph.py:416), formed HERE from the kappa_v the ghost row brought with it --
+// the same expression on the same bits as its owner's k_density_coff_warm, so nothing has to travel (round 6: one exchange per
+// step less).  Their positions do not change during the step.
+__global__ void k_ghost_records(Dev d, float dt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.nl || d.oid[i] < d.n_owned) return;
   const float4 p = d.pos[i];
-  d.pk[i] = make_float4(p.x, p.y, p.z, 0.f);
+  d.pk[i] = make_float4(p.x, p.y, p.z, 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0));
   d.pr[i] = make_float4(p.x, p.y, p.z, 0.f);
 }
 // which blocks of BLOCK consecutive sorted rows hold owned particles of the slab interior (bit 0) / of the rest (bit 1), for the
@@ -335,6 +337,17 @@ struct SlabRun {
     if (multi && (rc = cb->allreduce_acc(cb->user, slot))) return ctx->fail(rc, "slab callback allreduce_acc failed");
     return 0;
   }
+  // slots a..b (contiguous; what lies between must be zero on every rank or not yet needed) in one call on the native plane, one
+  // call per end slot behind callbacks
+  int allreduce_range(int a, int b) {
+    if (!multi) return 0;
+    if (ctx->comm && cb == &ctx->comm->cb) {
+      int rc = native_allreduce_slots(ctx->comm, a, b - a + 1);
+      return rc ? ctx->fail(rc, "native all-reduce of the reduction slots failed") : 0;
+    }
+    int rc = allreduce(a);
+    return rc ? rc : allreduce(b);
+  }
   int fetch() { n_wait++; return pull_scalars(ctx); }   // one host wait: every slot total + the error flags
 };
 }  // namespace
@@ -389,7 +402,7 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
     SRC(wcsph_grid_update_end(ctx));
   } else SRC(wcsph_grid_update(ctx));
   if (d.nl == 0) { if (stats) stats[0] = stats[1] = 0; return WCSPH_OK; }
-  if (d.n_owned < d.nl) ELEM(k_ghost_records);
+  if (d.n_owned < d.nl) ELEM(k_ghost_records, ctx->dt);
   if (R.overlap) {
     // The interior is taken to whole TILES of the cell order along x (4 columns when x is the middle axis, 2 when it is the outer
     // one; device.h cell_lin): 64 consecutive sorted particles are then all interior or all rest except where a run of tiles ends,
@@ -408,18 +421,20 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   // pos_j / vel_j only, which the ghost rows brought with them
   PASS(k_density_coff_warm, ctx->dt);
   ctx->dv_iter = 0;
-  // rho_j (field and gather record) and the rescaled kappa_v_j (the payload of the warm-start velocity pass) in ONE message
-  R.hf_begin(); R.hf_add(d.rho, 1, 1); R.hf_add((const float *)d.pk + 3, 1, 4);
+  // Halo refreshes of the step's opening (round 6: two where there were three).  The warm-start velocity pass (dfsph.py:420-439)
+  // needs the neighbours' rescaled kappa_v: the ghost rows formed it themselves (k_ghost_records) -- no exchange.  rho_j (the field
+  // and the (pos, rho) records) is first read by the last divergence iteration: it rides on the velocity refresh that
+  // begin_divergence_iter needs anyway.
+  SRC(SPASS_(k_vel_from_k<1>, (const float4 *)d.pk, ctx->dt)());      // warm-start velocities; interior and boundary alike: no ghost field is stale
+  const float dt = ctx->dt;
+  R.hf_begin(); R.hf_add(d.vel, 3, 4); R.hf_add(d.rho, 1, 1);
   {
-    HaloFields also = R.h;                    // column 0 once more: -> pr.w
-    also.ptr[0] = (const float *)d.pr + 3; also.stride[0] = 4;
-    SRC(R.xp(false, no_pass, &also));
+    HaloFields also = R.h;                    // the rho column once more: -> pr.w
+    also.ptr[0] = nullptr;
+    also.ptr[1] = (const float *)d.pr + 3; also.stride[1] = 4;
+    SRC(R.xp(true, SPASS_((k_drho_div<DRHO_BEGIN, true>), dt), &also));
   }
   ctx->pr_valid = true;                       // (pos, rho) records of every row: own rows by the density pass, ghosts just now
-  SRC(SPASS_(k_vel_from_k<1>, (const float4 *)d.pk, ctx->dt)());      // warm-start velocities (dfsph.py:420-439); ghosts' kappa_v arrived above
-  const float dt = ctx->dt;
-  R.hf_begin(); R.hf_add(d.vel, 3, 4);
-  SRC(R.xp(true, SPASS_((k_drho_div<DRHO_BEGIN, true>), dt)));
 
   // ---- the pieces of the step; every launch honours ctx->d.pred (a gated piece does nothing when its predicate is 0), the
   // exchanges in between are unconditional: a gated-off exchange moves a stale buffer that nobody unpacks
@@ -440,13 +455,15 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
       R.hf_begin(); R.hf_add(d.normal, 3, 4);
       if ((rc = R.xp(true, SPASS_(k_tension_accel)))) return rc;
     }
-    R.hf_begin(); R.hf_add(d.vel_guess, 3, 4);
-    if (vort) { if ((rc = R.xp(true, SPASS_(k_visc_minv_residual, dt)))) return rc; }
-    else if ((rc = R.xp(true, SPASS_(k_visc_minv_residual_vort, dt)))) return rc;
-    if ((rc = R.allreduce(ACC_DZERO))) return rc;                     // the first k_visc_update takes delta_zero from the device
+    // (no refresh of vel_guess_j: k_end_div_begin_nonpressure advanced it on the ghost rows too -- from the vel_guess they
+    // brought with them and the velocities the last refresh gave them, the owner's own arithmetic on the owner's own bits;
+    // round 6: one exchange per step less)
+    if (vort) { if ((rc = SPASS_(k_visc_minv_residual, dt)())) return rc; }
+    else if ((rc = SPASS_(k_visc_minv_residual_vort, dt)())) return rc;
     R.hf_begin(); R.hf_add(d.cg_dir, 3, 4);
     if ((rc = R.xp(true, SPASS_(k_visc_Ad, dt)))) return rc;
-    if ((rc = R.allreduce(ACC_DAD))) return rc;
+    // delta_zero (first read by k_visc_update) and dAd in ONE all-reduce where the communicator can sum a range of slots
+    if ((rc = R.allreduce_range(ACC_DAD, ACC_DZERO))) return rc;
     ELEM(k_visc_update, 0.0f, 1);
     return R.allreduce(ACC_DNEW);
   };

@@ -879,6 +879,7 @@ __global__ void k_halo_unpack(HaloFields h, const int *where, const int *idx, in
   const int k = t / h.W;
   int c = t % h.W, f = 0;
   while (c >= h.width[f]) { c -= h.width[f]; f++; }
+  if (!h.ptr[f]) return;   // (a second set of destinations may leave columns out)
   const_cast<float *>(h.ptr[f])[(size_t)where[idx[k]] * h.stride[f] + c] = in[t];
 }
 // rows by explicit ORIGINAL index list (single field)
