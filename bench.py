@@ -306,10 +306,21 @@ def leg(value_n, r, steps):
 
 
 def main():
-    # the reference's classes print scene statistics (ParticleData.py:185, HashGrid.py:54); stdout carries the JSON line only
+    # stdout carries the ONE JSON line and nothing else: the reference's classes print scene statistics (ParticleData.py:185,
+    # HashGrid.py:54), and C++ layers under torch.distributed write to file descriptor 1 directly (gloo's "[Gloo] Rank r is
+    # connected to ...", RCCL's version banner at the first communicator) -- for the whole run fd 1 points at stderr, and the line
+    # goes to the real stdout at the end
     import contextlib
-    with contextlib.redirect_stdout(sys.stderr):
-        out = _main()
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            out = _main()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real, 1)
+        os.close(real)
     if out is not None:
         print(json.dumps(out), flush=True)
 

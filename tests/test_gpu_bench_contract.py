@@ -44,8 +44,9 @@ def test_two_rank_bench_line_over_gloo():
                         "--cpu-n", "8"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout
+    # stdout of the whole job is the ONE line: nothing of gloo's / RCCL's own chatter (they write to fd 1 directly) may reach it
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["neighbor_mode"] == "faithful" and sum(d["config"]["owned_per_rank"]) == d["config"]["n_liquid"]
@@ -68,8 +69,8 @@ def test_two_rank_bench_survives_an_rccl_that_refuses():
                         "--cpu-n", "8"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and sum(d["config"]["owned_per_rank"]) == d["config"]["n_liquid"]
     assert d["config"]["comm"].startswith("gloo fallback") and "RCCL probe failed" in r.stderr

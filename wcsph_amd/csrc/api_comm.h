@@ -167,6 +167,7 @@ static int ncb_buffers(void *u, int32_t W, void **snd, void **rcv) {
 // done; whatever the caller queues on the context's stream next runs beside them
 static int ncb_post(void *u, int32_t W) {
   NativeComm *c = (NativeComm *)u;
+  if (c->ctx->n_halo_send == 0 && c->ctx->n_halo_ghost == 0) { c->n_exchanges++; return 0; }   // nothing travels: no call, no event hop
   // inline: the exchange sits between the pack and the unpack on the context's stream -- no event hop (two of ~12 us each on
   // this platform), nothing beside it: the cheaper form when the pass is not split (profiles/r06_overlap.md)
   if (c->mode == 0) return comm_exchange(c, W, c->buf.send, c->buf.recv, c->ctx->n_halo_send, c->ctx->n_halo_ghost, c->ctx->stream);
