@@ -31,4 +31,6 @@ rocprofv3 --kernel-trace --stats -d /tmp/profb -o bench -- python $R/bench.py --
 python $R/tools/rocpd_stats.py /tmp/profb/bench_results.db 0.0 > $O/${TAG}_bench_rocprof_stats.md 2>/dev/null
 rm -rf /tmp/profb
 $R/tools/micro/prio_probe f > $O/${TAG}_prio_probe.txt 2>&1
-cd $R && timeout 1200 python -m pytest tests -m gpu -q > $O/${TAG}_gputests.log 2>&1
+cd $R && timeout 1500 python -m pytest tests -m gpu -q > $O/${TAG}_gputests.log 2>&1
+# the live-state parity numbers themselves (flip candidates, quantiles, slabs against one context)
+timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_slab_live.py tests/test_gpu_slab_c4.py -m gpu -q -s -k "live or perturbed" 2>&1 | grep -i "live\|step \|slabs vs\|vs callbacks\|passed\|failed\|flip" > $O/${TAG}_live_parity.log

@@ -34,7 +34,6 @@ struct wcsph_ctx {
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false, bk_rows_valid = false;
-  int *part_flags = nullptr;      // [nblk8(capacity)] per block of sorted rows: interior / rest present (api_slab.h k_part_flags)
   NativeComm *comm = nullptr;     // the native RCCL data plane of a slab decomposition (wcsph_comm_init), or none
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers

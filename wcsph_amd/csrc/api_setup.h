@@ -75,7 +75,6 @@ int wcsph_create(const wcsph_params *p, wcsph_ctx **out) {
   size_t stage_n = (nl + d.ns) * 3 > nl * 9 ? (nl + d.ns) * 3 : nl * 9;
   DALLOC(ctx->stage, stage_n);
   DALLOC(ctx->pred_dev, 4); DALLOC(ctx->dt_dev, 2);
-  DALLOC(ctx->part_flags, (size_t)nblk8(ctx->capacity) + 8);
   HIPCHK(hipMemsetAsync(ctx->pred_dev, 0, 4 * sizeof(int), ctx->stream));
   static_assert(MAIL_RING * sizeof(HostMail) <= 8 * ACC_STRIPES * sizeof(double), "mail ring fits the pinned buffer");
   HIPCHK(hipHostMalloc((void **)&ctx->h_acc_raw, 8 * ACC_STRIPES * sizeof(double)));

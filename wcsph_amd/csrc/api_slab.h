@@ -251,20 +251,8 @@ __global__ void k_ghost_records(Dev d, float dt) {
   d.pk[i] = make_float4(p.x, p.y, p.z, 0.5f * fmaxf(d.kappa_v[i] / dt, -0.5f * d.rho_L0 * d.rho_L0));
   d.pr[i] = make_float4(p.x, p.y, p.z, 0.f);
 }
-// which blocks of BLOCK consecutive sorted rows hold owned particles of the slab interior (bit 0) / of the rest (bit 1), for the
-// split launches of the halo / compute overlap (PART_GATE): d.part_x0 / part_x1 are set, the test is part_ok's
-__global__ void __launch_bounds__(BLOCK) k_part_flags(Dev d, int *flags) {
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
-  bool in = false, out = false;
-  if (i < d.nl && owned(d, i)) {
-    Dev e = d; e.part_mode = 1;
-    in = part_ok(e, d.pos[i]); out = !in;
-  }
-  const int a = __syncthreads_or(in), b = __syncthreads_or(out);
-  if (threadIdx.x == 0) flags[blockIdx.x] = (a ? 1 : 0) | (b ? 2 : 0);
-}
 namespace {
-struct PartGuard { Dev &d; ~PartGuard() { d.part_flags = nullptr; d.part_mode = 0; } };
+struct PartGuard { Dev &d; ~PartGuard() { d.part_mode = 0; } };
 struct SlabRun {
   wcsph_ctx *ctx;
   const wcsph_slab_callbacks *cb;
@@ -406,16 +394,13 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   if (R.overlap) {
     // The interior is taken to whole TILES of the cell order along x (4 columns when x is the middle axis, 2 when it is the outer
     // one; device.h cell_lin): 64 consecutive sorted particles are then all interior or all rest except where a run of tiles ends,
-    // so a split launch does not run its waves half empty -- measured on the 32 x 252 x 252 ring (profiles/r06_overlap.md): with
-    // the cut columns themselves as the boundary set the two launches of a pass cost 1.16 x the whole pass, 0.27 ms per step.
-    // Rounding inwards keeps every interior particle at least two columns from a ghost.
+    // so a split launch does not run its waves half empty (measured on the 32 x 252 x 252 ring, profiles/r06_overlap.md).  Rounding
+    // inwards keeps every interior particle at least two columns from a ghost.  (Also measured, and taken out again: a per-block
+    // flag word that lets a workgroup without work leave on one scalar load -- it saved 35 us per split step and cost the
+    // UNsplit developed step 40 us: the early exit in the passes' prologue perturbs their code, k_drho_div_iter_vort +8 %.)
     const int T = d.perm ? (1 << T1B) : (1 << T0B);
     if (R.ilo > d.x0) R.ilo = d.x0 + ((R.ilo - d.x0 + T - 1) / T) * T;
     if (R.ihi < d.x0 + d.nx) R.ihi = d.x0 + ((R.ihi - d.x0) / T) * T;
-    d.part_x0 = R.ilo; d.part_x1 = R.ihi > R.ilo ? R.ihi : R.ilo;
-    hipLaunchKernelGGL(k_part_flags, dim3(nblk8(d.nl)), dim3(BLOCK), 0, ctx->stream, d, ctx->part_flags);
-    LAUNCHCHK();
-    d.part_flags = ctx->part_flags;
   }
   // ---- compute_density(); compute_dfsph_coff(); and the first pass of solve_vel_divergence() (dfsph.py:131-146): they read
   // pos_j / vel_j only, which the ghost rows brought with them

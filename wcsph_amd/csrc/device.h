@@ -27,9 +27,6 @@ struct Dev {
   // slab halo/compute overlap: 0 = every owned particle; 1 = only those in global cell columns [part_x0, part_x1)
   // (the interior: no ghost within their 5^3 cells); 2 = only the others (see part_ok)
   int part_mode, part_x0, part_x1;
-  // ... and per block of BLOCK consecutive sorted rows: bit 0 = holds an owned interior particle, bit 1 = an owned particle of
-  // the rest (k_part_flags, once per slab step): a workgroup of a split launch that has nothing to do leaves on one scalar load
-  const int *part_flags;
   // traversal direction of this launch (sorted_index): consecutive neighbour passes alternate, so that a pass starts on
   // the data the previous one touched last -- the part of it that is still in the 256 MB Infinity Cache
   int rev;
@@ -217,15 +214,13 @@ __device__ __forceinline__ bool part_ok(const Dev &d, float4 pi) {
 // dispatch"); give every XCD one CONTIGUOUS eighth of the cell-sorted particle range so that its
 // private L2 holds one spatial region instead of a 1/8 sample of all of them.  gridDim.x is a
 // multiple of 8 by construction (grid_for()).
-__device__ __forceinline__ int sorted_block(const Dev &d) {
+__device__ __forceinline__ int sorted_index(const Dev &d) {
   const int per = gridDim.x >> 3;
   int q = blockIdx.x >> 3;
   if (d.rev) q = per - 1 - q;   // every XCD walks its eighth backwards
-  return (blockIdx.x & 7) * per + q;
+  const int blk = (blockIdx.x & 7) * per + q;
+  return blk * BLOCK + threadIdx.x;
 }
-__device__ __forceinline__ int sorted_index(const Dev &d) { return sorted_block(d) * BLOCK + threadIdx.x; }
-// first statement (behind PRED_GATE) of a neighbour pass that may be launched on a part of the slab: block-uniform
-#define PART_GATE(d) do { if ((d).part_mode != 0 && (d).part_flags && !(((d).part_flags[sorted_block(d)] >> ((d).part_mode - 1)) & 1)) return; } while (0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -11,7 +11,6 @@
 // not displace it.  The (pos, k) record of the divergence iteration that also takes the vorticity sums likewise: in three
 // steps of four it is the LAST iteration and nobody reads the record.
 #define LOAD_I                                        \
-  PART_GATE(d);                                       \
   const int i = sorted_index(d);                       \
   const bool live = i < d.nl;                         \
   const float4 pi = live ? d.pos[i] : make_float4(0, 0, 0, __int_as_float(-1)); \
@@ -19,7 +18,6 @@
 // for the walks that gather the (pos, rho) records: the particle's own position comes from its record too (pi.w = rho_i
 // then) unless a slab decomposition needs the packed cell in pos.w -- 32 MB less read, and kept out of the cache, per pass
 #define LOAD_I_PR                                     \
-  PART_GATE(d);                                       \
   const int i = sorted_index(d);                       \
   const bool live = i < d.nl;                         \
   const bool whole = d.part_mode == 0;                \
@@ -199,7 +197,6 @@ __global__ void __launch_bounds__(BLOCK) WAVES6 k_drho_press(Dev d, float dt) {
   PRED_GATE(d);
   DT_OVERRIDE(d, dt);
   constexpr bool REC = FUSEK && MODE == DRHO_ITER;
-  PART_GATE(d);
   const int i = sorted_index(d);
   const bool live = i < d.nl;
   const float4 pi = live ? (REC ? d.pk[i] : d.pos[i]) : make_float4(0, 0, 0, __int_as_float(-1));
@@ -263,7 +260,6 @@ __global__ void __launch_bounds__(BLOCK) k_vel_from_k(Dev d, const float4 *pk, f
   if (kap) acc_clear(ACC_SLOT(d, ACC_ERR));   // fused solver loops: the density-change pass launched next sums into it
   // The pass is HBM-bound on its own inputs: the particle's position comes with its (pos, k) record, and
   // pos[i] / oid[i] are read only where ownership is not trivial (slab decomposition) -- 40 B per particle less.
-  PART_GATE(d);
   const int i = sorted_index(d);
   if (i >= d.nl) return;
   if (d.n_owned < d.nl || d.part_mode != 0) {
