@@ -436,6 +436,12 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
  *        left, or appended); then the n_ghost ghost rows become original rows n_owned_new ... (replacing the old ghosts).  The
  *        arrays then have holes; the next grid update (wcsph_slab_step) drops them -- nothing else may run in between.
  * (all index arrays int64 on the device, as wcsph_slab_classify returns them) */
+/* (round 6) the same classification taken in the TAIL of wcsph_slab_step, on the positions the step has just written: register the
+ * parameters and buffers of wcsph_state_classify once (d_idx == NULL: off); when a step ends on its speculative path -- the common
+ * case -- the counts travel with its last mail, and wcsph_slab_tail_classify_result returns them (WCSPH_OK, consumed) without a
+ * host wait of its own; 1 = none available (the caller runs wcsph_state_classify as before) */
+int wcsph_slab_set_tail_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts);
+int wcsph_slab_tail_classify_result(wcsph_ctx *ctx, int32_t counts[5]);
 int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts);
 int wcsph_state_gather_rows(wcsph_ctx *ctx, const int64_t *d_idx, int32_t n, float *d_rows);
 int wcsph_state_apply(wcsph_ctx *ctx, int32_t n_owned_new, const int64_t *d_fold_dst, const int64_t *d_fold_src, int32_t n_fold,

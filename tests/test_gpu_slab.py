@@ -219,6 +219,37 @@ def test_speculative_slab_step_changes_nothing_and_hides_the_decisions(tmp_path,
     print("host waits per step: speculative %.2f, plain %.2f; exchanges per step %.1f / %.1f" % (w_spec[0] / steps, w_plain[0] / steps, w_spec[1] / steps, w_plain[1] / steps))
 
 
+def test_tail_classification_saves_a_host_wait_and_changes_nothing(tmp_path):
+    """(round 6) The classification of the next step's migration / ghost rebuild is taken in the TAIL of wcsph_slab_step, behind
+    the step's last gate, and its counts travel with one more mail queued right behind the last one: where a step ends on its
+    speculative path the driver finds them on the host (wcsph_slab_tail_classify_result) instead of waiting for a launch of its
+    own.  Three ranks, rows crossing both cuts: against WCSPH_SLAB_TAIL_CLASSIFY=0 the same rows, iteration counts and dt, and
+    fewer host waits."""
+    import slab_util
+    from test_slab_gloo import _free_port
+    n, outs = 12, []
+    try:
+        for tail in ("1", "0"):
+            out = os.path.join(str(tmp_path), "tail" + tail)
+            os.makedirs(out)
+            os.environ["WCSPH_SLAB_TAIL_CLASSIFY"] = tail
+            mp.spawn(_hip_run, args=(3, _free_port(), out, n), nprocs=3, join=True)
+            outs.append(out)
+    finally:
+        os.environ.pop("WCSPH_SLAB_TAIL_CLASSIFY", None)
+    rows = [np.concatenate([np.load(os.path.join(o, "hrows_w3_r%d.npy" % r)) for r in range(3)]) for o in outs]
+    logs = [np.load(os.path.join(o, "hlog_w3_r1.npy")) for o in outs]
+    np.testing.assert_array_equal(logs[0][:, :3], logs[1][:, :3])
+    np.testing.assert_allclose(logs[0][:, 3], logs[1][:, 3], rtol=1e-7)
+    assert logs[0][0, 4] != logs[0][-1, 4]                      # the middle rank's ownership changed: rows migrated
+    dpos, dvel, _ = slab_util.match_rows(rows[0], rows[1])
+    assert dpos < 1e-6 and dvel < 1e-4
+    w_on, w_off = (np.load(os.path.join(o, "hwaits_w3_r1.npy")) for o in outs)
+    steps = float(w_on[2])
+    print("host waits per step (rank 1 of 3): tail classification %.2f, without %.2f" % (w_on[0] / steps, w_off[0] / steps))
+    assert w_on[0] / steps <= w_off[0] / steps - 0.5          # (every step that ends on its speculative path saves one)
+
+
 def test_native_classifier_equals_the_torch_classification():
     """wcsph_slab_classify (one launch) against the torch form of SlabSim.redistribute: the same four row sets and the same
     five counts, cell columns formed as the grid update forms them (ref: HashGrid.py:68), including rows exactly on a cut"""

@@ -34,6 +34,10 @@ struct wcsph_ctx {
   bool hist_dirty = false;        // a grid update began and did not reach the kernels that zero bcount_l / region_occ
   BucketTab bk = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the reference's hash table itself (bucket.h), built on demand
   bool bk_valid = false, bk_rows_valid = false;
+  // the classification of the NEXT step's migration / ghost rebuild, taken in the tail of wcsph_slab_step (api_slab.h): its counts
+  // reach the host with the step's last mail instead of costing a host wait of their own
+  struct TailClassify { bool on = false, valid = false; int lo = 0, hi = 0, ghost = 0, has_l = 0, has_r = 0, cap = 0;
+                        long long *d_idx = nullptr; int *d_counts = nullptr; int *h_counts = nullptr; } tc;
   NativeComm *comm = nullptr;     // the native RCCL data plane of a slab decomposition (wcsph_comm_init), or none
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers

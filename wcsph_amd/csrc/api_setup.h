@@ -90,6 +90,7 @@ int wcsph_destroy(wcsph_ctx *ctx) {
   wcsph_comm_destroy(ctx);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
+  if (ctx->tc.h_counts) hipHostFree(ctx->tc.h_counts);
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   for (hipEvent_t e : ctx->lap_ev) hipEventDestroy(e);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);

@@ -59,6 +59,45 @@ int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, 
   LAUNCHCHK();
   return WCSPH_OK;
 }
+}  // extern "C"
+__global__ void k_counts_to_host(const int *c, int *h, const int *pred) {
+  if (pred && *pred == 0) return;
+  if (threadIdx.x < 5) h[threadIdx.x] = c[threadIdx.x];
+}
+// wcsph_state_classify in the tail of wcsph_slab_step, gated like the launches around it; the counts go to pinned host memory
+// in front of the mail that follows
+static int tail_classify(wcsph_ctx *ctx, const int *pred) {
+  auto &t = ctx->tc;
+  HIPCHK(hipMemsetAsync(t.d_counts, 0, 5 * sizeof(int32_t), ctx->stream));
+  const long long n = ctx->d.n_owned;
+  if (n > 0)
+    hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)ctx->d.pos, n, 4,
+                       ctx->d.minx, ctx->d.inv_grid, t.lo, t.hi, t.ghost, t.has_l, t.has_r, t.d_idx, t.cap, t.d_counts, (const int *)ctx->d.where, pred);
+  hipLaunchKernelGGL(k_counts_to_host, dim3(1), dim3(WAVE), 0, ctx->stream, (const int *)t.d_counts, t.h_counts, pred);
+  LAUNCHCHK();
+  return 0;
+}
+extern "C" {
+int wcsph_slab_set_tail_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts) {
+  NEED_SETUP();
+  auto &t = ctx->tc;
+  t.valid = false;
+  if (!d_idx || !d_counts || cap <= 0) { t.on = false; return WCSPH_OK; }
+  if (!t.h_counts) { HIPCHK(hipHostMalloc((void **)&t.h_counts, 8 * sizeof(int))); memset(t.h_counts, 0, 8 * sizeof(int)); }
+  t.lo = lo; t.hi = hi; t.ghost = ghost; t.has_l = has_left; t.has_r = has_right; t.d_idx = (long long *)d_idx; t.cap = cap; t.d_counts = d_counts;
+  t.on = true;
+  return WCSPH_OK;
+}
+// WCSPH_OK: counts[5] = the result of the classification taken in the last wcsph_slab_step's tail (consumed by this call; the
+// index lists are in the registered buffer); 1: none available (the step ended on its plain path): call wcsph_state_classify
+int wcsph_slab_tail_classify_result(wcsph_ctx *ctx, int32_t counts[5]) {
+  NEED_SETUP();
+  if (!counts) return WCSPH_EARG;
+  if (!ctx->tc.on || !ctx->tc.valid || ctx->nl_phys > 0) return 1;
+  for (int k = 0; k < 5; k++) counts[k] = ctx->tc.h_counts[k];
+  ctx->tc.valid = false;
+  return WCSPH_OK;
+}
 int wcsph_state_gather_rows(wcsph_ctx *ctx, const int64_t *d_idx, int32_t n, float *d_rows) {
   NEED_SETUP();
   if (n < 0 || (n > 0 && (!d_idx || !d_rows))) return WCSPH_EARG;
@@ -362,6 +401,7 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   Dev &d = ctx->d;
   int rc;
   d.pred = nullptr; d.dtp = nullptr;
+  ctx->tc.valid = false;
   PartGuard part_guard{d};
   const double N = (double)n_global;
   const bool tension = (flags & 2) && !(d.tension == 0.0f && d.tension_b == 0.0f);
@@ -554,6 +594,14 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
       d.pred = pD; d.dtp = ctx->dt_dev;
       ELEM(k_end_press_update_pos, dt);
       d.pred = nullptr; d.dtp = nullptr;
+      // the next step's migration / ghost classification on the positions just written, behind the same gate, and one more mail
+      // (E) behind it: when the step ends here -- the common case -- its counts are on the host without a wait of their own
+      unsigned long long seqE = 0;
+      if (ctx->tc.on && R.multi) {
+        SRC(tail_classify(ctx, pD));
+        SRC(publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pD}));
+        seqE = ctx->mail_seq;
+      }
       SRC(collect_mail(ctx, true, seqB));
       ctx->cg_delta_zero = (float)ctx->h_acc[ACC_DZERO];
       ctx->cg_delta_old = ctx->cg_delta_zero;
@@ -574,7 +622,16 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
         err = (double)ctx->avg_density_err / N;
         ctx->pr_iter = 2;
         stage = ctx->h_pred ? ST_END : ST_PRESS;             // ST_PRESS: go on from iteration 3
-        if (stage == ST_END) { if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; } return WCSPH_OK; }
+        if (stage == ST_END) {
+          if (seqE) {   // (queued right behind D: it has arrived, or is about to -- the GPU is not idle meanwhile)
+            const float err_keep = ctx->avg_density_err;
+            SRC(collect_mail(ctx, true, seqE));
+            ctx->avg_density_err = err_keep;
+            ctx->tc.valid = true;
+          }
+          if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; }
+          return WCSPH_OK;
+        }
       } else { ctx->prof_used = prof_mark; stage = ST_VISC; R.n_wait++; }   // the PCG goes on; everything behind B did nothing
     } else { stage = ST_DIV; R.n_wait++; }                   // the divergence solve goes on; everything behind A did nothing
   }

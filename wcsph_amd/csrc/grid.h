@@ -829,7 +829,9 @@ __global__ void k_permute1(float *f, const int *where, int n, const float *in) {
 constexpr int CLS_ROWS = 16;
 // where != nullptr: the rows are the context's own (x of original row i = rows[where[i] * W])
 __global__ void __launch_bounds__(BLOCK) k_slab_classify(const float *rows, long long n, int W, float minx, float inv_grid, int lo, int hi, int ghost,
-                                                         int has_l, int has_r, long long *idx, int cap, int *counts, const int *where = nullptr) {
+                                                         int has_l, int has_r, long long *idx, int cap, int *counts, const int *where = nullptr,
+                                                         const int *pred = nullptr) {   // pred: as Dev::pred (the slab step's speculative tail)
+  if (pred && *pred == 0) return;
   __shared__ int cnt[5], base[5];
   if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
   __syncthreads();

@@ -125,15 +125,34 @@ class HipBackend:
     # ---- state resident in the library between steps (include/wcsph.h "slab state resident in the library") -------------
     def classify_state(self, lo, hi, ghost, has_l, has_r):
         """classify_rows over the context's OWN owned rows (no row table in the driver): counts + four int64 lists of
-        original indices, one launch and one host wait; None when a list did not fit its buffer"""
+        original indices; None when a list did not fit its buffer.  One launch and one host wait -- or neither (round 6): the
+        library takes the same classification in the tail of wcsph_slab_step and its counts arrive with the step's last mail
+        (`self.classify_waited` says which it was)."""
         n = int(self.n_owned)
         cap = max(65536, n // 8)
         if getattr(self, "_cls_idx", None) is None or self._cls_idx.shape[1] < cap:
             self._cls_idx = torch.empty((4, cap), dtype=torch.int64, device=self.device)
             self._cls_cnt = torch.empty(5, dtype=torch.int32, device=self.device)
-        self._chk(self.lib.wcsph_state_classify(self.ctx, int(lo), int(hi), int(ghost), int(has_l), int(has_r),
-                                                C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.c_void_p(self._cls_cnt.data_ptr())))
-        c = self._cls_cnt.tolist()
+            self._tc_key = None
+        key = (int(lo), int(hi), int(ghost), int(has_l), int(has_r), int(self._cls_idx.shape[1]), self._cls_idx.data_ptr())
+        c = None
+        if os.environ.get("WCSPH_SLAB_TAIL_CLASSIFY", "1") != "0":
+            if getattr(self, "_tc_key", None) != key:       # (re)register: the next step's tail classifies with these parameters
+                self._chk(self.lib.wcsph_slab_set_tail_classify(self.ctx, key[0], key[1], key[2], key[3], key[4], C.c_void_p(self._cls_idx.data_ptr()), key[5],
+                                                                C.c_void_p(self._cls_cnt.data_ptr())))
+                self._tc_key = key
+            else:
+                got = (C.c_int32 * 5)()
+                rc = self.lib.wcsph_slab_tail_classify_result(self.ctx, C.byref(got))
+                if rc < 0:
+                    self._chk(rc)
+                if rc == 0:
+                    c = list(got)
+        self.classify_waited = c is None
+        if c is None:
+            self._chk(self.lib.wcsph_state_classify(self.ctx, int(lo), int(hi), int(ghost), int(has_l), int(has_r),
+                                                    C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.c_void_p(self._cls_cnt.data_ptr())))
+            c = self._cls_cnt.tolist()
         if max(c[:4]) > self._cls_idx.shape[1]:
             return None
         return c, [self._cls_idx[k, :c[k]] for k in range(4)]
@@ -936,7 +955,7 @@ class SlabSim:
         n = int(self.n_owned)
         has_l, has_r = self.rank > 0, self.rank < self.world - 1
         native = B.classify_state(self.lo, self.hi, G, has_l, has_r)
-        self.n_host_waits += 1
+        self.n_host_waits += 1 if getattr(B, "classify_waited", True) else 0
         if native is None:                                   # a list overflowed its buffer: the classic path on a materialised table
             _ = self.rows
             return self.redistribute()
