@@ -241,7 +241,8 @@ def test_tail_classification_saves_a_host_wait_and_changes_nothing(tmp_path):
     logs = [np.load(os.path.join(o, "hlog_w3_r1.npy")) for o in outs]
     np.testing.assert_array_equal(logs[0][:, :3], logs[1][:, :3])
     np.testing.assert_allclose(logs[0][:, 3], logs[1][:, 3], rtol=1e-7)
-    assert logs[0][0, 4] != logs[0][-1, 4]                      # the middle rank's ownership changed: rows migrated
+    own = [np.load(os.path.join(outs[0], "hlog_w3_r%d.npy" % r))[:, 4] for r in range(3)]
+    assert sum(o[0] != o[-1] for o in own) >= 2               # rows migrated: at least two ranks gained or lost some
     dpos, dvel, _ = slab_util.match_rows(rows[0], rows[1])
     assert dpos < 1e-6 and dvel < 1e-4
     w_on, w_off = (np.load(os.path.join(o, "hwaits_w3_r1.npy")) for o in outs)

@@ -23,6 +23,11 @@ KINDS = [
     (r"gather_model|list_balance|stress_lists|wall_density|developed_parity|ablation", "model / diagnostic output"),
     (r"c5", "config C5 (tension on) kernel statistics"),
     (r"tile", "LDS tile walk experiment (round 5)"),
+    (r"r06_(overlap|cluster_pair|developed)\.md$", "round-6 write-up (what was built, measured, concluded)"),
+    (r"overlap|ring_gaps|ring", "halo / compute overlap on the loop-back ring of C4's per-rank shape (`tools/overlap_ring.py`, `rocpd_overlap.py`, `rocpd_ring_steps.py`)"),
+    (r"prio_probe", "micro-benchmark (`tools/micro/*`) or GPU-idle analysis"),
+    (r"cpair", "cluster-pair walk experiment (round 6): PMC passes"),
+    (r"live_parity", "live-state parity numbers (`pytest -s`: flip candidates, quantiles, slabs against one context)"),
 ]
 
 
