@@ -103,3 +103,61 @@ def test_max_of_bit_patterns_is_the_max_of_non_negative_floats():
         pick = rng.choice(v, size=8)
         bits = pick.view(np.int32)
         assert np.array([bits.max()], np.int32).view(np.float32)[0] == pick.max()
+
+
+def test_oracle_flip_candidate_diagnostic_is_consistent_with_update_drho_divergence():
+    """orc_diag_drho_divergence (test infrastructure behind the live-state parity tests, tests/test_gpu_configs.py): S is the
+    un-clamped sum of update_drho_divergence (dfsph.py:374-392), so max(S, 0) must be the oracle's own adv_rho wherever the raw
+    list length passes the `< 20` test of dfsph.py:391, A >= |S|, and a velocity field without relative motion has S = 0 exactly
+    for a particle with liquid neighbours only."""
+    import numpy as np
+    from oracle import Oracle
+    from wcsph_amd import scene
+    liquid, solid = scene.dam_break_dfsph(8)
+    pos = np.concatenate([liquid, solid]).astype(np.float32)
+    o = Oracle(pos, len(liquid), 0.025, mode="clean")
+    o.reset_param()
+    rng = np.random.default_rng(5)
+    o.vel[...] = rng.normal(size=o.vel.shape).astype(np.float32)
+    o.update_grid()
+    S, A, G = o.diag_drho_divergence()
+    o.update_drho_divergence()
+    full = np.asarray(o.neighborCount) >= 20
+    assert full.sum() > 50
+    np.testing.assert_allclose(np.maximum(S[full], 0.0), o.adv_rho[full], rtol=2e-5, atol=2e-5)
+    assert (o.adv_rho[~full] == 0).all() and (A >= np.abs(S) - 1e-9).all() and (G > 0).any()
+    o.vel[...] = np.float32(1.5)                       # rigid translation: (v_i - v_j) = 0 for every liquid pair
+    S2, A2, _ = o.diag_drho_divergence()
+    interior = np.ones(len(liquid), bool)
+    nb = np.asarray(o.neighbor)[:, :int(np.asarray(o.neighborCount).max())]
+    cnt = np.asarray(o.neighborCount)
+    has_solid = np.array([(nb[i, :cnt[i]] >= len(liquid)).any() for i in range(len(liquid))])
+    assert (~has_solid).sum() > 10 and (S2[~has_solid] == 0).all() and (A2[~has_solid] == 0).all()
+    o.close()
+
+
+def test_bench_lap_groups_cover_every_tag_of_the_fused_step():
+    """bench.py's per-group breakdown (config.*.breakdown): every lap tag the library can emit (PASS / ELEM kernel names, the
+    grid update's stages, the two solver-iteration scopes, the step boundary) lands in a named group"""
+    import bench
+    tags = {"grid:cells": "grid_update", "grid:scan+sort": "grid_update", "grid:neighborCount": "grid_update", "k_build_lists": "build_lists",
+            "k_density_coff_warm": "density_coff", "k_vel_from_k<1>": "divergence_open", "(k_drho_div<DRHO_BEGIN, true>)": "divergence_open",
+            "divergence_iter": "divergence_iter", "pressure_iter": "pressure_iter", "(k_drho_press<DRHO_BEGIN, true>)": "pressure_open",
+            "k_warm_press_vel_flagged": "pressure_open", "k_visc_minv_residual": "visc_iter", "k_visc_minv_residual_vort": "visc_iter",
+            "k_visc_Ad": "visc_iter", "k_visc_update": "visc_iter", "k_visc_dir": "visc_iter", "k_end_div_begin_nonpressure": "elementwise",
+            "k_finish_nonpressure": "elementwise", "k_update_vel_warm_scale": "elementwise", "k_end_press_update_pos": "elementwise",
+            "step_boundary": "step_boundary"}
+    for tag, group in tags.items():
+        assert bench.lap_group(tag) == group, (tag, bench.lap_group(tag))
+
+
+def test_fd_level_stdout_redirect_keeps_the_json_channel_clean(capfd):
+    """bench.py prints ONE JSON line: what C++ layers write to file descriptor 1 while a process group is set up (gloo's
+    connection lines, RCCL's banner) must land on stderr"""
+    import os
+    from wcsph_amd.slab import _fd_stdout_to_stderr
+    with _fd_stdout_to_stderr():
+        os.write(1, b"[Gloo] Rank 0 is connected to 1 peer ranks\\n")
+    os.write(1, b"{}\\n")
+    out, err = capfd.readouterr()
+    assert out == "{}\\n" and "Gloo" in err
