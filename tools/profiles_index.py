@@ -46,16 +46,18 @@ round ran on (or nearest to) its final source.  Boxes of the pool differ by +-3 
 libraries within ONE `gpurun` call.  C3 = 126^3 = 2 000 376 liquid + 1 008 602 boundary particles, faithful mode, unless a file
 says otherwise.  (Regenerate with `python tools/profiles_index.py`.)
 
-## Read first (round 5)
+## Read first (round 6)
 
 | file | what it shows |
 |---|---|
-| `r05_lds_tile_experiment.md` (+ `r05_tile_*`, `r05_pmc_build_lists.txt`, `r05_ab_flat_list_build.txt`) | (1) the LDS design VERDICT r04 asked for -- compact tiles, LDS-DMA staging, 16-bit LDS-slot lists -- built bit-exact and measured with counters: 191 vs 135 us at rest, 417 vs 326 us developed; where it loses.  (2) the list build in the developed flow: divergence-bound (34 of 64 lanes active), a flattened candidate loop built and 26-32 % slower |
-| `r05z_bench_20_5.json`, `r05z_bench_default.json`, `r05z_rest_kernel_stats.md`, `r05z_dev_kernel_stats.md`, `r05z_bench_rocprof_stats.md`, `r05z_pmc_*` | the campaign on the final source (`tools/campaign_r05.sh`): 1237-1248 M particle-steps/s (1.60-1.62 ms/step), 1018-1021 M over the default window, 607-610 M developed; DESIGN 4's table is generated from the ONE kernel trace here |
-| `r05_slab_overhead.txt`, `r05z_slab_overhead.txt`, `r05z_slab_nccl_world1.json` | slab driver on one GPU: +0.115 ms over the fused step (state store 0.052 + load 0.047) -> **+0.013 ... 0.018 ms** with the state resident in the library; the communicator called at every exchange point (Python callbacks or the native RCCL plane) adds 0.00-0.04 ms; the bench path on the real RCCL backend with one rank and the native data plane: 1184-1191 M |
-| `r05_c5.md` (+ `r05_c5_*_kernel_stats.md`) | C5 literal / repaired tension legs on the final source |
-| `r05z_gputests.log` | `pytest -m gpu` on the final source: 130 passed, 1 skipped |
-| `r04_experiments.md`, `r03_experiments.md`, `r02b_wave_brick_experiment.md` | every earlier measured-and-rejected idea with its counters (the stop list of VERDICT r04 comes from these) |
+| `r06_cluster_pair.md` (+ `r06_pmc_cpair.txt`) | the list-free cluster-pair walk VERDICT r05 asked for -- clusters of 4 / 2 consecutive sorted particles, j-windows, DPP sums -- built equal to rounding and measured with counters: 132 vs 86 us at rest, 256 vs 204 us developed (gate: 155); where it loses |
+| `r06_overlap.md` (+ `r06z_overlap.md`, `r06z_overlap_ring.json`, `r06z_ring_gaps_*.txt`, `r06z_overlap_*_kernel_stats.md`, `r06z_prio_probe.txt`) | halo refreshes of the native RCCL plane on their own stream: kernel trace of a loop-back ring of C4's per-rank shape (95 % of the RCCL time inside a compute kernel), the price list (split +253 us, event hop 12 us, RCCL launch 16 us, RCCL's kernel beside a saturating grid), every schedule timed, why the choice is measured at run time |
+| `r06_developed.md` (+ `r06z_bench_20_5.json`: `config.developed_flow.breakdown / window_2 / state`) | the developed-flow leg made explainable: two windows, per-group in-situ breakdown (lap events), state facts; what can and cannot explain round 5's 553 M |
+| `r06z_bench_20_5.json`, `r06z_bench_default.json`, `r06z_rest_kernel_stats.md`, `r06z_dev_kernel_stats.md`, `r06z_bench_rocprof_stats.md`, `r06z_pmc_*` | the campaign on the final source (`tools/campaign_r06.sh`): 1254 M particle-steps/s (1.595 ms/step), 1016-1021 M over the default window, 605 M developed; `pressure_iter` 136.6 us = 0.176 |
+| `r06z_slab_overhead.txt`, `r06z_slab_nccl_world1.json`, `r06z_bench_two_ranks_one_gpu_gloo.json` | slab driver on one GPU: +0.010 ... 0.014 ms (clean) over the fused step on either plane; the bench path on the real RCCL backend with one rank incl. the schedule tuning; two ranks on one GPU over gloo (2.2 host waits per step, stdout = the one JSON line) |
+| `r06z_live_parity.log`, `r06z_gputests.log` | the live-state parity numbers themselves (flip candidates, quantiles, 3 slabs and C4's 8 slabs against one context, native plane schedules against the callback plane); `pytest -m gpu` on the final source: 136 passed, 1 skipped |
+| `r06_compiler_sched_flags.txt` | seven LLVM scheduling strategies / biases on the whole library: none helps |
+| `r05_lds_tile_experiment.md`, `r04_experiments.md`, `r03_experiments.md`, `r02b_wave_brick_experiment.md` | every earlier measured-and-rejected idea with its counters |
 
 ## By round
 """
