@@ -125,9 +125,11 @@ static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_rec
   c->n_exchanges++;
   return 0;
 }
-// The halo stream has the HIGHEST priority the device offers: the few workgroups of a send / receive kernel must be placed as soon
-// as they are launched, not when the thousands of workgroups of the interior pass queued beside them drain (measured, round 6,
-// profiles/r06_overlap.md: at default priority the 16 us exchange stretched to the length of its companion pass, 65-187 us).
+// The halo stream has the HIGHEST priority the device offers: the few workgroups of a send / receive kernel should be placed as
+// soon as they are launched, not when the thousands of workgroups of the interior pass queued beside them drain.  (Measured, round
+// 6, profiles/r06_overlap.md: on one GPU RCCL's kernel stretches to the length of its companion pass at EITHER priority -- a plain
+// copy or a generic kernel of the same footprint does not --; the priority is kept because it is what a communication stream
+// should ask for, not because it was seen to help.)
 static hipError_t create_halo_stream(hipStream_t *s) {
   int lo = 0, hi = 0;
   hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // (numerically lowest = highest priority)
