@@ -195,3 +195,78 @@ def test_halo_schedule_tuning_picks_a_candidate_and_the_run_goes_on():
     torch.cuda.synchronize()
     assert sim.n_exchanges - x0 >= 9 and np.isfinite(sim.rows.cpu().numpy()).all()
     sim.B.close()
+
+
+def _periodic_ring(plane, n=(12, 14, 14), vx=4.0, mode="clean"):
+    """tools/ring_real.py in small: ONE slab that believes it is the middle rank of three, its neighbour exchange closed onto itself
+    with a shift of one period -- the REAL migration / ghost rebuild (SlabSim._redistribute_resident: tail classification, swap
+    plan, wcsph_state_apply) runs every step and rows really cross the seam"""
+    from wcsph_amd import scene
+    from wcsph_amd.slab import SlabSim, HipBackend, STATE_W
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    R = scene.PARTICLE_RADIUS
+    liquid = scene.dam_break_liquid(*n)
+    liquid = liquid + np.random.default_rng(3).uniform(-0.2, 0.2, liquid.shape) * R
+    L = max(n) * 2 * R
+    solid = scene.box_shell(L)
+    bounds = (np.array([-L, 0.0, -L], np.float32), np.array([L, 2 * L, L], np.float32))
+    cx = np.trunc((liquid[:, 0].astype(np.float32) - bounds[0][0]) * np.float32(1.0 / (2 * R))).astype(np.int64)
+    lo, hi = int(cx.min()), int(cx.max()) + 1
+    sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, [lo, hi], len(liquid), 0, 1, device=dev, neighbor_mode=mode)
+    period, nl = np.float32((hi - lo) * 2 * R), len(liquid)
+    if plane.startswith("native"):
+        sim.enable_native_comm(neighbours=(0, 0))
+        sim.B.comm_set_mode(int(plane[-1]))
+    sim.rank, sim.world = 1, 3
+    sim.loopback, sim.force_comm = True, True
+    sim.interior = (lo + G, hi - G)
+    sim.set_overlap(plane != "native0")
+    sim._allreduce_tensor = lambda t, op=None: None
+    sim._allreduce = lambda v, op: v
+    sim.migrated = 0
+
+    def exchange_var(to_left, to_right, head_l=(), head_r=()):
+        sim.n_host_waits += 1
+        from_left, from_right = to_right.clone(), to_left.clone()
+        from_left[:, 0] -= float(period); from_right[:, 0] += float(period)
+        a_l, a_r = int(head_r[0]), int(head_l[0])
+        ng_l, ng_r = from_left.shape[0] - a_l, from_right.shape[0] - a_r
+        gid = torch.arange(nl, nl + ng_l + ng_r, dtype=torch.int32, device=dev)
+        from_left[a_l:, STATE_W - 1] = gid[:ng_l].view(torch.float32)
+        from_right[a_r:, STATE_W - 1] = gid[ng_l:].view(torch.float32)
+        sim.migrated += a_l + a_r
+        return from_left, from_right, list(head_r), list(head_l)
+    sim._exchange_var = exchange_var
+    sim.rows[:, 3] = vx
+    return sim, nl
+
+
+def test_rows_migrate_across_the_seam_of_a_periodic_ring_on_every_plane():
+    """The migration path itself under the native plane: a drifting block on a periodic ring of one slab, driven by the real
+    _redistribute_resident (rows cross the seam every step; the classification arrives with the step's last mail).  Every plane
+    keeps every particle exactly once, the planes agree, and the host waits per step are the last mail + the neighbours' counts."""
+    res = {}
+    for plane in ("callbacks", "native0", "native1", "native2"):
+        sim, nl = _periodic_ring(plane)
+        w0 = None
+        for k in range(8):
+            sim.step()
+            assert sim.n_owned == nl
+            if k == 1:
+                w0 = sim.n_host_waits
+        torch.cuda.synchronize()
+        rows = sim.rows.cpu().numpy()
+        gid = rows[:, 14].copy().view(np.int32)
+        np.testing.assert_array_equal(np.sort(gid), np.arange(nl))
+        res[plane] = (rows[np.argsort(gid)], sim.migrated, (sim.n_host_waits - w0) / 6.0)
+        sim.B.close()
+    ra, mig, waits = res["callbacks"]
+    assert mig > 50                                                    # rows did cross the seam
+    print("periodic ring: %d rows migrated in 8 steps, host waits per step %.2f" % (mig, waits))
+    assert waits <= 2.5
+    vscale = float(np.abs(ra[:, 3:6]).max())
+    for plane in ("native0", "native1", "native2"):
+        rb, mb, wb = res[plane]
+        assert mb == mig
+        assert np.abs(ra[:, :3] - rb[:, :3]).max() < 5e-7 and np.abs(ra[:, 3:6] - rb[:, 3:6]).max() < 5e-6 * vscale, plane
