@@ -439,13 +439,42 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
 /* (round 6) the same classification taken in the TAIL of wcsph_slab_step, on the positions the step has just written: register the
  * parameters and buffers of wcsph_state_classify once (d_idx == NULL: off); when a step ends on its speculative path -- the common
  * case -- the counts travel with its last mail, and wcsph_slab_tail_classify_result returns them (WCSPH_OK, consumed) without a
- * host wait of its own; 1 = none available (the caller runs wcsph_state_classify as before) */
+ * host wait of its own; 2 = the step ended on its plain path: the counts are returned after this call has waited for them;
+ * 1 = none available (the caller runs wcsph_state_classify as before) */
 int wcsph_slab_set_tail_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts);
 int wcsph_slab_tail_classify_result(wcsph_ctx *ctx, int32_t counts[5]);
 int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts);
 int wcsph_state_gather_rows(wcsph_ctx *ctx, const int64_t *d_idx, int32_t n, float *d_rows);
 int wcsph_state_apply(wcsph_ctx *ctx, int32_t n_owned_new, const int64_t *d_fold_dst, const int64_t *d_fold_src, int32_t n_fold,
                       const int64_t *d_write_idx, const float *d_write_rows, int32_t n_write, const float *d_ghost_rows, int32_t n_ghost);
+
+/* (round 6) the whole migration + ghost rebuild of a resident slab state inside the library (csrc/api_migrate.h; no reference
+ * counterpart, dfsph.py:606-617 is single-device).  counts[5] / d_idx: a classification of the present state, as
+ * wcsph_state_classify / the step's tail leave it (lists 0..3 = near_left, near_right, go_left, go_right; 4 lists of `cap` int64).
+ *   wcsph_slab_migrate_begin(ctx, d_idx, cap, counts, &d_to_left, &d_to_right): the rows that travel, gathered into the library's
+ *        own send buffer: to_left = [go_left | near_left] (counts[2] + counts[0] rows of STATE_W floats), to_right = [go_right | near_right]
+ *   wcsph_slab_migrate_end(ctx, d_from_left, n_from_left, a_left, d_from_right, n_from_right, a_right, out): what the neighbours
+ *        sent; the first a_left / a_right rows of a message change owner to this rank, the others are its new ghosts.  Computes the
+ *        swap plan on the device (arrivals into the slots of what left, the tail folded by a swap of labels), writes the rows,
+ *        builds the halo lists of the coming step in the library's own buffers and installs them (wcsph_slab_set_halo; on a
+ *        native communicator wcsph_comm_set_halo_split too).  out[5] = {n_owned_new, n_send_left, n_send_right, n_ghost_left,
+ *        n_ghost_right}.  Five launches, no host wait; as after wcsph_state_apply only a grid update / wcsph_slab_step may follow.
+ *   wcsph_slab_halo_lists(ctx, &d_send_idx, &n_send, &d_ghost_idx, &n_ghost): the installed lists (int32, device)
+ *   wcsph_slab_tail_neighbour_counts(ctx, left, right): native data plane: the slab neighbours' counts of the classification
+ *        taken in the last step's tail (exchanged by one grouped ncclSend / ncclRecv of five words behind it, mailed with it);
+ *        WCSPH_OK, or 1 = none available.  A missing neighbour's counts are zero.
+ *   wcsph_slab_migrate(ctx, d_idx, cap, counts, nbr_left, nbr_right, out): begin + ONE grouped ncclSend / ncclRecv of exact sizes
+ *        on the library's communicator + end; nothing on the host in between
+ *   wcsph_slab_migrate_set_seam(ctx, shift_left, shift_right, ghost_gid_base): a periodic seam (a ring of slabs): x of what
+ *        arrives from the left / right is shifted; ghost_gid_base >= 0 numbers the ghost copies from there (-1: keep their ids) */
+int wcsph_slab_migrate_begin(wcsph_ctx *ctx, const int64_t *d_idx, int32_t cap, const int32_t counts[5], void **d_to_left, void **d_to_right);
+int wcsph_slab_migrate_end(wcsph_ctx *ctx, const void *d_from_left, int32_t n_from_left, int32_t a_left,
+                           const void *d_from_right, int32_t n_from_right, int32_t a_right, int32_t out[5]);
+int wcsph_slab_halo_lists(wcsph_ctx *ctx, void **d_send_idx, int32_t *n_send, void **d_ghost_idx, int32_t *n_ghost);
+int wcsph_slab_tail_neighbour_counts(wcsph_ctx *ctx, int32_t left[5], int32_t right[5]);
+int wcsph_slab_migrate(wcsph_ctx *ctx, const int64_t *d_idx, int32_t cap, const int32_t counts[5], const int32_t nbr_left[5],
+                       const int32_t nbr_right[5], int32_t out[5]);
+int wcsph_slab_migrate_set_seam(wcsph_ctx *ctx, float shift_left, float shift_right, int32_t ghost_gid_base);
 
 /* ---- native data plane (wcsph_comm_init / wcsph_halo_exchange) -----------------------------------------
  * The library's own implementation of the communicator above on RCCL: grouped ncclSend / ncclRecv with the slab neighbours

@@ -197,7 +197,7 @@ def test_halo_schedule_tuning_picks_a_candidate_and_the_run_goes_on():
     sim.B.close()
 
 
-def _periodic_ring(plane, n=(12, 14, 14), vx=4.0, mode="clean"):
+def _periodic_ring(plane, n=(12, 14, 14), vx=4.0, mode="clean", library_migrate=True, native_migrate=True):
     """tools/ring_real.py in small: ONE slab that believes it is the middle rank of three, its neighbour exchange closed onto itself
     with a shift of one period -- the REAL migration / ghost rebuild (SlabSim._redistribute_resident: tail classification, swap
     plan, wcsph_state_apply) runs every step and rows really cross the seam"""
@@ -238,35 +238,47 @@ def _periodic_ring(plane, n=(12, 14, 14), vx=4.0, mode="clean"):
         sim.migrated += a_l + a_r
         return from_left, from_right, list(head_r), list(head_l)
     sim._exchange_var = exchange_var
+    sim.library_migrate, sim.native_migrate = library_migrate, native_migrate
+    # the same seam for the migration that runs inside the library over its own communicator (wcsph_slab_migrate)
+    sim.B._chk(sim.B.lib.wcsph_slab_migrate_set_seam(sim.B.ctx, -float(period), float(period), nl))
     sim.rows[:, 3] = vx
     return sim, nl
 
 
 def test_rows_migrate_across_the_seam_of_a_periodic_ring_on_every_plane():
-    """The migration path itself under the native plane: a drifting block on a periodic ring of one slab, driven by the real
-    _redistribute_resident (rows cross the seam every step; the classification arrives with the step's last mail).  Every plane
-    keeps every particle exactly once, the planes agree, and the host waits per step are the last mail + the neighbours' counts."""
+    """The migration path itself: a drifting block on a periodic ring of one slab, driven by the real _redistribute_resident (rows
+    cross the seam every step; the classification arrives with the step's last mail).  The torch form of the swap plan (rounds 5-6)
+    against the one inside the library (csrc/api_migrate.h) behind the caller's exchange, and against wcsph_slab_migrate on the
+    library's own communicator in every halo schedule: every variant keeps every particle exactly once, all agree, and on the native
+    plane -- the neighbours' counts travel with the step's last mail -- ONE host wait per step is left."""
     res = {}
-    for plane in ("callbacks", "native0", "native1", "native2"):
-        sim, nl = _periodic_ring(plane)
-        w0 = None
+    variants = {"torch plan": ("callbacks", False, True), "library plan": ("callbacks", True, True),
+                "native0": ("native0", True, True), "native1": ("native1", True, True), "native2": ("native2", True, True),
+                "native0, rows over the caller's exchange": ("native0", True, False)}
+    for label, (plane, lib_mig, nat_mig) in variants.items():
+        sim, nl = _periodic_ring(plane, library_migrate=lib_mig, native_migrate=nat_mig)
+        w0 = a0 = None
         for k in range(8):
             sim.step()
             assert sim.n_owned == nl
             if k == 1:
-                w0 = sim.n_host_waits
+                w0, a0 = sim.n_host_waits, sim.n_rows_arrived if lib_mig else sim.migrated
         torch.cuda.synchronize()
         rows = sim.rows.cpu().numpy()
         gid = rows[:, 14].copy().view(np.int32)
         np.testing.assert_array_equal(np.sort(gid), np.arange(nl))
-        res[plane] = (rows[np.argsort(gid)], sim.migrated, (sim.n_host_waits - w0) / 6.0)
+        res[label] = (rows[np.argsort(gid)], (sim.n_rows_arrived if lib_mig else sim.migrated) - a0, (sim.n_host_waits - w0) / 6.0,
+                      getattr(sim, "n_native_migrations", 0))
         sim.B.close()
-    ra, mig, waits = res["callbacks"]
+    ra, mig, waits, _ = res["torch plan"]
     assert mig > 50                                                    # rows did cross the seam
-    print("periodic ring: %d rows migrated in 8 steps, host waits per step %.2f" % (mig, waits))
+    print("periodic ring: %d rows migrated in 6 steps; host waits per step: %s" % (mig, {k: round(v[2], 2) for k, v in res.items()}))
     assert waits <= 2.5
     vscale = float(np.abs(ra[:, 3:6]).max())
-    for plane in ("native0", "native1", "native2"):
-        rb, mb, wb = res[plane]
-        assert mb == mig
-        assert np.abs(ra[:, :3] - rb[:, :3]).max() < 5e-7 and np.abs(ra[:, 3:6] - rb[:, 3:6]).max() < 5e-6 * vscale, plane
+    for label, (rb, mb, wb, nm) in res.items():
+        assert mb == mig, label
+        assert np.abs(ra[:, :3] - rb[:, :3]).max() < 5e-7 and np.abs(ra[:, 3:6] - rb[:, 3:6]).max() < 5e-6 * vscale, label
+        if label in ("native0", "native1", "native2"):
+            assert nm >= 6 and wb <= 1.2, (label, nm, wb)             # the step's last mail, nothing else
+        else:
+            assert nm == 0, label

@@ -5,7 +5,10 @@ right neighbour), and its neighbour exchange is closed onto itself -- what leave
 lower, and vice versa.  Rows really migrate across the seam (the block drifts along x), the resident state / tail classification
 / swap plan / apply path runs every step as on a rank of a real decomposition, at C4's per-rank shape and halo sizes.
 
-   python tools/ring_real.py [nx=32] [ny=252] [nz=252] [steps=20] [planes=callbacks,native0,native1] [vx=2.0]
+   python tools/ring_real.py [nx=32] [ny=252] [nz=252] [steps=20] [planes=callbacks_torchplan,callbacks,native0,native1] [vx=2.0]
+planes: callbacks = the communicator behind wcsph_slab_callbacks, native<m> = the library's RCCL plane in halo schedule m;
+_torchplan = the swap plan / list assembly in torch (rounds 5-6) instead of inside the library (csrc/api_migrate.h); _hdr = the rows of a
+migration over the caller's exchange with a header round trip even on the native plane (instead of wcsph_slab_migrate).
 prints one JSON line: ms per step, ms per step spent in redistribute (host + GPU, measured with a device synchronisation on either
 side -- subtract it from the step to compare with tools/overlap_ring.py), host waits per step, rows migrated per step; and the
 planes' final states compared (by global id)."""
@@ -21,7 +24,7 @@ nx = int(a[0]) if len(a) > 0 else 32
 ny = int(a[1]) if len(a) > 1 else 252
 nz = int(a[2]) if len(a) > 2 else 252
 steps = int(a[3]) if len(a) > 3 else 20
-planes = (a[4] if len(a) > 4 else "callbacks,native0,native1").split(",")
+planes = (a[4] if len(a) > 4 else "callbacks_torchplan,callbacks,native0,native1").split(",")
 vx = float(a[5]) if len(a) > 5 else 2.0
 mode = os.environ.get("RING_MODE", "clean")
 dev = torch.device("cuda", 0)
@@ -42,14 +45,17 @@ def make(plane):
     sim = SlabSim(lambda **kw: HipBackend(**kw), liquid, solid, bounds, [lo, hi], len(liquid), 0, 1, device=dev, neighbor_mode=mode)
     period = np.float32((hi - lo) * 2 * R)
     nl = len(liquid)
-    if plane.startswith("native"):
+    base = plane.replace("_torchplan", "").replace("_hdr", "").replace("_nosplit", "")
+    if base.startswith("native"):
         sim.enable_native_comm(neighbours=(0, 0))
-        sim.B.comm_set_mode(int(plane[-1]))
+        sim.B.comm_set_mode(int(base[-1]))
+    sim.library_migrate, sim.native_migrate = "_torchplan" not in plane, "_hdr" not in plane
+    sim.B._chk(sim.B.lib.wcsph_slab_migrate_set_seam(sim.B.ctx, -float(period), float(period), nl))
     # from here on: the middle rank of three, neighbours closed onto itself
     sim.rank, sim.world = 1, 3
     sim.loopback, sim.force_comm = True, True
     sim.interior = (lo + G, hi - G)
-    sim.set_overlap(not plane.endswith("0") and plane != "callbacks_nosplit")
+    sim.set_overlap(not base.endswith("0") and "_nosplit" not in plane)
     sim._allreduce_tensor = lambda t, op=None: None
     sim._allreduce = lambda v, op: v
     stat = {"red_s": 0.0, "migrated": 0, "n": 0, "ghost_seq": 0}
@@ -64,7 +70,6 @@ def make(plane):
         gid = torch.arange(nl, nl + ng_l + ng_r, dtype=torch.int32, device=dev)
         from_left[a_l:, STATE_W - 1] = gid[:ng_l].view(torch.float32)
         from_right[a_r:, STATE_W - 1] = gid[ng_l:].view(torch.float32)
-        stat["migrated"] += a_l + a_r
         return from_left, from_right, list(head_r), list(head_l)
     sim._exchange_var = exchange_var
     orig = sim.redistribute
@@ -84,8 +89,8 @@ for plane in planes:
     sim, stat, nl = make(plane)
     for _ in range(4):
         sim.step()
-    stat.update(red_s=0.0, migrated=0, n=0)
-    w0 = sim.n_host_waits
+    stat.update(red_s=0.0, n=0)
+    w0, m0 = sim.n_host_waits, sim.n_rows_arrived
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         sim.step()
@@ -93,7 +98,7 @@ for plane in planes:
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / steps
     out[plane] = {"ms_per_step": round(t * 1e3, 3), "redistribute_ms_per_step": round(stat["red_s"] / stat["n"] * 1e3, 3),
                   "step_without_redistribute_ms": round((t - stat["red_s"] / stat["n"]) * 1e3, 3),
-                  "host_waits_per_step": round((sim.n_host_waits - w0) / steps, 2), "rows_migrated_per_step": round(stat["migrated"] / steps, 1),
+                  "host_waits_per_step": round((sim.n_host_waits - w0) / steps, 2), "rows_migrated_per_step": round((sim.n_rows_arrived - m0) / steps, 1), "migrations_inside_the_library_over_rccl": getattr(sim, "n_native_migrations", 0),
                   "halo_rows": [int(sim.send_l.numel()), int(sim.send_r.numel())], "iters_last": [sim.vs_iter, sim.dv_iter, sim.pr_iter]}
     rows = sim.rows.cpu().numpy()
     gid = rows[:, 14].copy().view(np.int32)

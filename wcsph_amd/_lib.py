@@ -69,7 +69,7 @@ CTX_ONLY = [
 ]
 OTHER = ["wcsph_create", "wcsph_last_error", "wcsph_set_stream", "wcsph_device_count", "wcsph_setup",
          "wcsph_get_block_size", "wcsph_field_to_host", "wcsph_field_from_host", "wcsph_get_scalar",
-         "wcsph_set_scalar", "wcsph_get_iters", "wcsph_set_iters", "wcsph_neighbors_to_host", "wcsph_compact_lists_to_host", "wcsph_list_stats", "wcsph_time_kernel", "wcsph_state_classify", "wcsph_slab_set_tail_classify", "wcsph_slab_tail_classify_result", "wcsph_state_gather_rows", "wcsph_state_apply", "wcsph_comm_unique_id", "wcsph_comm_last_error", "wcsph_comm_init", "wcsph_comm_destroy", "wcsph_comm_set_neighbours", "wcsph_comm_set_mode", "wcsph_comm_set_halo_split", "wcsph_halo_exchange", "wcsph_comm_allreduce", "wcsph_comm_stats", "wcsph_comm_detach", "wcsph_comm_attach", "wcsph_profile_begin", "wcsph_profile_end", "wcsph_profile_laps_begin", "wcsph_profile_laps_end",
+         "wcsph_set_scalar", "wcsph_get_iters", "wcsph_set_iters", "wcsph_neighbors_to_host", "wcsph_compact_lists_to_host", "wcsph_list_stats", "wcsph_time_kernel", "wcsph_state_classify", "wcsph_slab_set_tail_classify", "wcsph_slab_tail_classify_result", "wcsph_slab_migrate_begin", "wcsph_slab_migrate_end", "wcsph_slab_halo_lists", "wcsph_slab_tail_neighbour_counts", "wcsph_slab_migrate", "wcsph_slab_migrate_set_seam", "wcsph_state_gather_rows", "wcsph_state_apply", "wcsph_comm_unique_id", "wcsph_comm_last_error", "wcsph_comm_init", "wcsph_comm_destroy", "wcsph_comm_set_neighbours", "wcsph_comm_set_mode", "wcsph_comm_set_halo_split", "wcsph_halo_exchange", "wcsph_comm_allreduce", "wcsph_comm_stats", "wcsph_comm_detach", "wcsph_comm_attach", "wcsph_profile_begin", "wcsph_profile_end", "wcsph_profile_laps_begin", "wcsph_profile_laps_end",
          "wcsph_field_gather_rows", "wcsph_field_scatter_rows", "wcsph_set_owned", "wcsph_set_cell_window",
          "wcsph_load_state", "wcsph_load_state_split", "wcsph_store_state", "wcsph_get_acc", "wcsph_set_acc", "wcsph_phase", "wcsph_set_part", "wcsph_set_acc_buffer",
          "wcsph_surface_anisotropic_kernel", "wcsph_dfsph_step_fixed", "wcsph_sample_surface", "wcsph_mc_tables",
@@ -141,6 +141,13 @@ def load():
     lib.wcsph_slab_set_tail_classify.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp]
     lib.wcsph_slab_tail_classify_result.argtypes = [vp, C.POINTER(C.c_int32 * 5)]
     lib.wcsph_state_gather_rows.argtypes = [vp, vp, C.c_int32, vp]
+    i5 = C.POINTER(C.c_int32 * 5)
+    lib.wcsph_slab_migrate_begin.argtypes = [vp, vp, C.c_int32, i5, C.POINTER(vp), C.POINTER(vp)]
+    lib.wcsph_slab_migrate_end.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, i5]
+    lib.wcsph_slab_halo_lists.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(C.c_int32)]
+    lib.wcsph_slab_tail_neighbour_counts.argtypes = [vp, i5, i5]
+    lib.wcsph_slab_migrate.argtypes = [vp, vp, C.c_int32, i5, i5, i5, i5]
+    lib.wcsph_slab_migrate_set_seam.argtypes = [vp, C.c_float, C.c_float, C.c_int32]
     lib.wcsph_state_apply.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32]
     lib.wcsph_comm_unique_id.argtypes = [vp]
     lib.wcsph_comm_last_error.argtypes = []

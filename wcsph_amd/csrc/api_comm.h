@@ -111,11 +111,7 @@ static int comm_check_split(NativeComm *c, int n_send, int n_ghost) {
 // [0, n_ghost_left) of d_recv come from the left, the rest from the right.  The receives are posted right-first: on a loop-back
 // communicator (left == right == this rank: the one-GPU test of the data plane) what goes out to the left comes in from the
 // right, as on a ring.
-static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_recv, int n_send, int n_ghost, hipStream_t s) {
-  int rc = comm_check_split(c, n_send, n_ghost);
-  if (rc) return rc;
-  const size_t sl = (size_t)c->n_send_left * W, sr = (size_t)(n_send - c->n_send_left) * W;
-  const size_t gl = (size_t)c->n_ghost_left * W, gr = (size_t)(n_ghost - c->n_ghost_left) * W;
+static int comm_exchange_sized(NativeComm *c, const float *d_send, size_t sl, size_t sr, float *d_recv, size_t gl, size_t gr, hipStream_t s) {
   NCCLCHK(c->api->GroupStart());
   if (c->left >= 0 && sl) NCCLCHK(c->api->Send(d_send, sl, ncclFloat, c->left, c->comm, s));
   if (c->right >= 0 && sr) NCCLCHK(c->api->Send(d_send + sl, sr, ncclFloat, c->right, c->comm, s));
@@ -124,6 +120,23 @@ static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_rec
   NCCLCHK(c->api->GroupEnd());
   c->n_exchanges++;
   return 0;
+}
+static int comm_exchange(NativeComm *c, int W, const float *d_send, float *d_recv, int n_send, int n_ghost, hipStream_t s) {
+  int rc = comm_check_split(c, n_send, n_ghost);
+  if (rc) return rc;
+  return comm_exchange_sized(c, d_send, (size_t)c->n_send_left * W, (size_t)(n_send - c->n_send_left) * W,
+                             d_recv, (size_t)c->n_ghost_left * W, (size_t)(n_ghost - c->n_ghost_left) * W, s);
+}
+// the five classification counts of this rank's next migration (api_slab.h tail_classify) to both slab neighbours, theirs into
+// d_nbr[0..5) (left) and d_nbr[8..13) (right); a missing neighbour's block stays as it is (zeroed at allocation)
+static int comm_counts_exchange(NativeComm *c, const int *d_mine, int *d_nbr, hipStream_t s) {
+  NCCLCHK(c->api->GroupStart());
+  if (c->left >= 0) NCCLCHK(c->api->Send(d_mine, 5, ncclInt32, c->left, c->comm, s));
+  if (c->right >= 0) NCCLCHK(c->api->Send(d_mine, 5, ncclInt32, c->right, c->comm, s));
+  if (c->right >= 0) NCCLCHK(c->api->Recv(d_nbr + 8, 5, ncclInt32, c->right, c->comm, s));
+  if (c->left >= 0) NCCLCHK(c->api->Recv(d_nbr, 5, ncclInt32, c->left, c->comm, s));
+  NCCLCHK(c->api->GroupEnd());
+  return 0;    // (not counted in n_exchanges: that is the halo refreshes and the row migrations)
 }
 // The halo stream has the HIGHEST priority the device offers: the few workgroups of a send / receive kernel should be placed as
 // soon as they are launched, not when the thousands of workgroups of the interior pass queued beside them drain.  (Measured, round

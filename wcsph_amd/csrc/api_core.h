@@ -37,7 +37,18 @@ struct wcsph_ctx {
   // the classification of the NEXT step's migration / ghost rebuild, taken in the tail of wcsph_slab_step (api_slab.h): its counts
   // reach the host with the step's last mail instead of costing a host wait of their own
   struct TailClassify { bool on = false, valid = false; int lo = 0, hi = 0, ghost = 0, has_l = 0, has_r = 0, cap = 0;
-                        long long *d_idx = nullptr; int *d_counts = nullptr; int *h_counts = nullptr; } tc;
+                        long long *d_idx = nullptr; int *d_counts = nullptr; int *h_counts = nullptr;
+                        // native data plane: the two slab neighbours' counts, exchanged by RCCL behind the classification and mailed with
+                        // it (h_counts[8..13) left, [16..21) right): the next migration needs no header round trip (api_migrate.h)
+                        int *d_nbr = nullptr; bool nbr_valid = false; bool nbr_queued = false;
+                        unsigned long long pending_seq = 0; } tc;   // pending_seq != 0: the plain path's tail, its mail not collected yet
+  // migration + ghost rebuild of a resident slab state inside the library (api_migrate.h): buffers owned here, grown on demand
+  struct Migrate { float *send = nullptr, *recv = nullptr; size_t cap_send = 0, cap_recv = 0;      // rows of STATE_W floats
+                   int *halo_send = nullptr, *halo_ghost = nullptr; size_t cap_hs = 0, cap_hg = 0; // the halo lists the migration leaves behind
+                   int *work = nullptr; size_t cap_work = 0;
+                   const long long *d_idx = nullptr; int cap = 0, c[4] = {0, 0, 0, 0};             // of the begin() in progress: near_l, near_r, go_l, go_r
+                   bool begun = false;
+                   float shift_l = 0.f, shift_r = 0.f; int ghost_gid_base = -1; } mg;               // periodic seam (wcsph_slab_migrate_set_seam)
   NativeComm *comm = nullptr;     // the native RCCL data plane of a slab decomposition (wcsph_comm_init), or none
   bool pr_valid = false;          // Dev::pr holds (pos, rho) of every row (dfsph_kernels.h k_pack_pr)
   // staging for original-order transfers

@@ -91,6 +91,8 @@ int wcsph_destroy(wcsph_ctx *ctx) {
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->h_acc_raw) hipHostFree(ctx->h_acc_raw);
   if (ctx->tc.h_counts) hipHostFree(ctx->tc.h_counts);
+  if (ctx->tc.d_nbr) hipFree(ctx->tc.d_nbr);
+  { auto &m = ctx->mg; if (m.send) hipFree(m.send); if (m.recv) hipFree(m.recv); if (m.halo_send) hipFree(m.halo_send); if (m.halo_ghost) hipFree(m.halo_ghost); if (m.work) hipFree(m.work); }
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   for (hipEvent_t e : ctx->lap_ev) hipEventDestroy(e);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);

@@ -60,42 +60,81 @@ int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, 
   return WCSPH_OK;
 }
 }  // extern "C"
-__global__ void k_counts_to_host(const int *c, int *h, const int *pred) {
+__global__ void k_counts_to_host(const int *c, int *h, const int *pred, const int *nbr) {
   if (pred && *pred == 0) return;
   if (threadIdx.x < 5) h[threadIdx.x] = c[threadIdx.x];
+  if (nbr && threadIdx.x >= 8 && threadIdx.x < 24) h[threadIdx.x] = nbr[threadIdx.x - 8];
 }
 // wcsph_state_classify in the tail of wcsph_slab_step, gated like the launches around it; the counts go to pinned host memory
-// in front of the mail that follows
-static int tail_classify(wcsph_ctx *ctx, const int *pred) {
+// in front of the mail that follows.  native != nullptr (the library's own RCCL plane): the counts also go to the two slab
+// neighbours and theirs come back (one grouped send / recv of five words, unconditional like every exchange of the step) and
+// travel in the same mail -- the next migration then knows every message size without a header round trip (api_migrate.h)
+static int tail_classify(wcsph_ctx *ctx, const int *pred, NativeComm *native) {
   auto &t = ctx->tc;
   HIPCHK(hipMemsetAsync(t.d_counts, 0, 5 * sizeof(int32_t), ctx->stream));
   const long long n = ctx->d.n_owned;
   if (n > 0)
     hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)ctx->d.pos, n, 4,
                        ctx->d.minx, ctx->d.inv_grid, t.lo, t.hi, t.ghost, t.has_l, t.has_r, t.d_idx, t.cap, t.d_counts, (const int *)ctx->d.where, pred);
-  hipLaunchKernelGGL(k_counts_to_host, dim3(1), dim3(WAVE), 0, ctx->stream, (const int *)t.d_counts, t.h_counts, pred);
+  t.nbr_queued = false;
+  if (native) {
+    if (!t.d_nbr) { HIPCHK(hipMalloc((void **)&t.d_nbr, 16 * sizeof(int))); HIPCHK(hipMemsetAsync(t.d_nbr, 0, 16 * sizeof(int), ctx->stream)); }
+    int rc = comm_counts_exchange(native, t.d_counts, t.d_nbr, ctx->stream);
+    if (rc) return rc;
+    t.nbr_queued = true;
+  }
+  hipLaunchKernelGGL(k_counts_to_host, dim3(1), dim3(WAVE), 0, ctx->stream, (const int *)t.d_counts, t.h_counts, pred, (const int *)(native ? t.d_nbr : nullptr));
   LAUNCHCHK();
+  return 0;
+}
+// the tail of a step that ended on its plain path: its mail has not been waited for yet
+static int tail_collect(wcsph_ctx *ctx) {
+  auto &t = ctx->tc;
+  if (!t.pending_seq) return 0;
+  const unsigned long long seq = t.pending_seq;
+  t.pending_seq = 0;
+  const float err_keep = ctx->avg_density_err;
+  int rc = collect_mail(ctx, true, seq);
+  ctx->avg_density_err = err_keep;
+  if (rc) return rc;
+  t.valid = true; t.nbr_valid = t.nbr_queued;
   return 0;
 }
 extern "C" {
 int wcsph_slab_set_tail_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, int32_t has_left, int32_t has_right, int64_t *d_idx, int32_t cap, int32_t *d_counts) {
   NEED_SETUP();
   auto &t = ctx->tc;
-  t.valid = false;
+  { int rc0 = tail_collect(ctx); if (rc0) return rc0; }   // (a plain-path tail still in flight writes the OLD buffers: let it land first)
+  t.valid = false;      // (the neighbours' counts of the last step stay valid: they do not depend on this rank's buffers)
   if (!d_idx || !d_counts || cap <= 0) { t.on = false; return WCSPH_OK; }
-  if (!t.h_counts) { HIPCHK(hipHostMalloc((void **)&t.h_counts, 8 * sizeof(int))); memset(t.h_counts, 0, 8 * sizeof(int)); }
+  if (!t.h_counts) { HIPCHK(hipHostMalloc((void **)&t.h_counts, 32 * sizeof(int))); memset(t.h_counts, 0, 32 * sizeof(int)); }
   t.lo = lo; t.hi = hi; t.ghost = ghost; t.has_l = has_left; t.has_r = has_right; t.d_idx = (long long *)d_idx; t.cap = cap; t.d_counts = d_counts;
   t.on = true;
   return WCSPH_OK;
 }
-// WCSPH_OK: counts[5] = the result of the classification taken in the last wcsph_slab_step's tail (consumed by this call; the
-// index lists are in the registered buffer); 1: none available (the step ended on its plain path): call wcsph_state_classify
+// WCSPH_OK / 2: counts[5] = the result of the classification taken in the last wcsph_slab_step's tail (consumed by this call; the
+// index lists are in the registered buffer); 1: none available: call wcsph_state_classify.  WCSPH_OK: the step ended on its
+// speculative path, the counts were on the host already; 2: it ended on its plain path and this call has waited for them.
 int wcsph_slab_tail_classify_result(wcsph_ctx *ctx, int32_t counts[5]) {
   NEED_SETUP();
   if (!counts) return WCSPH_EARG;
+  const bool waited = ctx->tc.pending_seq != 0;
+  int rc = tail_collect(ctx);
+  if (rc) return rc;
   if (!ctx->tc.on || !ctx->tc.valid || ctx->nl_phys > 0) return 1;
   for (int k = 0; k < 5; k++) counts[k] = ctx->tc.h_counts[k];
   ctx->tc.valid = false;
+  return waited ? 2 : WCSPH_OK;
+}
+// WCSPH_OK: the slab neighbours' classification counts of the same moment (native data plane only: exchanged in the step's tail);
+// 1: none available.  A missing neighbour's counts are zero.  Not consumed: wcsph_slab_migrate reads them too.
+int wcsph_slab_tail_neighbour_counts(wcsph_ctx *ctx, int32_t left[5], int32_t right[5]) {
+  NEED_SETUP();
+  if (!left || !right) return WCSPH_EARG;
+  int rc = tail_collect(ctx);
+  if (rc) return rc;
+  if (!ctx->tc.nbr_valid) return 1;
+  for (int k = 0; k < 5; k++) { left[k] = ctx->tc.h_counts[8 + k]; right[k] = ctx->tc.h_counts[16 + k]; }
   return WCSPH_OK;
 }
 int wcsph_state_gather_rows(wcsph_ctx *ctx, const int64_t *d_idx, int32_t n, float *d_rows) {
@@ -401,8 +440,9 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
   Dev &d = ctx->d;
   int rc;
   d.pred = nullptr; d.dtp = nullptr;
-  ctx->tc.valid = false;
+  ctx->tc.valid = false; ctx->tc.nbr_valid = false; ctx->tc.pending_seq = 0;
   PartGuard part_guard{d};
+  NativeComm *const tail_native = (cb && ctx->comm && cb == &ctx->comm->cb) ? ctx->comm : nullptr;
   const double N = (double)n_global;
   const bool tension = (flags & 2) && !(d.tension == 0.0f && d.tension_b == 0.0f);
   if (tension && ctx->p.tension_fixed == 0 && R.multi) return ctx->fail(WCSPH_EARG, "the literal compute_tension reads the reference's raw bucket rows, which span all slabs: tension_fixed = 1 on a decomposition");
@@ -598,7 +638,7 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
       // (E) behind it: when the step ends here -- the common case -- its counts are on the host without a wait of their own
       unsigned long long seqE = 0;
       if (ctx->tc.on && R.multi) {
-        SRC(tail_classify(ctx, pD));
+        SRC(tail_classify(ctx, pD, tail_native));
         SRC(publish_async(ctx, {PRED_PASS, 0.0, 1.0, nullptr, pD}));
         seqE = ctx->mail_seq;
       }
@@ -627,7 +667,7 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
             const float err_keep = ctx->avg_density_err;
             SRC(collect_mail(ctx, true, seqE));
             ctx->avg_density_err = err_keep;
-            ctx->tc.valid = true;
+            ctx->tc.valid = true; ctx->tc.nbr_valid = ctx->tc.nbr_queued;
           }
           if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; }
           return WCSPH_OK;
@@ -704,6 +744,14 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
     err = (double)ctx->avg_density_err / N;
   }
   ELEM(k_end_press_update_pos, dtn);
+  // the same tail on the plain path (every rank is here or none: the decisions were taken on all-reduced sums): the classification
+  // and, on the native plane, the neighbours' counts are queued now, their mail is waited for by whoever asks for the result
+  // (wcsph_slab_tail_classify_result) -- the migration's message sizes are then known without a header round trip on this path too
+  if (ctx->tc.on && R.multi) {
+    SRC(tail_classify(ctx, nullptr, tail_native));
+    SRC(publish_async(ctx));
+    ctx->tc.pending_seq = ctx->mail_seq;
+  }
   if (stats) { stats[0] = R.n_xchg; stats[1] = R.n_wait; }
   return WCSPH_OK;
 }

@@ -31,4 +31,5 @@
 #include "api_post.h"
 #include "api_comm.h"
 #include "api_slab.h"
+#include "api_migrate.h"
 #include "api_measure.h"

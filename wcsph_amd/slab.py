@@ -123,39 +123,92 @@ class HipBackend:
         return c, [self._cls_idx[k, :c[k]] for k in range(4)]
 
     # ---- state resident in the library between steps (include/wcsph.h "slab state resident in the library") -------------
-    def classify_state(self, lo, hi, ghost, has_l, has_r):
+    def classify_state(self, lo, hi, ghost, has_l, has_r, grow=False):
         """classify_rows over the context's OWN owned rows (no row table in the driver): counts + four int64 lists of
-        original indices; None when a list did not fit its buffer.  One launch and one host wait -- or neither (round 6): the
-        library takes the same classification in the tail of wcsph_slab_step and its counts arrive with the step's last mail
-        (`self.classify_waited` says which it was)."""
+        original indices; None when a list did not fit its buffer (grow: a larger buffer and once more instead).  One launch and
+        one host wait -- or neither (round 6): the library takes the same classification in the tail of wcsph_slab_step and its
+        counts arrive with the step's last mail (`self.classify_waited` says which it was)."""
         n = int(self.n_owned)
         cap = max(65536, n // 8)
         if getattr(self, "_cls_idx", None) is None or self._cls_idx.shape[1] < cap:
             self._cls_idx = torch.empty((4, cap), dtype=torch.int64, device=self.device)
             self._cls_cnt = torch.empty(5, dtype=torch.int32, device=self.device)
             self._tc_key = None
-        key = (int(lo), int(hi), int(ghost), int(has_l), int(has_r), int(self._cls_idx.shape[1]), self._cls_idx.data_ptr())
         c = None
-        if os.environ.get("WCSPH_SLAB_TAIL_CLASSIFY", "1") != "0":
-            if getattr(self, "_tc_key", None) != key:       # (re)register: the next step's tail classifies with these parameters
-                self._chk(self.lib.wcsph_slab_set_tail_classify(self.ctx, key[0], key[1], key[2], key[3], key[4], C.c_void_p(self._cls_idx.data_ptr()), key[5],
-                                                                C.c_void_p(self._cls_cnt.data_ptr())))
-                self._tc_key = key
-            else:
-                got = (C.c_int32 * 5)()
-                rc = self.lib.wcsph_slab_tail_classify_result(self.ctx, C.byref(got))
-                if rc < 0:
-                    self._chk(rc)
-                if rc == 0:
-                    c = list(got)
-        self.classify_waited = c is None
-        if c is None:
-            self._chk(self.lib.wcsph_state_classify(self.ctx, int(lo), int(hi), int(ghost), int(has_l), int(has_r),
-                                                    C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.c_void_p(self._cls_cnt.data_ptr())))
-            c = self._cls_cnt.tolist()
-        if max(c[:4]) > self._cls_idx.shape[1]:
-            return None
+        self.classify_waited = False
+        for _attempt in range(2):
+            key = (int(lo), int(hi), int(ghost), int(has_l), int(has_r), int(self._cls_idx.shape[1]), self._cls_idx.data_ptr())
+            if c is None and os.environ.get("WCSPH_SLAB_TAIL_CLASSIFY", "1") != "0":
+                if getattr(self, "_tc_key", None) != key:       # (re)register: the next step's tail classifies with these parameters
+                    self._chk(self.lib.wcsph_slab_set_tail_classify(self.ctx, key[0], key[1], key[2], key[3], key[4], C.c_void_p(self._cls_idx.data_ptr()), key[5],
+                                                                    C.c_void_p(self._cls_cnt.data_ptr())))
+                    self._tc_key = key
+                else:
+                    got = (C.c_int32 * 5)()
+                    rc = self.lib.wcsph_slab_tail_classify_result(self.ctx, C.byref(got))
+                    if rc < 0:
+                        self._chk(rc)
+                    if rc in (0, 2):                            # 2: the step ended on its plain path, the call has waited for the counts
+                        c = list(got)
+                        self.classify_waited = rc == 2
+            if c is None:
+                self._chk(self.lib.wcsph_state_classify(self.ctx, int(lo), int(hi), int(ghost), int(has_l), int(has_r),
+                                                        C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.c_void_p(self._cls_cnt.data_ptr())))
+                c = self._cls_cnt.tolist()
+                self.classify_waited = True
+            if max(c[:4]) <= self._cls_idx.shape[1]:
+                break
+            if not grow:
+                return None
+            # a list did not fit (the lists were cut at the buffer's end): a larger buffer, the classification once more
+            self._cls_idx = torch.empty((4, int(max(c[:4]) * 1.25) + 4096), dtype=torch.int64, device=self.device)
+            self._tc_key = None
+            c = None
         return c, [self._cls_idx[k, :c[k]] for k in range(4)]
+
+    # ---- migration + ghost rebuild inside the library (csrc/api_migrate.h) ------------------------------------------------
+    def migrate_begin(self, counts):
+        """the rows that travel, gathered into the library's send buffer: (to_left, to_right) as torch views of it"""
+        c5 = (C.c_int32 * 5)(*[int(v) for v in counts])
+        pl, pr = C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.wcsph_slab_migrate_begin(self.ctx, C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.byref(c5), C.byref(pl), C.byref(pr)))
+        n_l, n_r = int(counts[2] + counts[0]), int(counts[3] + counts[1])
+        view = lambda ptr, n: (torch.as_tensor(_DevArray(ptr.value, n * STATE_W, "<f4"), device=self.device).view(n, STATE_W) if n   # noqa: E731
+                               else torch.empty((0, STATE_W), dtype=torch.float32, device=self.device))
+        return view(pl, n_l), view(pr, n_r)
+
+    def _adopt_migration(self, out):
+        out = [int(v) for v in out]
+        self.n_owned = out[0]
+        ps, pg, ns, ng = C.c_void_p(), C.c_void_p(), C.c_int32(), C.c_int32()
+        self._chk(self.lib.wcsph_slab_halo_lists(self.ctx, C.byref(ps), C.byref(ns), C.byref(pg), C.byref(ng)))
+        i32 = lambda ptr, n: (torch.as_tensor(_DevArray(ptr.value, n, "<i4"), device=self.device) if n else torch.zeros(0, dtype=torch.int32, device=self.device))   # noqa: E731
+        return out, i32(ps, ns.value), i32(pg, ng.value)
+
+    def migrate_end(self, in_l, a_l, in_r, a_r):
+        """what the neighbours sent (the first a_l / a_r rows of a message become this rank's): plan, rows and halo lists on the
+        device.  Returns ([n_owned, n_send_left, n_send_right, n_ghost_left, n_ghost_right], send list, ghost list)"""
+        in_l, in_r = in_l.contiguous(), in_r.contiguous()
+        out = (C.c_int32 * 5)()
+        self._chk(self.lib.wcsph_slab_migrate_end(self.ctx, C.c_void_p(in_l.data_ptr()), int(in_l.shape[0]), int(a_l),
+                                                  C.c_void_p(in_r.data_ptr()), int(in_r.shape[0]), int(a_r), C.byref(out)))
+        self._keep = (in_l, in_r)            # alive until the stream has consumed them
+        return self._adopt_migration(out)
+
+    def tail_neighbour_counts(self):
+        """native data plane: the slab neighbours' counts of the classification taken in the last step's tail, or None"""
+        l, r = (C.c_int32 * 5)(), (C.c_int32 * 5)()
+        rc = self.lib.wcsph_slab_tail_neighbour_counts(self.ctx, C.byref(l), C.byref(r))
+        if rc < 0:
+            self._chk(rc)
+        return (list(l), list(r)) if rc == 0 else None
+
+    def migrate_native(self, counts, nbr_l, nbr_r):
+        """begin + one grouped ncclSend / ncclRecv of exact sizes + end inside the library (wcsph_slab_migrate)"""
+        c5, l5, r5 = (C.c_int32 * 5)(*[int(v) for v in counts]), (C.c_int32 * 5)(*nbr_l), (C.c_int32 * 5)(*nbr_r)
+        out = (C.c_int32 * 5)()
+        self._chk(self.lib.wcsph_slab_migrate(self.ctx, C.c_void_p(self._cls_idx.data_ptr()), int(self._cls_idx.shape[1]), C.byref(c5), C.byref(l5), C.byref(r5), C.byref(out)))
+        return self._adopt_migration(out)
 
     def gather_state_rows(self, idx):
         """the STATE_W-float rows of the listed original indices (int64, device)"""
@@ -442,6 +495,12 @@ class SlabSim:
         self._cb_exc = None
         # flags bit 3 of wcsph_slab_step: call the communicator at every exchange point even with one rank (tools/slab_overhead.py)
         self.force_comm = os.environ.get("WCSPH_SLAB_FORCE_COMM", "0") == "1"
+        # the rows of a migration over the library's own RCCL communicator when it is on (wcsph_slab_migrate); False: over this
+        # rank's torch.distributed group with a header round trip, as on the callback plane
+        self.native_migrate = os.environ.get("WCSPH_SLAB_NATIVE_MIGRATE", "1") != "0"
+        # swap plan, row writes and halo lists of a migration inside the library (csrc/api_migrate.h); False: the torch form (rounds 5-6)
+        self.library_migrate = os.environ.get("WCSPH_SLAB_LIBRARY_MIGRATE", "1") != "0"
+        self.n_rows_arrived = 0
 
     # ---- the owned rows (STATE_W floats each) ------------------------------------------------------------------------------
     # With the HIP backend and the native step the state LIVES IN THE LIBRARY between steps (WCSPH_SLAB_RESIDENT=0 switches it
@@ -954,7 +1013,8 @@ class SlabSim:
         G = GHOST_CELLS
         n = int(self.n_owned)
         has_l, has_r = self.rank > 0, self.rank < self.world - 1
-        native = B.classify_state(self.lo, self.hi, G, has_l, has_r)
+        in_library = hasattr(B, "migrate_begin") and self.library_migrate
+        native = B.classify_state(self.lo, self.hi, G, has_l, has_r, grow=True) if in_library else B.classify_state(self.lo, self.hi, G, has_l, has_r)
         self.n_host_waits += 1 if getattr(B, "classify_waited", True) else 0
         if native is None:                                   # a list overflowed its buffer: the classic path on a materialised table
             _ = self.rows
@@ -963,23 +1023,43 @@ class SlabSim:
         if n_lost:
             raise RuntimeError("rank %d: %d particles moved more than %d cell columns past a cut in one step (CFL violated); "
                                "they would land outside the neighbour's cell window" % (self.rank, n_lost, G))
+        if in_library:
+            # Round 6: gather, swap plan, row writes and the halo lists of the coming step inside the library (csrc/api_migrate.h: five
+            # launches, no host wait) instead of ~20 small torch launches with the GPU idle behind them.  On the library's own RCCL
+            # plane the neighbours' counts came with the step's last mail (every rank has them or none: the tail of
+            # wcsph_slab_step is the same launch sequence on every rank), so the rows travel in ONE grouped ncclSend / ncclRecv of
+            # exact sizes; otherwise header + rows over this rank's communicator as before.
+            nbr = B.tail_neighbour_counts() if (getattr(B, "native_comm", False) and self.native_migrate) else None
+            if nbr is not None:
+                out, self.send_all, self.ghost_all = B.migrate_native(native[0], nbr[0], nbr[1])
+                self.n_exchanges += 1
+                self.n_native_migrations = getattr(self, "n_native_migrations", 0) + 1
+                self.n_rows_arrived += (nbr[0][3] if has_l else 0) + (nbr[1][2] if has_r else 0)
+            else:
+                to_l, to_r = B.migrate_begin(native[0])
+                in_l, in_r, hl, hr = self._exchange_var(to_l, to_r, (n_ml,), (n_mr,))
+                out, self.send_all, self.ghost_all = B.migrate_end(in_l, int(hl[0]), in_r, int(hr[0]))
+                self.n_rows_arrived += int(hl[0]) + int(hr[0])
+            self.n_owned, n_sl, n_gl = out[0], out[1], out[3]
+            self.send_l, self.send_r = self.send_all[:n_sl], self.send_all[n_sl:]
+            self.ghost_l, self.ghost_r = self.ghost_all[:n_gl], self.ghost_all[n_gl:]
+            return
         out = B.gather_state_rows(torch.cat([idx_gl, idx_nl, idx_gr, idx_nr]))
         to_l, to_r = out[:n_ml + n_nl], out[n_ml + n_nl:]
         mig_l, mig_r = to_l[:n_ml], to_r[:n_mr]
         in_l, in_r, hl, hr = self._exchange_var(to_l, to_r, (n_ml,), (n_mr,))
         a_l, a_r = int(hl[0]), int(hr[0])
+        self.n_rows_arrived += a_l + a_r
         arrivals = torch.cat([in_l[:a_l], in_r[:a_r]], 0) if (a_l or a_r) else out[:0]
         n_new, pos_arr, idx_nl, idx_nr, fold_dst, fold_src = self._swap_plan(n, torch.cat([idx_gl, idx_gr]), int(arrivals.shape[0]), idx_nl, idx_nr)
-        gl = torch.cat([in_l[a_l:], mig_l], 0)
-        gr = torch.cat([in_r[a_r:], mig_r], 0)
-        B.apply_state(n_new, fold_dst, fold_src, pos_arr, arrivals, torch.cat([gl, gr], 0))
+        n_gl, n_gr = int(in_l.shape[0]) - a_l + int(mig_l.shape[0]), int(in_r.shape[0]) - a_r + int(mig_r.shape[0])
+        B.apply_state(n_new, fold_dst, fold_src, pos_arr, arrivals, torch.cat([in_l[a_l:], mig_l, in_r[a_r:], mig_r], 0))
         n = n_new
-        self.send_l = torch.cat([idx_nl, pos_arr[:a_l]]).to(i32)
-        self.send_r = torch.cat([idx_nr, pos_arr[a_l:]]).to(i32)
-        self.ghost_l = torch.arange(n, n + gl.shape[0], dtype=i32, device=self.device)
-        self.ghost_r = torch.arange(n + gl.shape[0], n + gl.shape[0] + gr.shape[0], dtype=i32, device=self.device)
-        self.send_all = torch.cat([self.send_l, self.send_r])
-        self.ghost_all = torch.cat([self.ghost_l, self.ghost_r])
+        n_sl = int(idx_nl.shape[0]) + a_l
+        self.send_all = torch.cat([idx_nl, pos_arr[:a_l], idx_nr, pos_arr[a_l:]]).to(i32)
+        self.send_l, self.send_r = self.send_all[:n_sl], self.send_all[n_sl:]
+        self.ghost_all = torch.arange(n, n + n_gl + n_gr, dtype=i32, device=self.device)
+        self.ghost_l, self.ghost_r = self.ghost_all[:n_gl], self.ghost_all[n_gl:]
         self.n_owned = n
 
     def _swap_plan(self, n, holes, a, *index_lists):
