@@ -17,7 +17,7 @@ timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 ( cd /tmp && export TMPDIR=/tmp
   for m in clean faithful; do python $R/tools/overlap_ring.py 32 252 252 $m 20 2>/dev/null | grep "^{"; done > $O/${TAG}_overlap_ring.json )
 ( cd /tmp && export TMPDIR=/tmp
-  python $R/tools/ring_real.py 32 252 252 20 callbacks,callbacks_nosplit,native0,native1,native2 2.0 2>/dev/null | grep "^{" > $O/${TAG}_ring_real.json )   # (clean mode: the faithful mode's global bucket table needs real ranks)
+  python $R/tools/ring_real.py 32 252 252 20 callbacks_torchplan,callbacks,callbacks_nosplit,native0_hdr,native0,native1,native2 2.0 2>/dev/null | grep "^{" > $O/${TAG}_ring_real.json )   # (clean mode: the faithful mode's global bucket table needs real ranks)
 bash $R/tools/r06_overlap.sh $TAG clean
 bash $R/tools/r06_overlap_gaps.sh $TAG clean
 cd /tmp && export TMPDIR=/tmp

@@ -1451,7 +1451,8 @@ def bench_main(args):
         faulthandler.dump_traceback_later(int(os.environ.get("WCSPH_BENCH_WATCHDOG_S", "1200")), exit=True)
         if ok:
             plane = ("native RCCL inside the library (wcsph_comm_init / wcsph_halo_exchange: grouped ncclSend/ncclRecv on the communicator's halo stream "
-                     "beside the interior pass, ncclAllReduce on the context's stream); migration + ghost rebuild over torch.distributed (RCCL)")
+                     "beside the interior pass, ncclAllReduce on the context's stream; migration + ghost rebuild by wcsph_slab_migrate: message sizes from "
+                     "the step's last mail, one grouped ncclSend/ncclRecv, plan and row writes on the device)")
         else:
             if why:
                 print("[bench rank %d] native data plane not used (%s): torch.distributed callbacks" % (rank, why), file=sys.stderr, flush=True)
@@ -1516,6 +1517,7 @@ def bench_main(args):
                                        "wcsph_slab_step (library, communicator behind callbacks)") if sim.native else "python phase driver",
                        "halo_schedule_tuning": tuning,
                        "host_waits_per_step": round(sim.n_host_waits / float(max(sim.steps_done, 1)), 1),
+                       "migrations_inside_the_library_over_rccl": getattr(sim, "n_native_migrations", 0),
                        "rebalance_every": sim.rebalance_every, "rebalanced": sim.n_rebalanced,
                        "owned_per_rank": [int(c.item()) for c in allc],
                        "halo_exchanges_per_step": round(sim.n_exchanges / float(max(sim.steps_done, 1)), 1),
