@@ -24,6 +24,7 @@ KINDS = [
     (r"c5", "config C5 (tension on) kernel statistics"),
     (r"tile", "LDS tile walk experiment (round 5)"),
     (r"r06_(overlap|cluster_pair|developed)\.md$", "round-6 write-up (what was built, measured, concluded)"),
+    (r"migrate_plan", "`pytest -m gpu tests/test_gpu_migrate_plan.py` log"),
     (r"overlap|ring_gaps|ring", "halo / compute overlap on the loop-back ring of C4's per-rank shape (`tools/overlap_ring.py`, `rocpd_overlap.py`, `rocpd_ring_steps.py`)"),
     (r"prio_probe", "micro-benchmark (`tools/micro/*`) or GPU-idle analysis"),
     (r"cpair", "cluster-pair walk experiment (round 6): PMC passes"),
@@ -56,6 +57,7 @@ says otherwise.  (Regenerate with `python tools/profiles_index.py`.)
 | `r06z_bench_20_5.json`, `r06z_bench_default.json`, `r06z_rest_kernel_stats.md`, `r06z_dev_kernel_stats.md`, `r06z_bench_rocprof_stats.md`, `r06z_pmc_*` | the campaign on the final source (`tools/campaign_r06.sh`): 1254 M particle-steps/s (1.595 ms/step), 1016-1021 M over the default window, 605 M developed; `pressure_iter` 136.6 us = 0.176 |
 | `r06z_slab_overhead.txt`, `r06z_slab_nccl_world1.json`, `r06z_bench_two_ranks_one_gpu_gloo.json` | slab driver on one GPU: +0.010 ... 0.014 ms (clean) over the fused step on either plane; the bench path on the real RCCL backend with one rank incl. the schedule tuning; two ranks on one GPU over gloo (2.2 host waits per step, stdout = the one JSON line) |
 | `r06z_live_parity.log`, `r06z_gputests.log` | the live-state parity numbers themselves (flip candidates, quantiles, 3 slabs and C4's 8 slabs against one context, native plane schedules against the callback plane); `pytest -m gpu` on the final source: 136 passed, 1 skipped |
+| `r06f_*` (same file names as `r06z_*`), `r06f_ring_real.json`, `r06f_ring_real_nosync.json`, `r06f_migrate_plan_tests.log` | the campaign repeated on the round's FINAL source (migration + ghost rebuild inside the library, `csrc/api_migrate.h`): 1242 M / 1012-1018 M / 605 M, `pressure_iter` 137.9 us = 0.174, 145 GPU tests passed; the periodic ring driven by the real migration code: host waits per step 2.0 -> 1.0, redistribute 0.25 ms (torch plan) -> 0.145 (library plan behind the caller's exchange) -> 0.107 (`wcsph_slab_migrate` over RCCL), every variant bit-identical; `_nosync`: the same steps without the measurement's synchronisations (2.87 -> 2.67 ms per step) |
 | `r06_compiler_sched_flags.txt` | seven LLVM scheduling strategies / biases on the whole library: none helps |
 | `r05_lds_tile_experiment.md`, `r04_experiments.md`, `r03_experiments.md`, `r02b_wave_brick_experiment.md` | every earlier measured-and-rejected idea with its counters |
 

@@ -78,7 +78,8 @@ def make(plane):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         orig()
         torch.cuda.synchronize(); stat["red_s"] += time.perf_counter() - t0; stat["n"] += 1
-    sim.redistribute = timed_redistribute
+    if os.environ.get("RING_NOSYNC") != "1":     # RING_NOSYNC=1: the step as it runs (no synchronisation around the redistribute: the host runs ahead)
+        sim.redistribute = timed_redistribute
     sim.rows[:, 3] = vx
     return sim, stat, nl
 
@@ -96,8 +97,9 @@ for plane in planes:
         sim.step()
         assert sim.n_owned == nl, (sim.n_owned, nl)             # nobody lost on the ring
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / steps
-    out[plane] = {"ms_per_step": round(t * 1e3, 3), "redistribute_ms_per_step": round(stat["red_s"] / stat["n"] * 1e3, 3),
-                  "step_without_redistribute_ms": round((t - stat["red_s"] / stat["n"]) * 1e3, 3),
+    red = stat["red_s"] / max(stat["n"], 1)
+    out[plane] = {"ms_per_step": round(t * 1e3, 3), "redistribute_ms_per_step": round(red * 1e3, 3) if stat["n"] else None,
+                  "step_without_redistribute_ms": round((t - red) * 1e3, 3) if stat["n"] else None,
                   "host_waits_per_step": round((sim.n_host_waits - w0) / steps, 2), "rows_migrated_per_step": round((sim.n_rows_arrived - m0) / steps, 1), "migrations_inside_the_library_over_rccl": getattr(sim, "n_native_migrations", 0),
                   "halo_rows": [int(sim.send_l.numel()), int(sim.send_r.numel())], "iters_last": [sim.vs_iter, sim.dv_iter, sim.pr_iter]}
     rows = sim.rows.cpu().numpy()
