@@ -87,11 +87,13 @@ def make(plane):
 out = {"shape": [nx, ny, nz], "mode": mode, "steps": steps, "vx": vx}
 final = {}
 for plane in planes:
+    free0 = torch.cuda.mem_get_info()[0]
     sim, stat, nl = make(plane)
     for _ in range(4):
         sim.step()
     stat.update(red_s=0.0, n=0)
     w0, m0 = sim.n_host_waits, sim.n_rows_arrived
+    free1 = torch.cuda.mem_get_info()[0]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         sim.step()
@@ -102,6 +104,7 @@ for plane in planes:
                   "step_without_redistribute_ms": round((t - red) * 1e3, 3) if stat["n"] else None,
                   "host_waits_per_step": round((sim.n_host_waits - w0) / steps, 2), "rows_migrated_per_step": round((sim.n_rows_arrived - m0) / steps, 1), "migrations_inside_the_library_over_rccl": getattr(sim, "n_native_migrations", 0),
                   "halo_rows": [int(sim.send_l.numel()), int(sim.send_r.numel())], "iters_last": [sim.vs_iter, sim.dv_iter, sim.pr_iter]}
+    out[plane]["device_memory_taken_during_the_timed_steps_MB"] = round((free1 - torch.cuda.mem_get_info()[0]) / 1e6, 1)   # (a long run: nothing may grow)
     rows = sim.rows.cpu().numpy()
     gid = rows[:, 14].copy().view(np.int32)
     assert np.array_equal(np.sort(gid), np.arange(nl)), "global ids are no longer a permutation"
