@@ -437,7 +437,8 @@ int wcsph_slab_step(wcsph_ctx *ctx, const wcsph_slab_callbacks *cb, int64_t n_gl
  *        arrays then have holes; the next grid update (wcsph_slab_step) drops them -- nothing else may run in between.
  * (all index arrays int64 on the device, as wcsph_slab_classify returns them) */
 /* (round 6) the same classification taken in the TAIL of wcsph_slab_step, on the positions the step has just written: register the
- * parameters and buffers of wcsph_state_classify once (d_idx == NULL: off); when a step ends on its speculative path -- the common
+ * parameters and buffers of wcsph_state_classify once (d_idx == NULL: off; the tail fills d_idx, its counts go to the host only -- d_counts
+ * stays wcsph_state_classify's); when a step ends on its speculative path -- the common
  * case -- the counts travel with its last mail, and wcsph_slab_tail_classify_result returns them (WCSPH_OK, consumed) without a
  * host wait of its own; 2 = the step ended on its plain path: the counts are returned after this call has waited for them;
  * 1 = none available (the caller runs wcsph_state_classify as before) */

@@ -70,7 +70,8 @@ def test_the_librarys_migration_equals_the_torch_plan(n, g_old, n_ml, n_mr, a_l,
             if form == "library":
                 to_l, to_r = B.migrate_begin(counts)
                 sent = torch.cat([to_l, to_r]).clone()
-                out, send_all, ghost_all = B.migrate_end(in_l, a_l, in_r, a_r)
+                out = B.migrate_end(in_l, a_l, in_r, a_r)
+                send_all, ghost_all = B.halo_list_views()
                 n_new, n_sl, n_gl = out[0], out[1], out[3]
                 assert out[2] == n_nr + a_r and out[4] == g_r + n_mr
             else:

@@ -28,18 +28,25 @@ __device__ __forceinline__ void state_row_out(const Dev &d, int o, float *r) {
   r[9] = g.x; r[10] = g.y; r[11] = g.z; r[12] = d.kappa[i]; r[13] = d.kappa_v[i];
   r[14] = __int_as_float(d.gid ? d.gid[o] : o);
 }
-// out = [go_left | near_left | go_right | near_right] rows of STATE_W floats
+// out = [go_left | near_left | go_right | near_right] rows of STATE_W floats.  A row is 60 bytes: the 256 rows of a block go through
+// LDS so that the writes are contiguous (as k_store_state; written straight from the lanes it is a 60-byte-stride store)
 __global__ void __launch_bounds__(BLOCK) k_mig_gather(Dev d, MigLists m, float *out) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float sh[BLOCK * STATE_W];
   const int total = m.n_ml + m.n_nl + m.n_mr + m.n_nr;
-  if (k >= total) return;
-  float *r = out + (size_t)k * STATE_W;
-  long long o;
-  if (k < m.n_ml) o = m.gl[k];
-  else if ((k -= m.n_ml) < m.n_nl) o = m.nl[k];
-  else if ((k -= m.n_nl) < m.n_mr) o = m.gr[k];
-  else o = m.nr[k - m.n_mr];
-  state_row_out(d, (int)o, r);
+  const int k0 = blockIdx.x * BLOCK, cnt = min(BLOCK, total - k0);
+  if (cnt <= 0) return;
+  if ((int)threadIdx.x < cnt) {
+    int k = k0 + threadIdx.x;
+    long long o;
+    if (k < m.n_ml) o = m.gl[k];
+    else if ((k -= m.n_ml) < m.n_nl) o = m.nl[k];
+    else if ((k -= m.n_nl) < m.n_mr) o = m.gr[k];
+    else o = m.nr[k - m.n_mr];
+    state_row_out(d, (int)o, sh + threadIdx.x * STATE_W);
+  }
+  __syncthreads();
+  float *dst = out + (size_t)k0 * STATE_W;
+  for (int q = threadIdx.x; q < cnt * STATE_W; q += BLOCK) dst[q] = sh[q];
 }
 // a < k: the plan of the shrinking table.  ONE workgroup (the lists are a few thousand entries); work = hole_tail[L] | T[L] | dest[L].
 // dest[j] = the label that tail label n_new + j has afterwards (itself when it is an open hole: it falls off the end).

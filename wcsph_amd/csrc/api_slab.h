@@ -60,9 +60,10 @@ int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, 
   return WCSPH_OK;
 }
 }  // extern "C"
-__global__ void k_counts_to_host(const int *c, int *h, const int *pred, const int *nbr) {
+// (the counts are left ZERO for the next classification: no memset launch per step -- a fill kernel costs ~5 us)
+__global__ void k_counts_to_host(int *c, int *h, const int *pred, const int *nbr) {
   if (pred && *pred == 0) return;
-  if (threadIdx.x < 5) h[threadIdx.x] = c[threadIdx.x];
+  if (threadIdx.x < 5) { h[threadIdx.x] = c[threadIdx.x]; c[threadIdx.x] = 0; }
   if (nbr && threadIdx.x >= 8 && threadIdx.x < 24) h[threadIdx.x] = nbr[threadIdx.x - 8];
 }
 // wcsph_state_classify in the tail of wcsph_slab_step, gated like the launches around it; the counts go to pinned host memory
@@ -71,19 +72,21 @@ __global__ void k_counts_to_host(const int *c, int *h, const int *pred, const in
 // travel in the same mail -- the next migration then knows every message size without a header round trip (api_migrate.h)
 static int tail_classify(wcsph_ctx *ctx, const int *pred, NativeComm *native) {
   auto &t = ctx->tc;
-  HIPCHK(hipMemsetAsync(t.d_counts, 0, 5 * sizeof(int32_t), ctx->stream));
+  // The tail counts into the library's OWN five words (t.d_nbr + 16; the caller's d_counts belongs to wcsph_state_classify, which
+  // leaves its result there).  They are zero here: zeroed at allocation and by every k_counts_to_host that read them; a gated-off
+  // classification leaves them so.
+  int *const mine = t.d_nbr + 16;
   const long long n = ctx->d.n_owned;
   if (n > 0)
     hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)ctx->d.pos, n, 4,
-                       ctx->d.minx, ctx->d.inv_grid, t.lo, t.hi, t.ghost, t.has_l, t.has_r, t.d_idx, t.cap, t.d_counts, (const int *)ctx->d.where, pred);
+                       ctx->d.minx, ctx->d.inv_grid, t.lo, t.hi, t.ghost, t.has_l, t.has_r, t.d_idx, t.cap, mine, (const int *)ctx->d.where, pred);
   t.nbr_queued = false;
   if (native) {
-    if (!t.d_nbr) { HIPCHK(hipMalloc((void **)&t.d_nbr, 16 * sizeof(int))); HIPCHK(hipMemsetAsync(t.d_nbr, 0, 16 * sizeof(int), ctx->stream)); }
-    int rc = comm_counts_exchange(native, t.d_counts, t.d_nbr, ctx->stream);
+    int rc = comm_counts_exchange(native, mine, t.d_nbr, ctx->stream);
     if (rc) return rc;
     t.nbr_queued = true;
   }
-  hipLaunchKernelGGL(k_counts_to_host, dim3(1), dim3(WAVE), 0, ctx->stream, (const int *)t.d_counts, t.h_counts, pred, (const int *)(native ? t.d_nbr : nullptr));
+  hipLaunchKernelGGL(k_counts_to_host, dim3(1), dim3(WAVE), 0, ctx->stream, mine, t.h_counts, pred, (const int *)(native ? t.d_nbr : nullptr));
   LAUNCHCHK();
   return 0;
 }
@@ -109,6 +112,8 @@ int wcsph_slab_set_tail_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t
   if (!d_idx || !d_counts || cap <= 0) { t.on = false; return WCSPH_OK; }
   if (!t.h_counts) { HIPCHK(hipHostMalloc((void **)&t.h_counts, 32 * sizeof(int))); memset(t.h_counts, 0, 32 * sizeof(int)); }
   t.lo = lo; t.hi = hi; t.ghost = ghost; t.has_l = has_left; t.has_r = has_right; t.d_idx = (long long *)d_idx; t.cap = cap; t.d_counts = d_counts;
+  // [0..5) / [8..13): the left / right neighbour's counts (native plane); [16..21): this rank's, zero between two tails
+  if (!t.d_nbr) { HIPCHK(hipMalloc((void **)&t.d_nbr, 24 * sizeof(int))); HIPCHK(hipMemsetAsync(t.d_nbr, 0, 24 * sizeof(int), ctx->stream)); }
   t.on = true;
   return WCSPH_OK;
 }

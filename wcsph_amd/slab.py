@@ -180,14 +180,18 @@ class HipBackend:
     def _adopt_migration(self, out):
         out = [int(v) for v in out]
         self.n_owned = out[0]
+        return out
+
+    def halo_list_views(self):
+        """the halo lists the library has installed (wcsph_slab_halo_lists) as torch int32 views: (send list, ghost list)"""
         ps, pg, ns, ng = C.c_void_p(), C.c_void_p(), C.c_int32(), C.c_int32()
         self._chk(self.lib.wcsph_slab_halo_lists(self.ctx, C.byref(ps), C.byref(ns), C.byref(pg), C.byref(ng)))
         i32 = lambda ptr, n: (torch.as_tensor(_DevArray(ptr.value, n, "<i4"), device=self.device) if n else torch.zeros(0, dtype=torch.int32, device=self.device))   # noqa: E731
-        return out, i32(ps, ns.value), i32(pg, ng.value)
+        return i32(ps, ns.value), i32(pg, ng.value)
 
     def migrate_end(self, in_l, a_l, in_r, a_r):
         """what the neighbours sent (the first a_l / a_r rows of a message become this rank's): plan, rows and halo lists on the
-        device.  Returns ([n_owned, n_send_left, n_send_right, n_ghost_left, n_ghost_right], send list, ghost list)"""
+        device.  Returns [n_owned, n_send_left, n_send_right, n_ghost_left, n_ghost_right]; the halo lists are installed (halo_list_views)"""
         in_l, in_r = in_l.contiguous(), in_r.contiguous()
         out = (C.c_int32 * 5)()
         self._chk(self.lib.wcsph_slab_migrate_end(self.ctx, C.c_void_p(in_l.data_ptr()), int(in_l.shape[0]), int(a_l),
@@ -380,8 +384,10 @@ class HipBackend:
         lib, ctx = self.lib, self.ctx
         if getattr(self, "_cbs_for", None) is not sim:
             self._cbs, self._cbs_for = sim._make_callbacks(), sim
-        self._chk(lib.wcsph_slab_set_halo(ctx, C.c_void_p(sim.send_all.data_ptr()), int(sim.send_all.numel()),
-                                          C.c_void_p(sim.ghost_all.data_ptr()), int(sim.ghost_all.numel())))
+        lib_halo = sim.__dict__.get("_halo_lib") is not None      # installed by wcsph_slab_migrate(_end), split included
+        if not lib_halo:
+            self._chk(lib.wcsph_slab_set_halo(ctx, C.c_void_p(sim.send_all.data_ptr()), int(sim.send_all.numel()),
+                                              C.c_void_p(sim.ghost_all.data_ptr()), int(sim.ghost_all.numel())))
         self._chk(lib.wcsph_set_scalar(ctx, _lib.SCALAR_ID["deltaT"], float(sim.dt)))
         self._chk(lib.wcsph_set_scalar(ctx, _lib.SCALAR_ID["avg_density_err"], float(sim.avg_density_err)))
         self._chk(lib.wcsph_set_iters(ctx, int(sim.vs_iter), int(sim.dv_iter), int(sim.pr_iter)))
@@ -390,7 +396,8 @@ class HipBackend:
         sim._cb_exc = None
         if self.native_comm:
             # the library's own communicator: no callback, no Python between the library and RCCL
-            self._chk(lib.wcsph_comm_set_halo_split(ctx, int(sim.send_l.numel()), int(sim.ghost_l.numel())))
+            if not lib_halo:
+                self._chk(lib.wcsph_comm_set_halo_split(ctx, int(sim.send_l.numel()), int(sim.ghost_l.numel())))
             cbp = None
         else:
             cbp = C.byref(self._cbs)
@@ -433,8 +440,54 @@ def balanced_cuts(cellx_hist, world, min_width=GHOST_CELLS):
     return cuts
 
 
+class _HaloList:
+    """one of SlabSim's six halo index lists (int32 device tensors).  After a migration inside the library (csrc/api_migrate.h) the
+    lists live there and are installed already: a torch view is only made when somebody asks for one (the step itself does not:
+    two torch.as_tensor() of a __cuda_array_interface__ cost more host time per step than the migration's own calls)."""
+
+    def __init__(self, name):
+        self.key = "_h_" + name
+
+    def __get__(self, obj, typ=None):
+        if obj is None:
+            return self
+        v = obj.__dict__.get(self.key)
+        if v is None and obj.__dict__.get("_halo_lib") is not None:
+            obj._materialise_halo()
+            v = obj.__dict__.get(self.key)
+        return v
+
+    def __set__(self, obj, v):
+        obj.__dict__[self.key] = v
+        obj.__dict__["_halo_lib"] = None          # the driver's own lists: wcsph_slab_set_halo hands them over before the step
+
+
 class SlabSim:
     """The DFSPH step of dfsph.py:606-617 on one slab, with halo exchanges between phases."""
+    send_l, send_r, ghost_l, ghost_r, send_all, ghost_all = (_HaloList(k) for k in ("send_l", "send_r", "ghost_l", "ghost_r", "send_all", "ghost_all"))
+
+    def _halo_counts(self):
+        """(rows sent per refresh, ghost rows, of them to / from the left neighbour) without touching the lists"""
+        lib = self.__dict__.get("_halo_lib")
+        if lib is not None:
+            return lib[0] + lib[1], lib[2] + lib[3], lib[0], lib[2]
+        return int(self.send_all.numel()), int(self.ghost_all.numel()), int(self.send_l.numel()), int(self.ghost_l.numel())
+
+    def _materialise_halo(self):
+        n_sl, n_sr, n_gl, n_gr = self._halo_lib
+        send_all, ghost_all = self.B.halo_list_views()
+        d = self.__dict__
+        d["_h_send_all"], d["_h_ghost_all"] = send_all, ghost_all
+        d["_h_send_l"], d["_h_send_r"] = send_all[:n_sl], send_all[n_sl:]
+        d["_h_ghost_l"], d["_h_ghost_r"] = ghost_all[:n_gl], ghost_all[n_gl:]
+
+    def _adopt_library_halo(self, out):
+        """the lists wcsph_slab_migrate(_end) left installed: out = [n_owned, n_send_left, n_send_right, n_ghost_left, n_ghost_right]"""
+        d = self.__dict__
+        for k in ("send_l", "send_r", "ghost_l", "ghost_r", "send_all", "ghost_all"):
+            d["_h_" + k] = None
+        d["_halo_lib"] = (out[1], out[2], out[3], out[4])
+        self.n_owned = out[0]
 
     def __init__(self, backend_factory, liquid_local, solid_all, bounds, cuts, n_global, rank, world,
                  particleR=0.025, device=None, capacity_factor=1.6, group=None, comm_device=None,
@@ -766,11 +819,12 @@ class SlabSim:
 
     def _halo_buffers(self, W):
         """send / receive buffers of a halo refresh of total row width W, allocated once per (W, ghost layout)"""
-        key = (W, self.send_all.numel(), self.ghost_all.numel())
+        n_send, n_ghost = self._halo_counts()[:2]
+        key = (W, n_send, n_ghost)
         b = self._hb.get(W)
         if b is None or b[0] != key:
-            b = (key, torch.empty((self.send_all.numel(), W), dtype=torch.float32, device=self.device),
-                 torch.empty((self.ghost_all.numel(), W), dtype=torch.float32, device=self.device))
+            b = (key, torch.empty((n_send, W), dtype=torch.float32, device=self.device),
+                 torch.empty((n_ghost, W), dtype=torch.float32, device=self.device))
             self._hb[W] = b
         return b[1], b[2]
 
@@ -786,7 +840,7 @@ class SlabSim:
         B = self.B
         W = sum(FIELD_W.get(f, 1) for f in fields)
         out, inc = self._halo_buffers(W)
-        nl, ngl = self.send_l.numel(), self.ghost_l.numel()
+        nl, ngl = self._halo_counts()[2:]
         if hasattr(B, "pack_rows"):
             B.pack_rows(fields, self.send_all, out)                        # ONE pack kernel for all fields, both neighbours
         else:
@@ -873,7 +927,7 @@ class SlabSim:
 
         def post(_u, W):
             out, inc = self._cb_buf
-            nl, ngl = self.send_l.numel(), self.ghost_l.numel()
+            nl, ngl = self._halo_counts()[2:]
             self._cb_pending = self._post(out[:nl], out[nl:], inc[:ngl], inc[ngl:])
 
         def wait(_u):
@@ -1031,18 +1085,16 @@ class SlabSim:
             # exact sizes; otherwise header + rows over this rank's communicator as before.
             nbr = B.tail_neighbour_counts() if (getattr(B, "native_comm", False) and self.native_migrate) else None
             if nbr is not None:
-                out, self.send_all, self.ghost_all = B.migrate_native(native[0], nbr[0], nbr[1])
+                out = B.migrate_native(native[0], nbr[0], nbr[1])
                 self.n_exchanges += 1
                 self.n_native_migrations = getattr(self, "n_native_migrations", 0) + 1
                 self.n_rows_arrived += (nbr[0][3] if has_l else 0) + (nbr[1][2] if has_r else 0)
             else:
                 to_l, to_r = B.migrate_begin(native[0])
                 in_l, in_r, hl, hr = self._exchange_var(to_l, to_r, (n_ml,), (n_mr,))
-                out, self.send_all, self.ghost_all = B.migrate_end(in_l, int(hl[0]), in_r, int(hr[0]))
+                out = B.migrate_end(in_l, int(hl[0]), in_r, int(hr[0]))
                 self.n_rows_arrived += int(hl[0]) + int(hr[0])
-            self.n_owned, n_sl, n_gl = out[0], out[1], out[3]
-            self.send_l, self.send_r = self.send_all[:n_sl], self.send_all[n_sl:]
-            self.ghost_l, self.ghost_r = self.ghost_all[:n_gl], self.ghost_all[n_gl:]
+            self._adopt_library_halo(out)
             return
         out = B.gather_state_rows(torch.cat([idx_gl, idx_nl, idx_gr, idx_nr]))
         to_l, to_r = out[:n_ml + n_nl], out[n_ml + n_nl:]
