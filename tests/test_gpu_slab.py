@@ -73,10 +73,10 @@ def test_hip_slab_ranks_match_one_rank(tmp_path, world, n):
     """world = 3: an INTERIOR rank (two neighbours, ghosts and migration on both sides); the block drifts at 4 m/s, so
     rows cross both cuts during the run"""
     import slab_util
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     out = str(tmp_path)
     _hip_run(0, 1, 0, out, n)
-    mp.spawn(_hip_run, args=(world, _free_port(), out, n), nprocs=world, join=True)
+    spawn_ranks(_hip_run, world, out, n)
     one = np.load(os.path.join(out, "hrows_w1_r0.npy"))
     many = np.concatenate([np.load(os.path.join(out, "hrows_w%d_r%d.npy" % (world, r))) for r in range(world)])
     assert len(one) == len(many) == n ** 3
@@ -97,13 +97,13 @@ def test_faithful_slabs_reproduce_the_single_context(tmp_path):
     (with a forced rebalance on the way) must reproduce one rank, and one rank must reproduce the plain library step --
     density to the north-star 1e-4."""
     import slab_util
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     from util import GpuSim
     n, out = 10, str(tmp_path)
     os.environ.update(SLAB_TEST_MODE="faithful", SLAB_TEST_REBALANCE_AT="3")
     try:
         _hip_run(0, 1, 0, out, n)
-        mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+        spawn_ranks(_hip_run, 2, out, n)
     finally:
         os.environ.pop("SLAB_TEST_MODE", None); os.environ.pop("SLAB_TEST_REBALANCE_AT", None)
     one = np.load(os.path.join(out, "hrows_w1_r0.npy"))
@@ -133,7 +133,7 @@ def test_faithful_slabs_reproduce_the_single_context(tmp_path):
 def test_overlapped_halo_exchange_changes_nothing(tmp_path):
     """WCSPH_SLAB_OVERLAP: every neighbour pass that needs a halo refresh runs on the slab interior while the exchange is
     in flight and on the rest afterwards -- same particles, same inputs, same results as exchange-then-pass."""
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     n = 14
     outs = []
     for flag in ("0", "1"):
@@ -141,7 +141,7 @@ def test_overlapped_halo_exchange_changes_nothing(tmp_path):
         os.makedirs(out)
         os.environ["WCSPH_SLAB_OVERLAP"] = flag
         try:
-            mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+            spawn_ranks(_hip_run, 2, out, n)
         finally:
             os.environ.pop("WCSPH_SLAB_OVERLAP", None)
         outs.append(out)
@@ -164,7 +164,7 @@ def test_native_slab_step_equals_the_python_phase_driver(tmp_path, mode):
     SlabSim._step's phase-by-phase Python form (WCSPH_SLAB_NATIVE=0), two ranks: same launches in the same order, so the
     same iteration counts, dt history and -- up to the order of the atomics -- the same rows."""
     import slab_util
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     n, outs = 10, []
     os.environ["SLAB_TEST_MODE"] = mode
     try:
@@ -172,7 +172,7 @@ def test_native_slab_step_equals_the_python_phase_driver(tmp_path, mode):
             out = os.path.join(str(tmp_path), "native" + native)
             os.makedirs(out)
             os.environ["WCSPH_SLAB_NATIVE"] = native
-            mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+            spawn_ranks(_hip_run, 2, out, n)
             outs.append(out)
     finally:
         os.environ.pop("WCSPH_SLAB_NATIVE", None); os.environ.pop("SLAB_TEST_MODE", None)
@@ -192,7 +192,7 @@ def test_speculative_slab_step_changes_nothing_and_hides_the_decisions(tmp_path,
     waits with an idle GPU behind them drop from >= 4 per step to the step's last mail (+ 1 for the row classification)
     wherever the common case holds."""
     import slab_util
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     n, outs = 12, []
     os.environ["SLAB_TEST_MODE"] = mode
     try:
@@ -200,7 +200,7 @@ def test_speculative_slab_step_changes_nothing_and_hides_the_decisions(tmp_path,
             out = os.path.join(str(tmp_path), "spec" + spec)
             os.makedirs(out)
             os.environ["WCSPH_SLAB_SPECULATE"] = spec
-            mp.spawn(_hip_run, args=(2, _free_port(), out, n), nprocs=2, join=True)
+            spawn_ranks(_hip_run, 2, out, n)
             outs.append(out)
     finally:
         os.environ.pop("WCSPH_SLAB_SPECULATE", None); os.environ.pop("SLAB_TEST_MODE", None)
@@ -226,14 +226,14 @@ def test_tail_classification_saves_a_host_wait_and_changes_nothing(tmp_path):
     own.  Three ranks, rows crossing both cuts: against WCSPH_SLAB_TAIL_CLASSIFY=0 the same rows, iteration counts and dt, and
     fewer host waits."""
     import slab_util
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     n, outs = 12, []
     try:
         for tail in ("1", "0"):
             out = os.path.join(str(tmp_path), "tail" + tail)
             os.makedirs(out)
             os.environ["WCSPH_SLAB_TAIL_CLASSIFY"] = tail
-            mp.spawn(_hip_run, args=(3, _free_port(), out, n), nprocs=3, join=True)
+            spawn_ranks(_hip_run, 3, out, n)
             outs.append(out)
     finally:
         os.environ.pop("WCSPH_SLAB_TAIL_CLASSIFY", None)
@@ -294,7 +294,7 @@ def test_resident_slab_state_equals_the_row_table_round_trip(tmp_path):
     -- instead of storing and reloading every row (WCSPH_SLAB_RESIDENT=0: rounds 2-4).  Three ranks, rows crossing both cuts of the
     interior rank, a forced rebalance on the way: the two forms agree to rounding level, and the resident form really ran."""
     import slab_util
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     n, world = 12, 3
     res = {}
     for flag in ("1", "0"):
@@ -302,7 +302,7 @@ def test_resident_slab_state_equals_the_row_table_round_trip(tmp_path):
         os.makedirs(out)
         os.environ.update(WCSPH_SLAB_RESIDENT=flag, SLAB_TEST_REBALANCE_AT="3")
         try:
-            mp.spawn(_hip_run, args=(world, _free_port(), out, n), nprocs=world, join=True)
+            spawn_ranks(_hip_run, world, out, n)
         finally:
             os.environ.pop("WCSPH_SLAB_RESIDENT", None); os.environ.pop("SLAB_TEST_REBALANCE_AT", None)
         rows = np.concatenate([np.load(os.path.join(out, "hrows_w%d_r%d.npy" % (world, r))) for r in range(world)])

@@ -89,9 +89,9 @@ def test_C4_16M_eight_slabs_match_one_context(tmp_path, n, world):
     free, total = torch.cuda.mem_get_info(0)
     if free < 80 * 2 ** 30:
         pytest.skip("needs ~80 GB of free device memory (8 slab contexts of ~8 GB each)")
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     out = str(tmp_path)
-    mp.spawn(_rank, args=(world, _free_port(), out, n), nprocs=world, join=True)
+    spawn_ranks(_rank, world, out, n)
     logs = [np.load(os.path.join(out, "c4log_r%d.npy" % r)) for r in range(world)]
     for r in range(1, world):
         np.testing.assert_array_equal(logs[0][:, :3], logs[r][:, :3])          # (vs, dv, pr) equal on every rank
@@ -193,10 +193,10 @@ def test_C4_16M_eight_slabs_on_a_live_state_match_one_context(tmp_path):
     free, total = torch.cuda.mem_get_info(0)
     if free < 80 * 2 ** 30:
         pytest.skip("needs ~80 GB of free device memory (8 slab contexts of ~8 GB each)")
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     from wcsph_amd import dfsph, scene
     out = str(tmp_path)
-    mp.spawn(_rank_live, args=(world, _free_port(), out, n), nprocs=world, join=True)
+    spawn_ranks(_rank_live, world, out, n)
     logs = [np.load(os.path.join(out, "c4llog_r%d.npy" % r)) for r in range(world)]
     for r in range(1, world):
         np.testing.assert_array_equal(logs[0][:, :3], logs[r][:, :3])

@@ -69,14 +69,14 @@ def _slab_run(rank, world, port, outdir):
 
 @pytest.mark.parametrize("MODE", ["clean", "faithful"])
 def test_three_slabs_on_a_live_squeezed_state_equal_the_single_context(tmp_path, MODE):
-    from test_slab_gloo import _free_port
+    from test_slab_gloo import spawn_ranks
     from scipy.spatial import cKDTree
     from oracle import Oracle
     from wcsph_amd import dfsph
     out, world = str(tmp_path), 3
     os.environ["SLAB_LIVE_MODE"] = MODE
     try:
-        mp.spawn(_slab_run, args=(world, _free_port(), out), nprocs=world, join=True)
+        spawn_ranks(_slab_run, world, out)
     finally:
         os.environ.pop("SLAB_LIVE_MODE", None)
     liquid, solid, bounds, vel0, omega0 = _scene()
