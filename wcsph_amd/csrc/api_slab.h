@@ -52,8 +52,12 @@ int wcsph_state_classify(wcsph_ctx *ctx, int32_t lo, int32_t hi, int32_t ghost, 
   if (cap < 0 || !d_idx || !d_counts) return WCSPH_EARG;
   if (ctx->nl_phys > 0) return ctx->fail(WCSPH_EARG, "wcsph_state_classify: the state has pending changes (wcsph_state_apply) that no grid update has sorted in yet");
   HIPCHK(hipMemsetAsync(d_counts, 0, 5 * sizeof(int32_t), ctx->stream));
+  // (in sorted order when the state is sorted -- always between two steps of wcsph_slab_step --, through where[] right after a load)
   const long long n = ctx->d.n_owned;
-  if (n > 0)
+  if (n > 0 && ctx->grid_valid)
+    hipLaunchKernelGGL(k_state_classify_sorted, dim3((unsigned)((ctx->d.nl + BLOCK * CLS_ROWS_SORTED - 1) / (BLOCK * CLS_ROWS_SORTED))), dim3(BLOCK), 0, ctx->stream, (const float4 *)ctx->d.pos,
+                       (const int *)ctx->d.oid, ctx->d.nl, ctx->d.n_owned, ctx->d.minx, ctx->d.inv_grid, lo, hi, ghost, has_left, has_right, (long long *)d_idx, cap, d_counts, (const int *)nullptr);
+  else if (n > 0)
     hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)ctx->d.pos, n, 4,
                        ctx->d.minx, ctx->d.inv_grid, lo, hi, ghost, has_left, has_right, (long long *)d_idx, cap, d_counts, (const int *)ctx->d.where);
   LAUNCHCHK();
@@ -76,10 +80,10 @@ static int tail_classify(wcsph_ctx *ctx, const int *pred, NativeComm *native) {
   // leaves its result there).  They are zero here: zeroed at allocation and by every k_counts_to_host that read them; a gated-off
   // classification leaves them so.
   int *const mine = t.d_nbr + 16;
-  const long long n = ctx->d.n_owned;
-  if (n > 0)
-    hipLaunchKernelGGL(k_slab_classify, dim3((unsigned)((n + BLOCK * CLS_ROWS - 1) / (BLOCK * CLS_ROWS))), dim3(BLOCK), 0, ctx->stream, (const float *)ctx->d.pos, n, 4,
-                       ctx->d.minx, ctx->d.inv_grid, t.lo, t.hi, t.ghost, t.has_l, t.has_r, t.d_idx, t.cap, mine, (const int *)ctx->d.where, pred);
+  // (the step has just written the positions in sorted order: walked so, coalesced -- k_state_classify_sorted)
+  if (ctx->d.n_owned > 0)
+    hipLaunchKernelGGL(k_state_classify_sorted, dim3((unsigned)((ctx->d.nl + BLOCK * CLS_ROWS_SORTED - 1) / (BLOCK * CLS_ROWS_SORTED))), dim3(BLOCK), 0, ctx->stream, (const float4 *)ctx->d.pos,
+                       (const int *)ctx->d.oid, ctx->d.nl, ctx->d.n_owned, ctx->d.minx, ctx->d.inv_grid, t.lo, t.hi, t.ghost, t.has_l, t.has_r, t.d_idx, t.cap, mine, pred);
   t.nbr_queued = false;
   if (native) {
     int rc = comm_counts_exchange(native, mine, t.d_nbr, ctx->stream);

@@ -863,6 +863,64 @@ __global__ void __launch_bounds__(BLOCK) k_slab_classify(const float *rows, long
   }
 }
 
+// the same classification over the context's OWN rows, walked in SORTED order: pos[i] and oid[i] are read coalesced (the form above
+// reaches a row through where[]: a 16-byte gather per row, 23 us at 2 M rows against ~10); a row's label is its original index
+// oid[i], ghost rows (label >= n_owned) are skipped.  The lists hold the same sets; their order is arbitrary in both forms.
+constexpr int CLS_ROWS_SORTED = 4;   // (16 rows per thread leave 560 workgroups at 2.3 M rows: 2 waves per SIMD, latency-bound; 4: 2240)
+__global__ void __launch_bounds__(BLOCK) k_state_classify_sorted(const float4 *pos, const int *oid, int nl, int n_owned, float minx, float inv_grid, int lo, int hi, int ghost,
+                                                                 int has_l, int has_r, long long *idx, int cap, int *counts, const int *pred) {
+  if (pred && *pred == 0) return;
+  __shared__ int cnt[5], base[5];
+  if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int first = blockIdx.x * (BLOCK * CLS_ROWS_SORTED) + threadIdx.x;
+  unsigned long long cls_of = 0;      // 4 bits per row: class + 1, 0 = interior
+  int at[CLS_ROWS_SORTED], lab[CLS_ROWS_SORTED];
+  float xs[CLS_ROWS_SORTED];
+  // every load of the thread is issued before anything is classified (label and position of a row do not wait for each other)
+#pragma unroll
+  for (int r = 0; r < CLS_ROWS_SORTED; r++) {
+    const int i = first + r * BLOCK;
+    lab[r] = i < nl ? oid[i] : 0x7fffffff;
+    xs[r] = i < nl ? reinterpret_cast<const float *>(pos + i)[0] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < CLS_ROWS_SORTED; r++) {
+    int cls = -1;
+    if (lab[r] < n_owned) {
+      const int cx = (int)__fmul_rn(__fsub_rn(xs[r], minx), inv_grid);
+      if (has_l) { if (cx < lo + ghost) cls = 0; if (cx < lo) cls = 2; if (cx < lo - ghost) cls = 4; }
+      if (has_r) { if (cx >= hi - ghost) cls = 1; if (cx >= hi) cls = 3; if (cx >= hi + ghost) cls = 4; }
+    }
+    // in sorted order the rows next to a cut sit side by side: a wave of them would queue 64 LDS atomics on ONE counter per row
+    // (the whole kernel then runs at the pace of its few boundary blocks).  One atomic per wave and class instead.
+    at[r] = 0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+      if (m) {     // wave-uniform
+        const int lane = threadIdx.x & (WAVE - 1), leader = __builtin_ctzll(m);
+        int b = 0;
+        if (lane == leader) b = atomicAdd(&cnt[c], __builtin_popcountll(m));
+        b = __shfl(b, leader, WAVE);
+        if (cls == c) at[r] = b + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      }
+    }
+    cls_of |= (unsigned long long)(cls + 1) << (4 * r);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < CLS_ROWS_SORTED; r++) {
+    const int cls = (int)((cls_of >> (4 * r)) & 15) - 1;
+    if (cls >= 0 && cls < 4) {
+      const int o = base[cls] + at[r];
+      if (o < cap) idx[(size_t)cls * cap + o] = lab[r];
+    }
+  }
+}
+
 // halo pack / unpack of SEVERAL fields in one launch: out[k][W] = the listed fields of original row idx[k], side by side
 struct HaloFields { int n; const float *ptr[8]; int width[8], stride[8]; int W; const int *pred; };   // pred: as Dev::pred (speculative slab step)
 __global__ void k_halo_pack(HaloFields h, const int *where, const int *idx, int n, float *out) {
