@@ -24,6 +24,9 @@ KINDS = [
     (r"c5", "config C5 (tension on) kernel statistics"),
     (r"tile", "LDS tile walk experiment (round 5)"),
     (r"r06_(overlap|cluster_pair|developed)\.md$", "round-6 write-up (what was built, measured, concluded)"),
+    (r"hw_queues", "stream / hardware-queue hazard of the sixth context of a process (`r06_overlap.md`)"),
+    (r"step_boundary", "kernel trace of the step boundary of the periodic ring (`tools/r06_step_boundary.sh`, `rocpd_step_boundary.py`)"),
+    (r"smoke", "`__graft_entry__.smoke()` log"),
     (r"migrate_plan", "`pytest -m gpu tests/test_gpu_migrate_plan.py` log"),
     (r"overlap|ring_gaps|ring", "halo / compute overlap on the loop-back ring of C4's per-rank shape (`tools/overlap_ring.py`, `rocpd_overlap.py`, `rocpd_ring_steps.py`)"),
     (r"prio_probe", "micro-benchmark (`tools/micro/*`) or GPU-idle analysis"),
@@ -58,6 +61,7 @@ says otherwise.  (Regenerate with `python tools/profiles_index.py`.)
 | `r06z_slab_overhead.txt`, `r06z_slab_nccl_world1.json`, `r06z_bench_two_ranks_one_gpu_gloo.json` | slab driver on one GPU: +0.010 ... 0.014 ms (clean) over the fused step on either plane; the bench path on the real RCCL backend with one rank incl. the schedule tuning; two ranks on one GPU over gloo (2.2 host waits per step, stdout = the one JSON line) |
 | `r06z_live_parity.log`, `r06z_gputests.log` | the live-state parity numbers themselves (flip candidates, quantiles, 3 slabs and C4's 8 slabs against one context, native plane schedules against the callback plane); `pytest -m gpu` on the final source: 136 passed, 1 skipped |
 | `r06f_*` (same file names as `r06z_*`), `r06f_ring_real.json`, `r06f_ring_real_nosync.json`, `r06f_migrate_plan_tests.log` | the campaign repeated on the round's FINAL source (migration + ghost rebuild inside the library, `csrc/api_migrate.h`): 1242 M / 1012-1018 M / 605 M, `pressure_iter` 137.9 us = 0.174, 145 GPU tests passed; the periodic ring driven by the real migration code: host waits per step 2.0 -> 1.0, redistribute 0.25 ms (torch plan) -> 0.145 (library plan behind the caller's exchange) -> 0.107 (`wcsph_slab_migrate` over RCCL), every variant bit-identical; `_nosync`: the same steps without the measurement's synchronisations (2.87 -> 2.67 ms per step) |
+| `r06h_*` | the last campaign of the round (`tools/campaign_r06_final.sh`) after the step boundary's clean-up (lazy halo-list views, sorted-order classification, no fill launch): 1257 M / 1017 M / 609 M, `pytest -m gpu` twice 146 passed; ring with the real migration 2.62 ms per step on the native inline plane against 2.84 (torch plan, callbacks); `r06h_step_boundary.txt`, `r06h_sixth_context_hw_queues.json` (a stream / hardware-queue hazard of processes that create six contexts, see `r06_overlap.md`) |
 | `r06_compiler_sched_flags.txt` | seven LLVM scheduling strategies / biases on the whole library: none helps |
 | `r05_lds_tile_experiment.md`, `r04_experiments.md`, `r03_experiments.md`, `r02b_wave_brick_experiment.md` | every earlier measured-and-rejected idea with its counters |
 
