@@ -27,6 +27,11 @@ import time
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL and device-tensor sharing fail with hipIpcGetMemHandle: invalid
 # argument otherwise); the driver's environment exports it already -- keep it for every other launcher, before HIP starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# a rank of a decomposition drives five streams (compute, the communicator's halo and side streams, torch's own, the null stream); HIP
+# maps a process's streams onto FOUR hardware queues by default, and two dependent streams that share one pay ~260 us per cross-stream
+# event wait (profiles/r06_overlap.md, "a hazard found ...").  Eight queues for the multi-rank launch only: the 1-GPU run has one stream.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
