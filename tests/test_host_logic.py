@@ -161,3 +161,33 @@ def test_fd_level_stdout_redirect_keeps_the_json_channel_clean(capfd):
     os.write(1, b"{}\\n")
     out, err = capfd.readouterr()
     assert out == "{}\\n" and "Gloo" in err
+
+
+def test_halo_lists_of_a_library_migration_are_materialised_lazily_and_driver_lists_take_over():
+    """SlabSim's six halo lists (wcsph_amd/slab.py _HaloList): after a migration inside the library only the counts are known to the
+    driver and no torch view exists until somebody asks; assigning a list by hand (the torch path, the tools) switches back to the
+    driver's own lists, which the next step hands to the library again."""
+    import torch
+    from wcsph_amd.slab import SlabSim
+
+    class FakeBackend:
+        calls = 0
+
+        def halo_list_views(self):
+            FakeBackend.calls += 1
+            return torch.arange(10, dtype=torch.int32), torch.arange(100, 107, dtype=torch.int32)
+
+    sim = SlabSim.__new__(SlabSim)
+    sim.B = FakeBackend()
+    assert sim.send_all is None                                   # nothing set yet
+    sim._adopt_library_halo([1234, 6, 4, 3, 4])
+    assert sim.n_owned == 1234 and sim._halo_counts() == (10, 7, 6, 3) and FakeBackend.calls == 0
+    assert sim.send_l.tolist() == [0, 1, 2, 3, 4, 5] and sim.send_r.tolist() == [6, 7, 8, 9]
+    assert sim.ghost_l.tolist() == [100, 101, 102] and sim.ghost_r.tolist() == [103, 104, 105, 106]
+    assert sim.send_all.numel() == 10 and sim.ghost_all.numel() == 7 and FakeBackend.calls == 1      # one materialisation serves all six
+    assert sim.__dict__["_halo_lib"] is not None                  # reading does not take the lists away from the library
+    sim.send_l = torch.zeros(2, dtype=torch.int32)                # a driver that sets its own lists ...
+    assert sim.__dict__["_halo_lib"] is None                      # ... owns them from then on (wcsph_slab_set_halo before the step)
+    sim.send_r = torch.zeros(1, dtype=torch.int32); sim.send_all = torch.zeros(3, dtype=torch.int32)
+    sim.ghost_l = sim.ghost_r = torch.zeros(0, dtype=torch.int32); sim.ghost_all = torch.zeros(0, dtype=torch.int32)
+    assert sim._halo_counts() == (3, 0, 2, 0)
