@@ -139,3 +139,42 @@ def test_a_classification_list_longer_than_its_buffer_gets_a_larger_buffer():
     for w, have in zip(want, lists):
         np.testing.assert_array_equal(np.sort(have.cpu().numpy()), w)
     B.close()
+
+
+def test_migration_entry_points_refuse_what_they_cannot_do():
+    """wrong call order, lists longer than their buffer, a CFL violation, no communicator: error codes with a message, no launch"""
+    import slab_util
+    from wcsph_amd import _lib
+    from wcsph_amd.slab import HipBackend, STATE_W
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    _liquid, solid, bounds = slab_util.test_scene(8)
+    B = HipBackend(capacity=4000, solid_local=solid, bounds=bounds, window=(0, 17), particleR=0.025, device=dev)
+    lib, ctx = B.lib, B.ctx
+    with torch.cuda.stream(B.stream):
+        B.load_state(1000, torch.from_numpy(_state(1200, 5, bounds, (2, 14))).to(dev))
+        B._cls_idx = torch.zeros((4, 64), dtype=torch.int64, device=dev)
+        out = (C.c_int32 * 5)()
+        z = torch.zeros((4, STATE_W), dtype=torch.float32, device=dev)
+        rc = lib.wcsph_slab_migrate_end(ctx, C.c_void_p(z.data_ptr()), 0, 0, C.c_void_p(z.data_ptr()), 0, 0, C.byref(out))
+        assert rc == -1 and b"without wcsph_slab_migrate_begin" in lib.wcsph_last_error(ctx)
+        with pytest.raises(_lib.WcsphError, match="longer than its buffer"):
+            B.migrate_begin([65, 0, 0, 0, 0])
+        with pytest.raises(_lib.WcsphError, match="CFL"):
+            B.migrate_begin([1, 0, 0, 0, 3])
+        five = (C.c_int32 * 5)(0, 0, 0, 0, 0)
+        rc = lib.wcsph_slab_migrate(ctx, C.c_void_p(B._cls_idx.data_ptr()), 64, C.byref(five), C.byref(five), C.byref(five), C.byref(out))
+        assert rc == -1 and b"no native communicator" in lib.wcsph_last_error(ctx)
+        # a valid begin / end with nothing travelling leaves the state as it was, and only a grid update may follow
+        to_l, to_r = B.migrate_begin([0, 0, 0, 0, 0])
+        assert to_l.shape == (0, STATE_W) and to_r.shape == (0, STATE_W)
+        rc = lib.wcsph_slab_migrate_end(ctx, None, 0, 1, None, 0, 0, C.byref(out))          # more arrivals than rows in the message
+        assert rc == -1
+        res = B.migrate_end(z[:0], 0, z[:0], 0)
+        assert res == [1000, 0, 0, 0, 0]
+        with pytest.raises(_lib.WcsphError, match="pending changes"):
+            B.store_state()
+        B.grid_update()
+        assert B.store_state().shape[0] == 1000
+        torch.cuda.synchronize()
+    B.close()
